@@ -1,0 +1,21 @@
+/* csadp_kernels.h -- host-callable launchers of the HIP kernels (csadp_kernels.hip). */
+#ifndef CSADP_KERNELS_H
+#define CSADP_KERNELS_H
+
+#include <hip/hip_runtime_api.h>
+
+#include "csadp_device.h"
+
+namespace csadp {
+
+/* Launch one tile anti-diagonal: ntiles single-wave workgroups.  C = columns per lane
+ * (16 or 32), TR = steps per tile (64, 128 or 256). */
+hipError_t launch_fill(int C, int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles,
+                       hipStream_t st);
+
+/* Launch the direction walk: one wave per job. */
+hipError_t launch_traceback(int C, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st);
+
+}  // namespace csadp
+
+#endif

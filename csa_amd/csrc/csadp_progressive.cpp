@@ -1,0 +1,434 @@
+/*
+ * csadp_progressive.cpp -- host side of one ProgressiveDP task (see csadp_progressive.h).
+ * Line numbers cite /root/reference/source/dynamicprogramming.c unless stated otherwise.
+ */
+#include "csadp_progressive.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "csadp_device.h"
+
+namespace csadp {
+
+namespace {
+
+constexpr int kSym = 5;   /* A C G T - (:9-12) */
+constexpr int kGap = 4;
+
+/* compiled-in scores of the reference (:16-19) */
+constexpr int kMatch = +1, kDoubleGap = 0, kMismatch = -1, kIndel = -1;
+
+inline int code_of(char ch)   /* :74-85 */
+{
+	switch (ch) {
+	case 'A': return 0;
+	case 'C': return 1;
+	case 'G': return 2;
+	case 'T': return 3;
+	case '-': return 4;
+	default: return -1;
+	}
+}
+
+}  // namespace
+
+/* CharAt, alignment.c:16-20 */
+char Progressive::char_at(int pos, int seq) const
+{
+	int i = task_->rotations[seq] + pos;
+	if (i >= task_->textsizes[seq]) i -= task_->textsizes[seq];
+	return task_->texts[seq][i];
+}
+
+int Progressive::init(const csadp_task &task)
+{
+	task_ = &task;
+	nseq_ = task.nseq;
+	if (nseq_ < 2 || nseq_ > CSADP_MAX_SEQS) return CSADP_ERR_ARG;
+	if (!task.texts || !task.textsizes || !task.rotations || !task.starts || !task.ends) return CSADP_ERR_ARG;
+	int maxgap = 0;
+	for (int s = 0; s < nseq_; ++s) {
+		const int size = task.textsizes[s];
+		if (!task.texts[s] || size < 0) return CSADP_ERR_ARG;
+		if (task.starts[s] < 0 || task.ends[s] < task.starts[s] || task.ends[s] > size) return CSADP_ERR_ARG;
+		if (task.ends[s] > task.starts[s] && (task.rotations[s] < 0 || task.rotations[s] >= size)) return CSADP_ERR_ARG;
+		maxgap = std::max(maxgap, task.ends[s] - task.starts[s]);
+		for (int p = task.starts[s]; p < task.ends[s]; ++p) {
+			const int c = code_of(char_at(p, s));
+			if (c < 0 || c > 3) return CSADP_ERR_ALPHABET;   /* reference: scorevector[][-1], UB */
+		}
+	}
+	order_.resize(nseq_);
+	len_.resize(nseq_);
+	str_.assign(nseq_, std::string());
+	have_.assign(nseq_, 0);
+	if (maxgap == 0) {           /* :916 */
+		empty_task_ = true;
+		step_ = nseq_;
+		return CSADP_OK;
+	}
+	/* SortSequencesForDP :286-307 -- selection sort with swap (not stable) */
+	for (int i = 0; i < nseq_; ++i) {
+		order_[i] = i;
+		len_[i] = task.ends[i] - task.starts[i];
+	}
+	for (int i = 0; i < nseq_ - 1; ++i) {
+		int minpos = i;
+		for (int j = i + 1; j < nseq_; ++j)
+			if (len_[j] < len_[minpos]) minpos = j;
+		if (minpos != i) {
+			std::swap(order_[i], order_[minpos]);
+			std::swap(len_[i], len_[minpos]);
+		}
+	}
+	/* seed the profile with the shortest sequence, :926-944 */
+	consensus_ = len_[0];
+	prevconsensus_ = 0;
+	prevnrows_ = 0;
+	sv_.assign((size_t)(consensus_ + 1) * kSym, 0);
+	const int n = order_[0];
+	str_[n].resize(consensus_);
+	have_[n] = 1;
+	for (int m = 1; m <= consensus_; ++m) {
+		const char ch = char_at(task.starts[n] + m - 1, n);
+		str_[n][m - 1] = ch;
+		sv_[(size_t)m * kSym + code_of(ch)]++;
+	}
+	step_ = 1;
+	pending_ = false;
+	return CSADP_OK;
+}
+
+bool Progressive::next_fill()
+{
+	if (pending_) return true;
+	while (step_ < nseq_) {
+		const int n = order_[step_];
+		nrows_ = len_[step_];
+		if (nrows_ == 0) {                                 /* :950-956: all gaps, profile untouched */
+			str_[n].assign((size_t)consensus_, '-');
+			have_[n] = 1;
+			++step_;
+			continue;
+		}
+		if (consensus_ != prevconsensus_ || nrows_ > prevnrows_) {   /* :957 */
+			border_top_.resize((size_t)consensus_ + 1);
+			int colgap = 0;
+			border_top_[0] = 0;
+			for (int k = 1; k <= consensus_; ++k) {               /* :969-973 */
+				const int g = sv_[(size_t)k * kSym + kGap];
+				colgap += kDoubleGap * g + kIndel * (step_ - g);
+				border_top_[k] = colgap;
+			}
+			border_i_ = step_;                                    /* :963,:967 */
+			prevnrows_ = nrows_;                                  /* :986 */
+			stale_ = false;
+		} else {
+			stale_ = true;
+		}
+		pending_ = true;
+		return true;
+	}
+	return false;
+}
+
+void Progressive::write_tables(uint32_t *coltab, int ncols_pad, uint8_t *rowshift, int32_t *top) const
+{
+	const int i = step_;
+	const int ncols = consensus_;
+	for (int k = 1; k <= ncols; ++k) {
+		const int *col = &sv_[(size_t)k * kSym];
+		uint32_t w = 0;
+		for (int c = 0; c < 4; ++c) w |= (uint32_t)((i - col[c]) & 63) << (6 * c);
+		w |= (uint32_t)((i - col[kGap]) & 63) << 24;
+		coltab[k - 1] = w;
+	}
+	for (int k = ncols; k < ncols_pad; ++k) coltab[k] = 0;
+	const int n = order_[step_];
+	const int start = task_->starts[n];
+	for (int j = 0; j < nrows_; ++j) rowshift[j] = (uint8_t)(6 * code_of(char_at(start + j, n)));
+	for (int k = 0; k <= ncols; ++k) top[k] = -4 * border_top_[k];
+	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
+}
+
+/* Traceback application, :1033-1155, driven by the op list instead of dpdirs. */
+int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, int score)
+{
+	if (!pending_) return CSADP_ERR_STATE;
+	const int i = step_;
+	const int n = order_[i];
+	const int nrows = nrows_;
+	const int ncols = consensus_;
+	const int newcons = nops + remj + remk;             /* :1034-1049 */
+	const bool inplace = (newcons == ncols);            /* :1050 / :1059 */
+
+	/* consistency of the walk with the matrix geometry */
+	{
+		int dj = remj, dk = remk;
+		for (int t = 0; t < nops; ++t) {
+			if (ops[t] == DIR_D) { ++dj; ++dk; }
+			else if (ops[t] == DIR_L) ++dk;
+			else if (ops[t] == DIR_U) ++dj;
+			else return CSADP_ERR_HIP;
+		}
+		if (dj != nrows || dk != ncols) return CSADP_ERR_HIP;
+	}
+
+	std::vector<int> newsv;
+	std::vector<std::string> newstr;
+	std::vector<int> *svp = &sv_;
+	std::vector<std::string> *strp = &str_;
+	if (!inplace) {
+		newsv.assign((size_t)(newcons + 1) * kSym, 0);
+		newstr.assign(nseq_, std::string());
+		for (int l = 0; l < i; ++l) newstr[order_[l]].assign((size_t)newcons, '\0');
+		svp = &newsv;
+		strp = &newstr;
+	}
+	std::string cur((size_t)newcons, '\0');
+	int j = nrows, k = ncols, m = newcons - 1;
+	int pos = task_->ends[n] - 1;
+	auto copy_column = [&](int kk, int mm) {               /* :1075-1079 */
+		for (int l = 0; l < kSym; ++l) (*svp)[(size_t)(mm + 1) * kSym + l] = sv_[(size_t)kk * kSym + l];
+		for (int l = 0; l < i; ++l) { const int p = order_[l]; (*strp)[p][mm] = str_[p][kk - 1]; }
+	};
+	auto new_column = [&](int mm) {                         /* :1100-1105 / :1116-1120 */
+		for (int l = 0; l < i; ++l) {
+			(*strp)[order_[l]][mm] = '-';
+			(*svp)[(size_t)(mm + 1) * kSym + kGap]++;
+		}
+	};
+	for (int t = 0; t < nops; ++t, --m) {                   /* :1072-1114 */
+		const int op = ops[t];
+		if (op == DIR_D) {
+			if (!inplace) copy_column(k, m);
+			const char ch = char_at(pos, n);
+			cur[m] = ch;
+			(*svp)[(size_t)(m + 1) * kSym + code_of(ch)]++;
+			--pos; --j; --k;
+		} else if (op == DIR_L) {
+			if (!inplace) copy_column(k, m);
+			cur[m] = '-';
+			(*svp)[(size_t)(m + 1) * kSym + kGap]++;
+			--k;
+		} else {
+			if (!inplace) new_column(m);
+			const char ch = char_at(pos, n);
+			cur[m] = ch;
+			(*svp)[(size_t)(m + 1) * kSym + code_of(ch)]++;
+			--pos; --j;
+		}
+	}
+	for (; j > 0; --j, --m) {                               /* :1115-1127 */
+		new_column(m);
+		const char ch = char_at(pos, n);
+		cur[m] = ch;
+		(*svp)[(size_t)(m + 1) * kSym + code_of(ch)]++;
+		--pos;
+	}
+	for (; k > 0; --k, --m) {                               /* :1128-1138 */
+		if (!inplace) copy_column(k, m);
+		cur[m] = '-';
+		(*svp)[(size_t)(m + 1) * kSym + kGap]++;
+	}
+	if (!inplace) {                                         /* :1139-1153 */
+		sv_.swap(newsv);
+		for (int l = 0; l < i; ++l) str_[order_[l]].swap(newstr[order_[l]]);
+	}
+	str_[n].swap(cur);
+	have_[n] = 1;
+	prevconsensus_ = ncols;                                 /* :1033 */
+	consensus_ = newcons;
+	last_score_ = score;
+	cells_ += (long long)nrows * (long long)ncols;
+	++fills_;
+	if (i > 1) delete_gapped_columns(i + 1, (i + 1) / 2);   /* :1157 */
+	++step_;
+	pending_ = false;
+	return CSADP_OK;
+}
+
+/*
+ * DeleteGappedColumns, :643-899.  For every column with at least numseqs-maxnongaps gaps:
+ * try to slide the residue blocks of the non-gap sequences into the gaps that follow them
+ * (right first, then left), score each slide with the sum-of-pairs style column formula,
+ * take the LAST slide whose gain is >= the best so far (:791), apply it, drop the all-gap
+ * columns it leaves behind and re-examine from the left-most dropped column.
+ */
+void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
+{
+	struct Probe {                    /* state of one direction of the search */
+		std::vector<int> block;       /* postonextgap: residues from col to the next gap  */
+		std::vector<int> affected;    /* bestnposaffected                                  */
+		std::vector<int> best;        /* bestworkingsv, maxaffected x 5                    */
+		int maxaffected = 0;
+	};
+	auto SV = [&](int col, int sym) -> int & { return sv_[(size_t)col * kSym + sym]; };
+	const int mingaps = numseqs - maxnongaps;
+	std::vector<int> movers;          /* seqstoshift */
+	std::vector<int> block, nextgaps, affected, statv, movv, workv;
+	Probe keep;
+
+	for (int col = 1; col <= consensus_; ++col) {
+		if (SV(col, kGap) < mingaps) continue;                       /* :678 */
+		movers.clear();
+		for (int t = 0; t < numseqs; ++t) {
+			const int s = order_[t];
+			if (str_[s][col - 1] != '-') movers.push_back(s);
+		}
+		const int nmov = (int)movers.size();
+		if (nmov == 0) continue;                                      /* :688 (prints "!") */
+		int bestscore = 0, bestshift = 0;
+		block.assign(nmov, 0);
+		nextgaps.assign(nmov, 0);
+		affected.assign(nmov, 0);
+		for (int dir = +1; dir >= -1; dir -= 2) {
+			const int limit = (dir > 0) ? consensus_ + 1 : 0;
+			int farthest = 0, minnext = consensus_;
+			bool blocked = false;
+			for (int t = 0; t < nmov; ++t) {                          /* :699-715 */
+				const std::string &row = str_[movers[t]];
+				int j = col;
+				block[t] = 0;
+				while (j != limit && row[j - 1] != '-') { block[t]++; j += dir; }
+				if (j == limit) { blocked = true; break; }
+				farthest = std::max(farthest, block[t]);
+				nextgaps[t] = 0;
+				while (j != limit && row[j - 1] == '-') { nextgaps[t]++; j += dir; }
+				minnext = std::min(minnext, nextgaps[t]);
+			}
+			if (blocked) continue;                                    /* :716-721 */
+			for (int t = 0; t < nmov; ++t) affected[t] = block[t] + minnext;
+			const int maxaff = farthest + minnext;
+			statv.assign((size_t)maxaff * kSym, 0);
+			movv.assign((size_t)maxaff * kSym, 0);
+			workv.assign((size_t)maxaff * kSym, 0);
+			int current = 0;
+			for (int j = 0; j < maxaff; ++j) {                        /* :739-761 */
+				const int jj = col + dir * j;
+				for (int y = 0; y < kSym; ++y) statv[(size_t)j * kSym + y] = SV(jj, y);
+				for (int t = 0; t < nmov; ++t) {
+					if (j < affected[t]) {
+						const int c = code_of(str_[movers[t]][jj - 1]);
+						movv[(size_t)j * kSym + c]++;
+						statv[(size_t)j * kSym + c]--;
+					}
+				}
+				int colscore = 0;
+				for (int y = 0; y < kGap; ++y) {
+					const int mv = movv[(size_t)j * kSym + y];
+					if (mv != 0)
+						colscore += mv * (kMatch * (SV(jj, y) - 1) + kMismatch * (numseqs - (SV(jj, y) + SV(jj, kGap)))
+						                  + kIndel * SV(jj, kGap));
+				}
+				const int mg = movv[(size_t)j * kSym + kGap];
+				if (mg != 0) colscore += mg * (kDoubleGap * (SV(jj, kGap) - 1) + kIndel * (numseqs - SV(jj, kGap)));
+				current += colscore;
+			}
+			for (int sh = 1; sh <= minnext; ++sh) {                   /* :762-795 */
+				int shifted = 0;
+				for (int t = 0; t < nmov; ++t) {
+					movv[(size_t)(affected[t] - 1) * kSym + kGap]--;
+					affected[t]--;
+				}
+				for (int j = 0; j < maxaff; ++j) {
+					int *w = &workv[(size_t)j * kSym];
+					if (j < sh) {
+						for (int y = 0; y < kGap; ++y) w[y] = 0;
+						w[kGap] = statv[(size_t)j * kSym + kGap] + nmov;
+						if (w[kGap] == numseqs) continue;
+						shifted += nmov * (kDoubleGap * (w[kGap] - 1) + kIndel * (numseqs - w[kGap]));
+						continue;
+					}
+					const int *mvp = &movv[(size_t)(j - sh) * kSym];
+					for (int y = 0; y < kSym; ++y) w[y] = statv[(size_t)j * kSym + y] + mvp[y];
+					if (w[kGap] == numseqs) continue;
+					int colscore = 0;
+					for (int y = 0; y < kGap; ++y)
+						if (mvp[y] != 0)
+							colscore += mvp[y] * (kMatch * (w[y] - 1) + kMismatch * (numseqs - (w[y] + w[kGap])) + kIndel * w[kGap]);
+					if (mvp[kGap] != 0) colscore += mvp[kGap] * (kDoubleGap * (w[kGap] - 1) + kIndel * (numseqs - w[kGap]));
+					shifted += colscore;
+				}
+				shifted -= current;
+				if (shifted >= bestscore) {                           /* :791 */
+					bestshift = dir * sh;
+					bestscore = shifted;
+				}
+			}
+			if (bestshift != 0 && bestshift * dir > 0) {              /* :796-818 */
+				const int sh = bestshift * dir;
+				const int back = minnext - sh;
+				keep.maxaffected = maxaff;
+				keep.affected.assign(nmov, 0);
+				for (int t = 0; t < nmov; ++t) {
+					for (int y = 0; y < back; ++y) movv[(size_t)(block[t] + y) * kSym + kGap]++;
+					keep.affected[t] = block[t] + sh;
+				}
+				keep.best.assign((size_t)maxaff * kSym, 0);
+				for (int j = 0; j < maxaff; ++j) {
+					for (int y = 0; y < kSym; ++y) {
+						int v = statv[(size_t)j * kSym + y];
+						if (j >= sh) v += movv[(size_t)(j - sh) * kSym + y];
+						keep.best[(size_t)j * kSym + y] = v;
+					}
+					if (j < sh) keep.best[(size_t)j * kSym + kGap] += nmov;
+				}
+			}
+		}
+		if (bestshift == 0) continue;                                 /* :823 */
+		const int dir = (bestshift < 0) ? -1 : +1;
+		const int sh = (bestshift < 0) ? -bestshift : bestshift;
+		for (int j = 0; j < keep.maxaffected; ++j)                    /* :837-840 */
+			for (int y = 0; y < kSym; ++y) SV(col + dir * j, y) = keep.best[(size_t)j * kSym + y];
+		for (int t = 0; t < nmov; ++t) {                              /* :841-852 */
+			std::string &row = str_[movers[t]];
+			for (int j = keep.affected[t] - 1; j >= 0; --j) {
+				const int c = col + dir * j;
+				row[c - 1] = (j < sh) ? '-' : row[c - dir * sh - 1];
+			}
+		}
+		int right = 0, left = 0;                                      /* :853-864 */
+		for (int j = col; j <= consensus_; ++j) { if (SV(j, kGap) != numseqs) break; ++right; }
+		for (int j = col - 1; j >= 1; --j) { if (SV(j, kGap) != numseqs) break; ++left; }
+		const int drop = right + left;
+		if (drop > 0) {                                               /* :865-887 */
+			const int from = col - left;
+			sv_.erase(sv_.begin() + (size_t)from * kSym, sv_.begin() + (size_t)(from + drop) * kSym);
+			for (int t = 0; t < numseqs; ++t) str_[order_[t]].erase((size_t)(from - 1), (size_t)drop);
+			consensus_ -= drop;
+		}
+		col -= left + 1;                                              /* :888 */
+	}
+}
+
+int Progressive::finish(csadp_result *res)
+{
+	res->status = CSADP_OK;
+	res->score = last_score_;
+	res->consensus = empty_task_ ? 0 : consensus_;
+	res->cells = cells_;
+	res->fills = fills_;
+	res->aligned = nullptr;
+	if (empty_task_) return CSADP_OK;
+	if (step_ < nseq_ || pending_) return CSADP_ERR_STATE;
+	char **out = (char **)calloc((size_t)nseq_, sizeof(char *));
+	if (!out) return CSADP_ERR_NOMEM;
+	for (int s = 0; s < nseq_; ++s) {
+		out[s] = (char *)malloc(str_[s].size() + 1);
+		if (!out[s]) {
+			for (int t = 0; t < s; ++t) free(out[t]);
+			free(out);
+			return CSADP_ERR_NOMEM;
+		}
+		memcpy(out[s], str_[s].data(), str_[s].size());
+		out[s][str_[s].size()] = '\0';
+	}
+	res->aligned = out;
+	return CSADP_OK;
+}
+
+}  // namespace csadp

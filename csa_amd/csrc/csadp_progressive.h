@@ -1,0 +1,80 @@
+/*
+ * csadp_progressive.h -- host side of one ProgressiveDP task: everything of
+ * /root/reference/source/dynamicprogramming.c:906-1171 that is NOT the matrix fill or the
+ * direction walk (those run on the GPU): sequence ordering (:276-308), profile seeding
+ * (:926-944), the border-refresh rule (:957, survey quirk Q1), applying a traceback to the
+ * strings and the profile (:1050-1155) and the gapped-column refinement (:643-899).
+ */
+#ifndef CSADP_PROGRESSIVE_H
+#define CSADP_PROGRESSIVE_H
+
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "csadp.h"
+
+namespace csadp {
+
+class Progressive {
+public:
+	/* Validate the task, order the sequences, seed the profile.  CSADP_OK or an error. */
+	int init(const csadp_task &task);
+
+	/* Move to the next progressive step that needs a matrix fill; steps whose row sequence
+	 * is empty are completed here (:950-956).  False when the task is finished. */
+	bool next_fill();
+
+	/* geometry of the pending fill */
+	int nrows() const { return nrows_; }
+	int ncols() const { return consensus_; }
+	int nprev() const { return step_; }            /* the reference's loop variable i */
+	int border_i() const { return border_i_; }     /* i in force when the borders were last refreshed */
+	bool stale_borders() const { return stale_; }
+
+	/* Device-format inputs of the pending fill (layouts: csadp_device.h).
+	 *   coltab[0..ncols_pad)      packed profile fields, zero beyond ncols
+	 *   rowshift[0..nrows)        6*code of each row letter
+	 *   top[0..ncols_pad]         cost of border row 0 = -4*H[0][k]; beyond ncols: last value */
+	void write_tables(uint32_t *coltab, int ncols_pad, uint8_t *rowshift, int32_t *top) const;
+
+	/* Apply the GPU traceback of the pending fill: ops in walk order (DIR_* codes, from cell
+	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border. */
+	int apply_trace(const uint8_t *ops, int nops, int remj, int remk, int score);
+
+	/* Publish the result (malloc'd strings, original index order). */
+	int finish(csadp_result *res);
+
+	long long cells() const { return cells_; }
+	int fills() const { return fills_; }
+	int nseq() const { return nseq_; }
+
+private:
+	char char_at(int pos, int seq) const;
+	void delete_gapped_columns(int numseqs, int maxnongaps);
+
+	int nseq_ = 0;
+	const csadp_task *task_ = nullptr;
+	std::vector<int> order_, len_;
+	std::vector<int> sv_;                        /* (consensus+1) x 5, column 0 unused (:931) */
+	std::vector<std::string> str_;               /* aligned strings, ORIGINAL index order       */
+	std::vector<char> have_;                     /* str_[s] assigned                            */
+	int consensus_ = 0;
+	int step_ = 0;                               /* i                                           */
+	int nrows_ = 0;
+	bool pending_ = false;
+	bool empty_task_ = false;
+	/* survey Q1: borders are refreshed only if consensus != prevconsensus || nrows > prevnrows */
+	int prevconsensus_ = 0, prevnrows_ = 0;
+	std::vector<int> border_top_;                /* H[0][k] as of the last refresh              */
+	int border_i_ = 0;
+	bool stale_ = false;
+	int last_score_ = 0;
+	long long cells_ = 0;
+	int fills_ = 0;
+};
+
+}  // namespace csadp
+
+#endif

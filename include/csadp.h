@@ -1,0 +1,146 @@
+/*
+ * csadp.h -- C-ABI of libcsadp.so: MI355X (gfx950) implementation of CSA's
+ * dynamic-programming alignment hot path.
+ *
+ * The library replaces the reference translation unit
+ * /root/reference/source/dynamicprogramming.c (public surface:
+ * `void ProgressiveDP(struct _alignmapsegment *segment);`,
+ * dynamicprogramming.h:3, sole live caller RunAlignment, alignment.c:201).
+ * Plain C types only: pointers, ints, sizes.  Every entry point returns
+ * CSADP_OK (0) or a negative CSADP_ERR_* code and never calls exit().
+ *
+ * There is NO CPU fallback: if no gfx950 device / HIP runtime is usable the
+ * calls fail with CSADP_ERR_NO_DEVICE.
+ */
+#ifndef CSADP_H
+#define CSADP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSADP_VERSION 100
+
+#define CSADP_OK              0
+#define CSADP_ERR_ARG        -1   /* NULL / out-of-range argument                         */
+#define CSADP_ERR_ALPHABET   -2   /* region holds a letter other than A,C,G,T (see below)  */
+#define CSADP_ERR_NOMEM      -3   /* host allocation failed                                */
+#define CSADP_ERR_NO_DEVICE  -4   /* no usable HIP device / library not initialised        */
+#define CSADP_ERR_HIP        -5   /* a HIP runtime call or kernel failed                   */
+#define CSADP_ERR_RANGE      -6   /* task too large for 32-bit scores or device memory     */
+#define CSADP_ERR_STATE      -7   /* call sequence error (e.g. fetch before run)           */
+
+#define CSADP_MAX_SEQS 64         /* MAXNUMBEROFSEQS, csamsa.c:23 */
+
+/* ---- library lifetime ------------------------------------------------------------ */
+
+typedef struct csadp_config {
+	int device;        /* HIP device ordinal; -1 = take LOCAL_RANK / 0                     */
+	int tile_rows;     /* DP steps per tile launch (0 = default)                           */
+	int verbose;       /* 1 = print the reference's progress tokens in the drop-in adapter */
+} csadp_config;
+
+int csadp_init(const csadp_config *cfg);      /* idempotent; NULL = defaults */
+void csadp_shutdown(void);
+int csadp_version(void);
+const char *csadp_strerror(int code);
+/* name of the device in use, number of compute units; CSADP_ERR_NO_DEVICE before init */
+int csadp_device_info(char *name, int namelen, int *compute_units);
+
+/* ---- one alignment task = one ProgressiveDP call ---------------------------------- */
+
+/*
+ * Replaces the implicit inputs of ProgressiveDP (globals csamsa.h:8-12 and the
+ * alignmapsegment fields alignmentmap.h:3-10):
+ *   nseq          numberofseqs (2..64)
+ *   texts[s]      texts[s]: circular sequence, uppercase, textsizes[s] letters
+ *   rotations[s]  rotations[s]
+ *   starts[s]     segment->positions[s] + segment->size       (rotated coordinates)
+ *   ends[s]       segment->next->positions[s]                 (exclusive)
+ * A letter at rotated position p is texts[s][(rotations[s]+p) wrapped once]
+ * (CharAt, alignment.c:16-20).
+ *
+ * Letters other than A,C,G,T inside a region make the reference index
+ * scorevector[][-1] (dynamicprogramming.c:941-942,:991-993; undefined
+ * behaviour).  This library rejects such a task with CSADP_ERR_ALPHABET.
+ */
+typedef struct csadp_task {
+	int nseq;
+	const char *const *texts;
+	const int *textsizes;
+	const int *rotations;
+	const int *starts;
+	const int *ends;
+} csadp_task;
+
+/*
+ * Replaces the outputs of ProgressiveDP:
+ *   aligned       segment->alignedstrings (dynamicprogramming.c:1160): calloc'd array of
+ *                 nseq malloc'd NUL-terminated strings of equal length, ORIGINAL index
+ *                 order; NULL when every region is empty (early return, :916).
+ *                 Ownership passes to the caller: release with free() exactly as
+ *                 DeleteAlignmentMap does (alignmentmap.c:174-179) or csadp_free_result.
+ *   consensus     final consensus size (the value printed at :1159)
+ *   score         dpmatrix[nrows][ncols] of the last fill (not observable in the
+ *                 reference, which frees the matrix at :1161-1165)
+ *   cells         sum of nrows*ncols over the fills of this task
+ */
+typedef struct csadp_result {
+	int status;
+	int score;
+	int consensus;
+	int fills;
+	long long cells;
+	char **aligned;
+} csadp_result;
+
+/* Align ntasks independent tasks (any nseq each) on the device: upload, fill, traceback,
+ * progressive profile update.  results[t].status carries per-task errors. */
+int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results);
+void csadp_free_result(csadp_result *r, int nseq);
+
+/* ---- device-resident pair batches (the benchmarked path) --------------------------- */
+
+/*
+ * A batch of 2-sequence tasks whose inputs live in HBM: create() validates, packs and
+ * uploads; run() enqueues fill + traceback for the whole batch on the library stream and
+ * returns immediately; sync() waits; fetch() downloads the traceback and builds the
+ * aligned strings.  run() may be called repeatedly (benchmark steps).
+ */
+typedef struct csadp_pairbatch csadp_pairbatch;
+
+int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
+int csadp_pairs_run(csadp_pairbatch *b);
+int csadp_pairs_sync(csadp_pairbatch *b);
+int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results);
+void csadp_pairs_destroy(csadp_pairbatch *b);
+
+typedef struct csadp_timing {
+	long long cells;        /* DP cells of one run()                                      */
+	int fill_launches;      /* fill-kernel launches of the last run()                     */
+	long long fill_tiles;   /* tile workgroups of the last run()                          */
+	float fill_ms;          /* HIP-event time from first to last fill launch, last run()  */
+	float traceback_ms;     /* HIP-event time of the traceback kernel, last run()         */
+	float total_ms;         /* fill + traceback, HIP events on the library stream         */
+	long long dir_bytes;    /* direction bytes written to HBM by one run()                */
+	long long border_bytes; /* tile hand-off bytes written + read by one run()            */
+} csadp_timing;
+
+int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);
+
+/* ---- host helpers ------------------------------------------------------------------ */
+
+/* Longest-processing-time partition of n task costs over nparts devices.
+ * assign[i] receives the part of task i; returns the maximum part load via *maxload. */
+int csadp_partition_lpt(const long long *cost, int n, int nparts, int *assign, long long *maxload);
+
+/* FASTA loader following the reference's rules (csamsa.c:433-519): skips \n \r NUL '-'
+ * and space, uppercases, admits IUPAC letters, drops a record holding any other byte,
+ * at most CSADP_MAX_SEQS records.  texts/descs/sizes are malloc'd arrays of *nseq entries. */
+int csadp_load_fasta(const char *path, char ***texts, char ***descs, int **sizes, int *nseq);
+void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSADP_H */

@@ -1,0 +1,118 @@
+/*
+ * oracle/ref_shim.c -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Thin driver that is compiled TOGETHER WITH the unmodified reference sources
+ * where they lie (/root/reference/source/*.c, see oracle/Makefile target
+ * "_ref") into oracle/_ref/libcsa_ref.so.  It drives the reference's own
+ * ProgressiveDP() (dynamicprogramming.c:906) the way the reference's commented
+ * whole-sequence route does (alignment.c:173-178 + alignment.c:57-65):
+ * build a first/last alignmapsegment pair, fill the header-defined globals
+ * (csamsa.h:8-12), call ProgressiveDP, hand back segment->alignedstrings.
+ *
+ * No reference source text is copied here: only its public declarations are
+ * #included at build time from /root/reference/source.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+#include <fcntl.h>
+#include <time.h>
+
+#include "csamsa.h"            /* numberofseqs, texts, textsizes, descs, rotations */
+#include "alignment.h"         /* CharAt */
+#include "alignmentmap.h"      /* alignmapsegment, NewAlignmentMapSegment, UpdateSegmentGapSizes */
+#include "dynamicprogramming.h"/* ProgressiveDP */
+
+/* file-level globals of dynamicprogramming.c (non-static there, :28-33).  They
+ * are sized by the FIRST call's numberofseqs (:284-285, survey quirk Q5), so a
+ * driver that changes numberofseqs between calls must drop them. */
+extern int *orderedseqs;
+extern int *seqlengths;
+extern int **scorevector;
+
+static int quiet_begin(void)
+{
+	int saved;
+	int devnull;
+	fflush(stdout);
+	saved = dup(1);
+	devnull = open("/dev/null", O_WRONLY);
+	if (devnull >= 0) { dup2(devnull, 1); close(devnull); }
+	return saved;
+}
+
+static void quiet_end(int saved)
+{
+	fflush(stdout);
+	if (saved >= 0) { dup2(saved, 1); close(saved); }
+}
+
+/*
+ * Run the reference ProgressiveDP on one region.
+ *   nseq               2..64 sequences
+ *   txts[s], sizes[s]  full (un-rotated) circular texts, uppercase ACGT
+ *   rots[s]            rotation offsets (csamsa.h:12)
+ *   starts[s], ends[s] region in ROTATED coordinates, end exclusive
+ *   out[s]             receives a malloc'd NUL-terminated aligned string
+ *                      (original-index order) or NULL when the reference
+ *                      returns early (maxgapsize==0, dynamicprogramming.c:916)
+ *   seconds            wall time of the ProgressiveDP call alone
+ * returns the common aligned length (consensus size), or -1.
+ */
+int csa_ref_progressive_dp(int nseq, const char **txts, const int *sizes, const int *rots,
+                           const int *starts, const int *ends, char **out, double *seconds)
+{
+	alignmapsegment *first, *last;
+	struct timespec t0, t1;
+	int s, saved, cons = -1;
+
+	if (orderedseqs) { free(orderedseqs); orderedseqs = NULL; }
+	if (seqlengths) { free(seqlengths); seqlengths = NULL; }
+
+	numberofseqs = nseq;
+	texts = (char **)calloc((size_t)nseq, sizeof(char *));
+	textsizes = (int *)calloc((size_t)nseq, sizeof(int));
+	rotations = (int *)calloc((size_t)nseq, sizeof(int));
+	for (s = 0; s < nseq; s++) {
+		texts[s] = (char *)txts[s];
+		textsizes[s] = sizes[s];
+		rotations[s] = rots[s];
+	}
+	first = NewAlignmentMapSegment(NULL);
+	last = NewAlignmentMapSegment(NULL);
+	first->next = last;
+	first->size = 0;
+	for (s = 0; s < nseq; s++) {
+		first->positions[s] = starts[s];
+		last->positions[s] = ends[s];
+	}
+	UpdateSegmentGapSizes(first);
+
+	saved = quiet_begin();
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	ProgressiveDP(first);
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	quiet_end(saved);
+	if (seconds) *seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+
+	for (s = 0; s < nseq; s++) out[s] = NULL;
+	if (first->alignedstrings != NULL) {
+		for (s = 0; s < nseq; s++) {
+			out[s] = first->alignedstrings[s];
+			if (out[s] != NULL && cons < 0) cons = (int)strlen(out[s]);
+		}
+		free(first->alignedstrings);
+		first->alignedstrings = NULL;
+	} else {
+		cons = 0;
+	}
+	free(first->positions); free(first);
+	free(last->positions); free(last);
+	free(texts); texts = NULL;
+	free(textsizes); textsizes = NULL;
+	free(rotations); rotations = NULL;
+	return cons;
+}
+
+void csa_ref_free(void *p) { free(p); }

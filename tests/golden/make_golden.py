@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the COMPILED REFERENCE
+(oracle/_ref/libcsa_ref.so, built by `make -C oracle _ref` from the unmodified
+sources under /root/reference/source).  Only runs in the build container.
+
+Outputs (all data, no reference source text):
+  data/Primates.txt, data/Mammals.txt   the reference's own example inputs
+                                        (Manual/*.txt) with CRLF normalised
+  tiny_pairs.json      >=200 random + adversarial 2-sequence cases, full strings
+  tiny_families.json   N=3..8 progressive cases (DeleteGappedColumns, Q1), full strings
+  real_pairs.json      whole-sequence pairs of Primates/Mammals: length, SP score,
+                       FNV-1a digest (the values quoted in SURVEY.md 8c included)
+
+usage: python tests/golden/make_golden.py [--all-pairs]
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from helpers import (fnv1a, random_family, read_fasta, ref_progressive, rng,  # noqa: E402
+                     sp_score)
+
+REF_MANUAL = "/root/reference/Manual"
+# rotations printed by the reference's mode R for each example set
+ROT = {
+    "Primates": [1947, 1949, 1950, 2530, 1952, 1946, 1951, 1952, 1975, 1955, 1954, 2475, 1948, 1947, 1940, 1948],
+    "Mammals": [1283, 1304, 1263, 1640, 1277, 1722, 1295, 1272, 1851, 1273, 1266, 1273],
+}
+
+
+def case(texts, rots, starts, ends):
+    cons, strs, _ = ref_progressive(texts, rots, starts, ends)
+    return {
+        "texts": [t.decode() for t in texts], "rots": rots, "starts": starts, "ends": ends,
+        "consensus": cons,
+        "aligned": [s.decode() if s is not None else None for s in strs],
+    }
+
+
+def tiny_pairs():
+    r = rng(20261003)
+    cases = []
+    adversarial = [
+        (b"A", b"A"), (b"A", b"C"), (b"AAAAAAAA", b"AAAA"), (b"ACGTACGT", b"TGCATGCA"),
+        (b"AAAAAAAAAAAAAAAA", b"CCCCCCCCCCCCCCCC"), (b"ACGT" * 8, b"ACGT" * 8),
+        (b"ACGT" * 8, b"CGTA" * 8), (b"A" * 33, b"A" * 31 + b"C"), (b"GATTACA", b"GCATGCT"),
+        (b"ACACACACAC", b"CACACACACA"), (b"T", b"ACGTACGTACGT"), (b"ACGTACGTACGT", b"G"),
+    ]
+    for a, b in adversarial:
+        cases.append(case([a, b], [0, 0], [0, 0], [len(a), len(b)]))
+        cases.append(case([b, a], [0, 0], [0, 0], [len(b), len(a)]))
+    # empty regions (one side, both sides)
+    cases.append(case([b"ACGT", b"ACGT"], [0, 0], [2, 0], [2, 4]))
+    cases.append(case([b"ACGT", b"ACGT"], [0, 0], [0, 1], [4, 1]))
+    cases.append(case([b"ACGT", b"ACGT"], [1, 2], [3, 3], [3, 3]))
+    while len(cases) < 240:
+        la = r.choice([1, 2, 3, 5, 8, 13, 21, 34, 48, 64])
+        fam = random_family(r, 2, la, mut=r.choice([0.0, 0.05, 0.2, 0.75]), indel=r.choice([0.0, 0.1, 0.3]))
+        fam = [f if f else b"G" for f in fam]
+        rots = [r.randrange(len(f)) for f in fam]
+        starts, ends = [], []
+        for f in fam:
+            if r.random() < 0.7:
+                starts.append(0)
+                ends.append(len(f))
+            else:
+                a = r.randrange(len(f) + 1)
+                starts.append(a)
+                ends.append(r.randrange(a, len(f) + 1))
+        cases.append(case(fam, rots, starts, ends))
+    return cases
+
+
+def tiny_families():
+    r = rng(77)
+    cases = []
+    while len(cases) < 160:
+        n = r.choice([3, 3, 4, 5, 6, 8])
+        base = r.choice([4, 9, 17, 30, 48])
+        fam = random_family(r, n, base, mut=r.choice([0.0, 0.1, 0.3]), indel=r.choice([0.0, 0.15, 0.35]))
+        fam = [f if f else b"T" for f in fam]
+        if r.random() < 0.3:      # equal lengths trigger the stale-border rule (Q1)
+            m = min(len(f) for f in fam)
+            fam = [f[:m] for f in fam]
+        rots = [r.randrange(len(f)) for f in fam]
+        starts = [0] * n
+        ends = [len(f) for f in fam]
+        if r.random() < 0.2:      # one empty region
+            k = r.randrange(n)
+            starts[k] = ends[k] = r.randrange(len(fam[k]) + 1)
+        cases.append(case(fam, rots, starts, ends))
+    return cases
+
+
+def real_pairs(all_pairs):
+    out = []
+    for name in ("Primates", "Mammals"):
+        _, seqs = read_fasta(os.path.join(HERE, "data", name + ".txt"))
+        n = len(seqs)
+        if all_pairs:
+            pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+        elif name == "Primates":
+            pairs = [(0, 1), (2, 14), (9, 10), (3, 11)]
+        else:
+            pairs = [(0, 1), (5, 8)]
+        for a, b in pairs:
+            for rots in ([ROT[name][a], ROT[name][b]],) + (([0, 0],) if (name, a, b) == ("Primates", 0, 1) else ()):
+                cons, strs, sec = ref_progressive([seqs[a], seqs[b]], list(rots))
+                out.append({"set": name, "a": a, "b": b, "rots": list(rots), "consensus": cons,
+                            "sp": sp_score(strs), "fnv1a": "%08x" % fnv1a(strs),
+                            "len_a": len(seqs[a]), "len_b": len(seqs[b])})
+                print(name, a, b, rots, cons, out[-1]["sp"], out[-1]["fnv1a"], "%.1fs" % sec, flush=True)
+    return out
+
+
+def copy_data():
+    os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
+    for name in ("Primates", "Mammals"):
+        with open(os.path.join(REF_MANUAL, name + ".txt"), "rb") as f:
+            raw = f.read().replace(b"\r\n", b"\n")
+        with open(os.path.join(HERE, "data", name + ".txt"), "wb") as f:
+            f.write(raw)
+
+
+def main():
+    all_pairs = "--all-pairs" in sys.argv
+    copy_data()
+    if "--only-real" not in sys.argv:
+        with open(os.path.join(HERE, "tiny_pairs.json"), "w") as f:
+            json.dump(tiny_pairs(), f, indent=0)
+        with open(os.path.join(HERE, "tiny_families.json"), "w") as f:
+            json.dump(tiny_families(), f, indent=0)
+    with open(os.path.join(HERE, "real_pairs.json"), "w") as f:
+        json.dump(real_pairs(all_pairs), f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,226 @@
+"""Shared test helpers: ctypes bindings for the oracle / reference checker
+libraries, FASTA parsing (rules of /root/reference/source/csamsa.c:482-490),
+deterministic synthetic sequence generators.
+
+Everything under oracle/ is TEST INFRASTRUCTURE: it is loaded here as the
+checker only, never by the product package (csa_amd).
+"""
+import ctypes
+import os
+import random
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "libcsa_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "libcsa_ref.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+class OdpStats(ctypes.Structure):
+    _fields_ = [("cells", ctypes.c_longlong), ("fills", ctypes.c_int),
+                ("stale_border_fills", ctypes.c_int), ("last_score", ctypes.c_int),
+                ("consensus", ctypes.c_int), ("fill_seconds", ctypes.c_double)]
+
+
+_oracle = None
+_ref = None
+
+
+def build_oracle():
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            build_oracle()
+        lib = ctypes.CDLL(ORACLE_SO)
+        lib.odp_progressive_dp.restype = ctypes.c_int
+        lib.odp_sp_score.restype = ctypes.c_longlong
+        lib.odp_fnv1a.restype = ctypes.c_uint
+        lib.odp_fill.restype = ctypes.c_int
+        _oracle = lib
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        lib = ctypes.CDLL(REF_SO)
+        lib.csa_ref_progressive_dp.restype = ctypes.c_int
+        _ref = lib
+    return _ref
+
+
+def _task_args(texts, rots, starts, ends):
+    n = len(texts)
+    bts = [t if isinstance(t, bytes) else t.encode() for t in texts]
+    txt = (ctypes.c_char_p * n)(*bts)
+    sz = (ctypes.c_int * n)(*[len(t) for t in bts])
+    rt = (ctypes.c_int * n)(*rots)
+    st = (ctypes.c_int * n)(*starts)
+    en = (ctypes.c_int * n)(*ends)
+    return n, txt, sz, rt, st, en
+
+
+def _collect(out, n, free):
+    strs = []
+    for i in range(n):
+        if out[i]:
+            strs.append(ctypes.string_at(out[i]))
+            free(ctypes.c_void_p(out[i]))
+        else:
+            strs.append(None)
+    return strs
+
+
+def oracle_progressive(texts, rots=None, starts=None, ends=None):
+    """Run the CPU restatement.  Returns (consensus_or_error, strings, stats)."""
+    lib = oracle_lib()
+    n = len(texts)
+    rots = rots or [0] * n
+    starts = starts or [0] * n
+    ends = ends or [len(t) for t in texts]
+    n, txt, sz, rt, st, en = _task_args(texts, rots, starts, ends)
+    out = (ctypes.c_void_p * n)()
+    stats = OdpStats()
+    rc = lib.odp_progressive_dp(n, txt, sz, rt, st, en, out, ctypes.byref(stats))
+    strs = _collect(out, n, lib.odp_free) if rc >= 0 else [None] * n
+    return rc, strs, stats
+
+
+def ref_progressive(texts, rots=None, starts=None, ends=None):
+    """Run the compiled reference (oracle/_ref).  Returns (consensus, strings, seconds)."""
+    lib = ref_lib()
+    n = len(texts)
+    rots = rots or [0] * n
+    starts = starts or [0] * n
+    ends = ends or [len(t) for t in texts]
+    n, txt, sz, rt, st, en = _task_args(texts, rots, starts, ends)
+    out = (ctypes.c_void_p * n)()
+    sec = ctypes.c_double()
+    rc = lib.csa_ref_progressive_dp(n, txt, sz, rt, st, en, out, ctypes.byref(sec))
+    strs = _collect(out, n, lib.csa_ref_free)
+    return rc, strs, sec.value
+
+
+def sp_score(strs):
+    """Sum-of-pairs score, rule of tools.c:274-280 (numpy restatement)."""
+    arrs = [np.frombuffer(s, dtype=np.uint8) for s in strs]
+    score = 0
+    for i in range(len(arrs)):
+        for j in range(i + 1, len(arrs)):
+            both = (arrs[i] == 45) & (arrs[j] == 45)
+            eq = (arrs[i] == arrs[j]) & ~both
+            ne = arrs[i] != arrs[j]
+            score += int(eq.sum()) - int(ne.sum())
+    return score
+
+
+def fnv1a(strs):
+    h = 0x811C9DC5
+    for s in strs:
+        for ch in s:
+            h ^= ch
+            h = (h * 0x01000193) & 0xFFFFFFFF
+    return h
+
+
+def degap(s):
+    return s.replace(b"-", b"")
+
+
+def rotated(text, rot, start=0, end=None):
+    t = text if isinstance(text, bytes) else text.encode()
+    end = len(t) if end is None else end
+    r = t[rot:] + t[:rot]
+    return r[start:end]
+
+
+def read_fasta(path):
+    """FASTA reader following csamsa.c:433-519 for well-formed ACGT input."""
+    seqs, descs, cur = [], [], None
+    with open(path, "rb") as f:
+        for line in f:
+            line = line.strip()
+            if line.startswith(b">"):
+                descs.append(line[1:].decode(errors="replace"))
+                cur = []
+                seqs.append(cur)
+            elif cur is not None:
+                cur.append(line.replace(b" ", b"").replace(b"-", b"").upper())
+    return descs, [b"".join(s) for s in seqs]
+
+
+# ---- deterministic synthetic inputs -----------------
+
+MASK64 = (1 << 64) - 1
+
+
+class SplitMix64:
+    def __init__(self, seed):
+        self.s = seed & MASK64
+
+    def next(self):
+        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
+        z = self.s
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+        return z ^ (z >> 31)
+
+
+def synth_pair(p, length=16384, sub=0.10, ins=0.01, dele=0.01, unrelated=False):
+    """Pair p of the synthetic batch: (a, b_rotated, rot_a, rot_b).
+
+    a = uniform ACGT; b = a with per-base deletion, insertion, substitution
+    (draw order del, ins, sub), then left-rotated by r; the task rotations
+    {0, (len(b)-r) % len(b)} re-linearise the pair for the DP."""
+    g = SplitMix64(0x9E3779B97F4A7C15 * (p + 1))
+    a = bytes(b"ACGT"[g.next() & 3] for _ in range(length))
+    if unrelated:
+        b = bytes(b"ACGT"[g.next() & 3] for _ in range(length))
+    else:
+        out = bytearray()
+        scale = float(1 << 53)
+        for ch in a:
+            if (g.next() >> 11) / scale < dele:
+                continue
+            if (g.next() >> 11) / scale < ins:
+                out.append(b"ACGT"[g.next() & 3])
+            if (g.next() >> 11) / scale < sub:
+                ch = b"ACGT"[(b"ACGT".index(ch) + 1 + g.next() % 3) & 3]
+            out.append(ch)
+        b = bytes(out)
+    r = g.next() % len(b)
+    brot = b[r:] + b[:r]
+    return a, brot, 0, (len(b) - r) % len(b)
+
+
+def random_family(rng, nseq, length, mut=0.15, indel=0.08, alphabet=b"ACGT"):
+    """nseq related sequences for progressive-DP tests (python RNG, small sizes)."""
+    base = bytes(rng.choice(alphabet) for _ in range(length))
+    fam = []
+    for _ in range(nseq):
+        out = bytearray()
+        for ch in base:
+            x = rng.random()
+            if x < indel / 2:
+                continue
+            if x < indel:
+                out.append(rng.choice(alphabet))
+            if rng.random() < mut:
+                ch = rng.choice(alphabet)
+            out.append(ch)
+        fam.append(bytes(out))
+    return fam
+
+
+def rng(seed):
+    return random.Random(seed)
