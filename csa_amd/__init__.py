@@ -1,0 +1,233 @@
+"""csa_amd -- Python binding (ctypes) of libcsadp.so, the MI355X implementation of CSA's
+dynamic-programming alignment hot path (reference: source/dynamicprogramming.c).
+
+The binding mirrors the C-ABI in include/csadp.h one to one; it exists for the test-suite
+and bench.py.  There is no Python or CPU implementation behind it: if the shared library is
+missing or no gfx950 device is usable, calls raise CsadpError.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcsadp.so")
+
+OK = 0
+ERR_ARG, ERR_ALPHABET, ERR_NOMEM, ERR_NO_DEVICE, ERR_HIP, ERR_RANGE, ERR_STATE = -1, -2, -3, -4, -5, -6, -7
+
+
+class CsadpError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        msg = lib().csadp_strerror(code).decode() if _lib is not None else "library not loaded"
+        super().__init__("%s: %s (%d)" % (what, msg, code) if what else "%s (%d)" % (msg, code))
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("tile_rows", ctypes.c_int), ("verbose", ctypes.c_int)]
+
+
+class Task(ctypes.Structure):
+    _fields_ = [("nseq", ctypes.c_int),
+                ("texts", ctypes.POINTER(ctypes.c_char_p)),
+                ("textsizes", ctypes.POINTER(ctypes.c_int)),
+                ("rotations", ctypes.POINTER(ctypes.c_int)),
+                ("starts", ctypes.POINTER(ctypes.c_int)),
+                ("ends", ctypes.POINTER(ctypes.c_int))]
+
+
+class Result(ctypes.Structure):
+    _fields_ = [("status", ctypes.c_int), ("score", ctypes.c_int), ("consensus", ctypes.c_int),
+                ("fills", ctypes.c_int), ("cells", ctypes.c_longlong),
+                ("aligned", ctypes.POINTER(ctypes.c_void_p))]
+
+
+class Timing(ctypes.Structure):
+    _fields_ = [("cells", ctypes.c_longlong), ("fill_launches", ctypes.c_int),
+                ("fill_tiles", ctypes.c_longlong), ("fill_ms", ctypes.c_float),
+                ("traceback_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
+                ("dir_bytes", ctypes.c_longlong), ("border_bytes", ctypes.c_longlong)]
+
+
+# symbols declared in include/csadp.h and include/csadp_debug.h
+EXPORTS = [
+    "csadp_init", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
+    "csadp_align_batch", "csadp_free_result",
+    "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_fetch",
+    "csadp_pairs_destroy", "csadp_pairs_timing",
+    "csadp_partition_lpt", "csadp_load_fasta", "csadp_free_fasta",
+    "csadp_debug_align_with_filler",
+]
+
+DEBUG_FILL_FN = ctypes.CFUNCTYPE(
+    ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_byte), ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+    ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+    ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int))
+
+_lib = None
+
+
+def lib():
+    """Load libcsadp.so (built by __graft_entry__.build() / make -C csa_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("csa_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                               "there is no fallback implementation" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        L.csadp_strerror.restype = ctypes.c_char_p
+        L.csadp_strerror.argtypes = [ctypes.c_int]
+        L.csadp_init.argtypes = [ctypes.POINTER(Config)]
+        L.csadp_align_batch.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(Result)]
+        L.csadp_free_result.argtypes = [ctypes.POINTER(Result), ctypes.c_int]
+        L.csadp_pairs_create.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        for name in ("csadp_pairs_run", "csadp_pairs_sync"):
+            getattr(L, name).argtypes = [ctypes.c_void_p]
+        L.csadp_pairs_destroy.argtypes = [ctypes.c_void_p]
+        L.csadp_pairs_destroy.restype = None
+        L.csadp_pairs_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(Result)]
+        L.csadp_pairs_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(Timing)]
+        L.csadp_partition_lpt.argtypes = [ctypes.POINTER(ctypes.c_longlong), ctypes.c_int, ctypes.c_int,
+                                          ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_longlong)]
+        L.csadp_debug_align_with_filler.argtypes = [ctypes.POINTER(Task), DEBUG_FILL_FN, ctypes.c_void_p,
+                                                    ctypes.POINTER(Result)]
+        _lib = L
+    return _lib
+
+
+def _check(code, what=""):
+    if code != OK:
+        raise CsadpError(code, what)
+
+
+def init(device=-1, tile_rows=0, verbose=0):
+    cfg = Config(device, tile_rows, verbose)
+    _check(lib().csadp_init(ctypes.byref(cfg)), "csadp_init")
+
+
+def shutdown():
+    lib().csadp_shutdown()
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    cus = ctypes.c_int()
+    _check(lib().csadp_device_info(name, 256, ctypes.byref(cus)), "csadp_device_info")
+    return name.value.decode(), cus.value
+
+
+class TaskArray:
+    """Owns the ctypes memory of an array of csadp_task (texts are borrowed by the library
+    until the batch is fetched, so this object must stay alive that long)."""
+
+    def __init__(self, tasks):
+        # tasks: iterable of (texts, rotations, starts, ends); starts/ends may be None
+        self.n = len(tasks)
+        self.arr = (Task * self.n)()
+        self._keep = []
+        self.nseq = []
+        for t, (texts, rots, starts, ends) in enumerate(tasks):
+            n = len(texts)
+            bts = [x if isinstance(x, bytes) else x.encode() for x in texts]
+            rots = list(rots) if rots is not None else [0] * n
+            starts = list(starts) if starts is not None else [0] * n
+            ends = list(ends) if ends is not None else [len(b) for b in bts]
+            c_txt = (ctypes.c_char_p * n)(*bts)
+            c_sz = (ctypes.c_int * n)(*[len(b) for b in bts])
+            c_rt = (ctypes.c_int * n)(*rots)
+            c_st = (ctypes.c_int * n)(*starts)
+            c_en = (ctypes.c_int * n)(*ends)
+            self._keep.append((bts, c_txt, c_sz, c_rt, c_st, c_en))
+            self.arr[t] = Task(n, c_txt, c_sz, c_rt, c_st, c_en)
+            self.nseq.append(n)
+
+
+def _unpack(results, nseqs):
+    out = []
+    L = lib()
+    for r, n in zip(results, nseqs):
+        strs = None
+        if r.status == OK and r.aligned:
+            strs = [ctypes.string_at(r.aligned[i]) for i in range(n)]
+        out.append({"status": r.status, "score": r.score, "consensus": r.consensus, "fills": r.fills,
+                    "cells": r.cells, "aligned": strs})
+        L.csadp_free_result(ctypes.byref(r), n)
+    return out
+
+
+def align_batch(tasks):
+    """csadp_align_batch: tasks = [(texts, rotations, starts, ends), ...] -> list of dicts."""
+    ta = TaskArray(tasks)
+    res = (Result * max(ta.n, 1))()
+    _check(lib().csadp_align_batch(ta.arr, ta.n, res), "csadp_align_batch")
+    return _unpack(res[:ta.n], ta.nseq)
+
+
+class PairBatch:
+    """Device-resident batch of 2-sequence tasks (csadp_pairs_*)."""
+
+    def __init__(self, tasks):
+        self.ta = TaskArray(tasks)
+        self.h = ctypes.c_void_p()
+        _check(lib().csadp_pairs_create(self.ta.arr, self.ta.n, ctypes.byref(self.h)), "csadp_pairs_create")
+
+    def run(self):
+        _check(lib().csadp_pairs_run(self.h), "csadp_pairs_run")
+
+    def sync(self):
+        _check(lib().csadp_pairs_sync(self.h), "csadp_pairs_sync")
+
+    def timing(self):
+        t = Timing()
+        _check(lib().csadp_pairs_timing(self.h, ctypes.byref(t)), "csadp_pairs_timing")
+        return {k: getattr(t, k) for k, _ in Timing._fields_}
+
+    def fetch(self):
+        res = (Result * self.ta.n)()
+        _check(lib().csadp_pairs_fetch(self.h, res), "csadp_pairs_fetch")
+        return _unpack(res[:self.ta.n], self.ta.nseq)
+
+    def close(self):
+        if self.h:
+            lib().csadp_pairs_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def partition_lpt(costs, nparts):
+    n = len(costs)
+    c = (ctypes.c_longlong * max(n, 1))(*costs)
+    a = (ctypes.c_int * max(n, 1))()
+    m = ctypes.c_longlong()
+    _check(lib().csadp_partition_lpt(c, n, nparts, a, ctypes.byref(m)), "csadp_partition_lpt")
+    return list(a[:n]), m.value
+
+
+def load_fasta(path):
+    texts = ctypes.POINTER(ctypes.c_char_p)()
+    descs = ctypes.POINTER(ctypes.c_char_p)()
+    sizes = ctypes.POINTER(ctypes.c_int)()
+    n = ctypes.c_int()
+    L = lib()
+    _check(L.csadp_load_fasta(path.encode(), ctypes.byref(texts), ctypes.byref(descs), ctypes.byref(sizes),
+                              ctypes.byref(n)), "csadp_load_fasta")
+    out = [(descs[i].decode(errors="replace"), bytes(texts[i])) for i in range(n.value)]
+    L.csadp_free_fasta(texts, descs, sizes, n.value)
+    return out
+
+
+def debug_align_with_filler(task, filler):
+    """Host-logic test seam (include/csadp_debug.h): `filler` is a DEBUG_FILL_FN-compatible
+    Python callable supplied by the test-suite."""
+    ta = TaskArray([task])
+    res = Result()
+    cb = DEBUG_FILL_FN(filler)
+    rc = lib().csadp_debug_align_with_filler(ta.arr, cb, None, ctypes.byref(res))
+    if rc != OK:
+        return {"status": rc, "aligned": None, "consensus": 0, "score": 0, "fills": 0, "cells": 0}
+    return _unpack([res], ta.nseq)[0]

@@ -1,0 +1,246 @@
+/*
+ * csadp_api.cpp -- the C-ABI of libcsadp.so (include/csadp.h).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "csadp.h"
+#include "csadp_debug.h"
+#include "csadp_engine.h"
+#include "csadp_progressive.h"
+
+using csadp::Engine;
+using csadp::FillBatch;
+using csadp::Progressive;
+
+extern "C" {
+
+int csadp_version(void) { return CSADP_VERSION; }
+
+const char *csadp_strerror(int code)
+{
+	switch (code) {
+	case CSADP_OK: return "ok";
+	case CSADP_ERR_ARG: return "invalid argument";
+	case CSADP_ERR_ALPHABET: return "region holds a letter other than A, C, G, T";
+	case CSADP_ERR_NOMEM: return "out of host memory";
+	case CSADP_ERR_NO_DEVICE: return "no usable gfx950 HIP device (there is no CPU fallback)";
+	case CSADP_ERR_HIP: return "HIP runtime or kernel error";
+	case CSADP_ERR_RANGE: return "task exceeds the 32-bit score range or the device memory";
+	case CSADP_ERR_STATE: return "call sequence error";
+	default: return "unknown error";
+	}
+}
+
+int csadp_init(const csadp_config *cfg) { return Engine::get().init(cfg); }
+void csadp_shutdown(void) { Engine::get().shutdown(); }
+
+int csadp_device_info(char *name, int namelen, int *compute_units)
+{
+	Engine &E = Engine::get();
+	if (!E.ready()) return CSADP_ERR_NO_DEVICE;
+	if (name && namelen > 0) snprintf(name, (size_t)namelen, "%s", E.name());
+	if (compute_units) *compute_units = E.compute_units();
+	return CSADP_OK;
+}
+
+void csadp_free_result(csadp_result *r, int nseq)
+{
+	if (!r || !r->aligned) return;
+	for (int s = 0; s < nseq; ++s) free(r->aligned[s]);
+	free(r->aligned);
+	r->aligned = NULL;
+}
+
+}  // extern "C"
+
+namespace {
+
+/* Bring every task to its next pending fill; fills with an empty profile (ncols == 0) need
+ * no matrix and are completed on the host (the walk of :1037 never starts, :1115-1127 runs). */
+bool advance(Progressive &p)
+{
+	while (p.next_fill()) {
+		if (p.ncols() > 0) return true;
+		const int score = -p.border_i() * p.nrows();        /* dpmatrix[nrows][0], :967 */
+		if (p.apply_trace(nullptr, 0, p.nrows(), 0, score) != CSADP_OK) return false;
+	}
+	return false;
+}
+
+/* one lock-step round: every task with a pending fill contributes one job */
+int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, FillBatch &fb, std::vector<int> &status)
+{
+	fb.clear();
+	for (int t : active) fb.add(tasks[t].nrows(), tasks[t].ncols(), tasks[t].nprev(), tasks[t].border_i());
+	int rc = fb.layout();
+	if (rc != CSADP_OK) return rc;
+	for (size_t j = 0; j < active.size(); ++j)
+		tasks[active[j]].write_tables(fb.coltab((int)j), fb.ncols_pad((int)j), fb.rowshift((int)j), fb.top((int)j));
+	if ((rc = fb.upload()) != CSADP_OK) return rc;
+	if ((rc = fb.run()) != CSADP_OK) return rc;
+	if ((rc = fb.download()) != CSADP_OK) return rc;
+	for (size_t j = 0; j < active.size(); ++j) {
+		const int32_t *sm = fb.summary((int)j);
+		const int a = tasks[active[j]].apply_trace(fb.ops((int)j), sm[0], sm[1], sm[2], sm[3]);
+		if (a != CSADP_OK) status[active[j]] = a;
+	}
+	return CSADP_OK;
+}
+
+}  // namespace
+
+struct csadp_pairbatch {
+	std::vector<Progressive> tasks;
+	std::vector<int> status;
+	std::vector<int> active;     /* tasks that own a job of the batch */
+	FillBatch fb;
+	bool ran = false, fetched = false;
+};
+
+extern "C" {
+
+int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results)
+{
+	if (!tasks || !results || ntasks < 0) return CSADP_ERR_ARG;
+	if (!Engine::get().ready()) {
+		const int rc = csadp_init(NULL);
+		if (rc != CSADP_OK) return rc;
+	}
+	std::vector<Progressive> prog((size_t)ntasks);
+	std::vector<int> status((size_t)ntasks, CSADP_OK);
+	for (int t = 0; t < ntasks; ++t) {
+		memset(&results[t], 0, sizeof(results[t]));
+		status[t] = prog[t].init(tasks[t]);
+	}
+	FillBatch fb;
+	for (;;) {
+		std::vector<int> active;
+		for (int t = 0; t < ntasks; ++t)
+			if (status[t] == CSADP_OK && advance(prog[t])) active.push_back(t);
+		if (active.empty()) break;
+		const int rc = run_round(prog, active, fb, status);
+		if (rc != CSADP_OK) return rc;
+	}
+	int worst = CSADP_OK;
+	for (int t = 0; t < ntasks; ++t) {
+		if (status[t] == CSADP_OK) status[t] = prog[t].finish(&results[t]);
+		results[t].status = status[t];
+		if (status[t] != CSADP_OK) worst = status[t];
+	}
+	(void)worst;
+	return CSADP_OK;
+}
+
+int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out)
+{
+	if (!tasks || !out || ntasks <= 0) return CSADP_ERR_ARG;
+	if (!Engine::get().ready()) {
+		const int rc = csadp_init(NULL);
+		if (rc != CSADP_OK) return rc;
+	}
+	std::unique_ptr<csadp_pairbatch> b(new (std::nothrow) csadp_pairbatch);
+	if (!b) return CSADP_ERR_NOMEM;
+	b->tasks = std::vector<Progressive>((size_t)ntasks);
+	b->status.assign((size_t)ntasks, CSADP_OK);
+	for (int t = 0; t < ntasks; ++t) {
+		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
+		b->status[t] = b->tasks[t].init(tasks[t]);
+		if (b->status[t] == CSADP_OK && advance(b->tasks[t])) b->active.push_back(t);
+	}
+	if (!b->active.empty()) {
+		for (int t : b->active) b->fb.add(b->tasks[t].nrows(), b->tasks[t].ncols(), b->tasks[t].nprev(), b->tasks[t].border_i());
+		int rc = b->fb.layout();
+		if (rc != CSADP_OK) return rc;
+		for (size_t j = 0; j < b->active.size(); ++j)
+			b->tasks[b->active[j]].write_tables(b->fb.coltab((int)j), b->fb.ncols_pad((int)j), b->fb.rowshift((int)j),
+			                                    b->fb.top((int)j));
+		if ((rc = b->fb.upload()) != CSADP_OK) return rc;
+		if ((rc = b->fb.sync()) != CSADP_OK) return rc;
+	}
+	*out = b.release();
+	return CSADP_OK;
+}
+
+int csadp_pairs_run(csadp_pairbatch *b)
+{
+	if (!b) return CSADP_ERR_ARG;
+	if (b->fetched) return CSADP_ERR_STATE;
+	b->ran = true;
+	if (b->active.empty()) return CSADP_OK;
+	return b->fb.run();
+}
+
+int csadp_pairs_sync(csadp_pairbatch *b)
+{
+	if (!b) return CSADP_ERR_ARG;
+	return b->fb.sync();
+}
+
+int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t)
+{
+	if (!b || !t) return CSADP_ERR_ARG;
+	if (!b->ran || b->active.empty()) return CSADP_ERR_STATE;
+	return b->fb.timing(t);
+}
+
+int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
+{
+	if (!b || !results) return CSADP_ERR_ARG;
+	if (!b->ran || b->fetched) return CSADP_ERR_STATE;
+	if (!b->active.empty()) {
+		const int rc = b->fb.download();
+		if (rc != CSADP_OK) return rc;
+		for (size_t j = 0; j < b->active.size(); ++j) {
+			const int32_t *sm = b->fb.summary((int)j);
+			const int a = b->tasks[b->active[j]].apply_trace(b->fb.ops((int)j), sm[0], sm[1], sm[2], sm[3]);
+			if (a != CSADP_OK) b->status[b->active[j]] = a;
+		}
+	}
+	for (size_t t = 0; t < b->tasks.size(); ++t) {
+		memset(&results[t], 0, sizeof(results[t]));
+		if (b->status[t] == CSADP_OK) b->status[t] = b->tasks[t].finish(&results[t]);
+		results[t].status = b->status[t];
+	}
+	b->fetched = true;
+	return CSADP_OK;
+}
+
+void csadp_pairs_destroy(csadp_pairbatch *b) { delete b; }
+
+/* ---- test seam: run the HOST logic of one task with a caller-supplied matrix filler ------- */
+
+int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fill, void *user, csadp_result *result)
+{
+	if (!task || !fill || !result) return CSADP_ERR_ARG;
+	Progressive p;
+	memset(result, 0, sizeof(*result));
+	int rc = p.init(*task);
+	if (rc != CSADP_OK) { result->status = rc; return rc; }
+	std::vector<unsigned char> ops;
+	std::vector<signed char> rows;
+	while (p.next_fill()) {
+		const int nrows = p.nrows(), ncols = p.ncols();
+		int nops = 0, remj = nrows, remk = 0, score = -p.border_i() * nrows;
+		if (ncols > 0) {
+			ops.assign((size_t)nrows + ncols + 64, 0);
+			rows.resize((size_t)nrows);
+			p.debug_rowcodes(rows.data());
+			rc = fill(user, nrows, ncols, p.nprev(), p.debug_sv(), rows.data(), p.debug_border_top(), p.border_i(),
+			          ops.data(), &nops, &remj, &remk, &score);
+			if (rc != CSADP_OK) { result->status = rc; return rc; }
+		}
+		rc = p.apply_trace(ops.data(), nops, remj, remk, score);
+		if (rc != CSADP_OK) { result->status = rc; return rc; }
+	}
+	rc = p.finish(result);
+	result->status = rc;
+	return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+/*
+ * csadp_engine.h -- device runtime of libcsadp: device selection, the batch arena in HBM,
+ * tile scheduling (one launch per tile anti-diagonal) and HIP-event timing.
+ */
+#ifndef CSADP_ENGINE_H
+#define CSADP_ENGINE_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "csadp.h"
+#include "csadp_device.h"
+
+namespace csadp {
+
+class Engine {
+public:
+	static Engine &get();
+	int init(const csadp_config *cfg);
+	void shutdown();
+	bool ready() const { return ready_; }
+	hipStream_t stream() const { return stream_; }
+	int C() const { return C_; }
+	int TR() const { return TR_; }
+	int device() const { return device_; }
+	const char *name() const { return name_; }
+	int compute_units() const { return cus_; }
+	bool verbose() const { return verbose_; }
+
+private:
+	bool ready_ = false;
+	bool verbose_ = false;
+	int device_ = 0;
+	int C_ = 16, TR_ = 128;
+	int cus_ = 0;
+	char name_[256] = {0};
+	hipStream_t stream_ = nullptr;
+};
+
+/*
+ * A batch of independent matrix fills executed in lock-step: all tiles on the same tile
+ * anti-diagonal (a + s) of every job go into one kernel launch.
+ *
+ * Arena layout in HBM (one allocation, offsets in FillJob):
+ *   [ jobs | tiles | per-job inputs: coltab, rowshift, top ]   <- one H2D copy
+ *   [ per-job results: summary, ops ]                          <- one D2H copy
+ *   [ per-job scratch: final_row, state, handoff, dirs ]       <- never leaves the device
+ */
+class FillBatch {
+public:
+	FillBatch() = default;
+	~FillBatch();
+	FillBatch(const FillBatch &) = delete;
+	FillBatch &operator=(const FillBatch &) = delete;
+
+	void clear();
+	/* register a fill; returns its job index */
+	int add(int nrows, int ncols, int nprev, int left_i);
+	int njobs() const { return (int)jobs_.size(); }
+	/* compute the arena layout and the tile schedule, (re)allocate HBM and pinned staging */
+	int layout();
+	/* host staging pointers for the inputs of job j (valid after layout) */
+	uint32_t *coltab(int j);
+	uint8_t *rowshift(int j);        /* points at row 1 (index padl) */
+	int32_t *top(int j);
+	int ncols_pad(int j) const;
+	int upload();                    /* inputs -> HBM (async on the engine stream) */
+	int run();                       /* enqueue all fill launches + the traceback */
+	int sync();
+	int download();                  /* results -> host (blocking) */
+	const uint8_t *ops(int j) const;
+	const int32_t *summary(int j) const;   /* nops, remj, remk, score */
+	int timing(csadp_timing *t);
+
+private:
+	struct Extra { int ncols_pad; size_t in_coltab, in_rowshift, in_top, res_summary, res_ops; };
+	std::vector<FillJob> jobs_;
+	std::vector<Extra> extra_;
+	std::vector<TileRef> tiles_;
+	std::vector<size_t> diag_off_;   /* tiles_ index of the first tile of each diagonal, +1 sentinel */
+	size_t in_bytes_ = 0, res_off_ = 0, res_bytes_ = 0, total_bytes_ = 0;
+	size_t jobs_off_ = 0, tiles_off_ = 0;
+	uint8_t *arena_ = nullptr;
+	size_t arena_cap_ = 0;
+	uint8_t *h_in_ = nullptr;        /* pinned mirror of the input region */
+	size_t h_in_cap_ = 0;
+	uint8_t *h_res_ = nullptr;       /* pinned mirror of the result region */
+	size_t h_res_cap_ = 0;
+	hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
+	bool laid_out_ = false, ran_ = false;
+	long long cells_ = 0, dir_bytes_ = 0, border_bytes_ = 0;
+};
+
+}  // namespace csadp
+
+#endif

@@ -1,0 +1,107 @@
+/*
+ * csadp_hostutil.cpp -- host helpers of the C-ABI: work partitioning over GPUs and the
+ * FASTA reader (wire format of the reference's loader, csamsa.c:433-519).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "csadp.h"
+
+extern "C" {
+
+/* Longest-processing-time-first: sort by cost descending, give each task to the least
+ * loaded part (ties: lowest part index; equal costs keep task order) -- SURVEY.md 8(e). */
+int csadp_partition_lpt(const long long *cost, int n, int nparts, int *assign, long long *maxload)
+{
+	if (n < 0 || nparts <= 0 || (n > 0 && (!cost || !assign))) return CSADP_ERR_ARG;
+	std::vector<int> idx((size_t)n);
+	std::iota(idx.begin(), idx.end(), 0);
+	std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return cost[a] > cost[b]; });
+	std::vector<long long> load((size_t)nparts, 0);
+	for (int t : idx) {
+		if (cost[t] < 0) return CSADP_ERR_ARG;
+		const int p = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+		assign[t] = p;
+		load[(size_t)p] += cost[t];
+	}
+	if (maxload) *maxload = *std::max_element(load.begin(), load.end());
+	return CSADP_OK;
+}
+
+/*
+ * csamsa.c:433-519.  Records start at '>', the description runs to end of line; sequence
+ * bytes: \n \r NUL '-' ' ' skipped; ACGT and the IUPAC codes RYSWKMDHBVN kept (lower case
+ * upper-cased); any other byte drops the whole record ("INVALID_CHARS"); empty records are
+ * dropped; at most 64 records are kept; fewer than 2 valid records is an error.
+ */
+int csadp_load_fasta(const char *path, char ***texts, char ***descs, int **sizes, int *nseq)
+{
+	if (!path || !texts || !descs || !sizes || !nseq) return CSADP_ERR_ARG;
+	FILE *f = fopen(path, "rb");
+	if (!f) return CSADP_ERR_ARG;
+	std::string data;
+	char buf[1 << 16];
+	size_t got;
+	while ((got = fread(buf, 1, sizeof(buf), f)) > 0) data.append(buf, got);
+	fclose(f);
+
+	std::vector<std::string> seqs, names;
+	size_t p = data.find('>');
+	while (p != std::string::npos && (int)seqs.size() < CSADP_MAX_SEQS) {
+		size_t eol = p + 1;
+		while (eol < data.size() && data[eol] != '\n' && data[eol] != '\r') ++eol;
+		std::string name = data.substr(p + 1, eol - (p + 1));
+		size_t next = data.find('>', eol);
+		const size_t end = (next == std::string::npos) ? data.size() : next;
+		std::string seq;
+		bool valid = true;
+		for (size_t q = eol; q < end; ++q) {
+			unsigned char c = (unsigned char)data[q];
+			if (c == '\n' || c == '\r' || c == '\0' || c == '-' || c == ' ') continue;
+			if (c >= 'a' && c <= 'z') c = (unsigned char)(c - 32);
+			if (strchr("ACGTRYSWKMDHBVN", c) != NULL) seq.push_back((char)c);
+			else { valid = false; break; }
+		}
+		if (valid && !seq.empty()) {
+			seqs.push_back(seq);
+			names.push_back(name);
+		}
+		p = next;
+	}
+	if (seqs.size() < 2) return CSADP_ERR_ARG;
+	const int n = (int)seqs.size();
+	char **t = (char **)calloc((size_t)n, sizeof(char *));
+	char **d = (char **)calloc((size_t)n, sizeof(char *));
+	int *z = (int *)calloc((size_t)n, sizeof(int));
+	if (!t || !d || !z) { free(t); free(d); free(z); return CSADP_ERR_NOMEM; }
+	for (int i = 0; i < n; ++i) {
+		t[i] = strdup(seqs[(size_t)i].c_str());
+		d[i] = strdup(names[(size_t)i].c_str());
+		z[i] = (int)seqs[(size_t)i].size();
+		if (!t[i] || !d[i]) { csadp_free_fasta(t, d, z, n); return CSADP_ERR_NOMEM; }
+	}
+	*texts = t;
+	*descs = d;
+	*sizes = z;
+	*nseq = n;
+	return CSADP_OK;
+}
+
+void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq)
+{
+	for (int i = 0; i < nseq; ++i) {
+		if (texts) free(texts[i]);
+		if (descs) free(descs[i]);
+	}
+	free(texts);
+	free(descs);
+	free(sizes);
+}
+
+}  // extern "C"

@@ -38,17 +38,21 @@ inline int code_of(char ch)   /* :74-85 */
 /* CharAt, alignment.c:16-20 */
 char Progressive::char_at(int pos, int seq) const
 {
-	int i = task_->rotations[seq] + pos;
-	if (i >= task_->textsizes[seq]) i -= task_->textsizes[seq];
-	return task_->texts[seq][i];
+	int i = rotations_[seq] + pos;
+	if (i >= textsizes_[seq]) i -= textsizes_[seq];
+	return texts_[seq][i];
 }
 
 int Progressive::init(const csadp_task &task)
 {
-	task_ = &task;
 	nseq_ = task.nseq;
 	if (nseq_ < 2 || nseq_ > CSADP_MAX_SEQS) return CSADP_ERR_ARG;
 	if (!task.texts || !task.textsizes || !task.rotations || !task.starts || !task.ends) return CSADP_ERR_ARG;
+	texts_.assign(task.texts, task.texts + nseq_);
+	textsizes_.assign(task.textsizes, task.textsizes + nseq_);
+	rotations_.assign(task.rotations, task.rotations + nseq_);
+	starts_.assign(task.starts, task.starts + nseq_);
+	ends_.assign(task.ends, task.ends + nseq_);
 	int maxgap = 0;
 	for (int s = 0; s < nseq_; ++s) {
 		const int size = task.textsizes[s];
@@ -148,10 +152,16 @@ void Progressive::write_tables(uint32_t *coltab, int ncols_pad, uint8_t *rowshif
 	}
 	for (int k = ncols; k < ncols_pad; ++k) coltab[k] = 0;
 	const int n = order_[step_];
-	const int start = task_->starts[n];
+	const int start = starts_[n];
 	for (int j = 0; j < nrows_; ++j) rowshift[j] = (uint8_t)(6 * code_of(char_at(start + j, n)));
 	for (int k = 0; k <= ncols; ++k) top[k] = -4 * border_top_[k];
 	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
+}
+
+void Progressive::debug_rowcodes(signed char *out) const
+{
+	const int n = order_[step_];
+	for (int j = 0; j < nrows_; ++j) out[j] = (signed char)code_of(char_at(starts_[n] + j, n));
 }
 
 /* Traceback application, :1033-1155, driven by the op list instead of dpdirs. */
@@ -190,7 +200,7 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, i
 	}
 	std::string cur((size_t)newcons, '\0');
 	int j = nrows, k = ncols, m = newcons - 1;
-	int pos = task_->ends[n] - 1;
+	int pos = ends_[n] - 1;
 	auto copy_column = [&](int kk, int mm) {               /* :1075-1079 */
 		for (int l = 0; l < kSym; ++l) (*svp)[(size_t)(mm + 1) * kSym + l] = sv_[(size_t)kk * kSym + l];
 		for (int l = 0; l < i; ++l) { const int p = order_[l]; (*strp)[p][mm] = str_[p][kk - 1]; }

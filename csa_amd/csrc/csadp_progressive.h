@@ -46,6 +46,11 @@ public:
 	/* Publish the result (malloc'd strings, original index order). */
 	int finish(csadp_result *res);
 
+	/* H-domain views of the pending fill for the test seam (include/csadp_debug.h) */
+	const int *debug_sv() const { return sv_.data(); }
+	const int *debug_border_top() const { return border_top_.data(); }
+	void debug_rowcodes(signed char *out) const;
+
 	long long cells() const { return cells_; }
 	int fills() const { return fills_; }
 	int nseq() const { return nseq_; }
@@ -55,7 +60,10 @@ private:
 	void delete_gapped_columns(int numseqs, int maxnongaps);
 
 	int nseq_ = 0;
-	const csadp_task *task_ = nullptr;
+	/* private copy of the task's small arrays; the sequence texts themselves are borrowed
+	 * and must outlive this object */
+	std::vector<const char *> texts_;
+	std::vector<int> textsizes_, rotations_, starts_, ends_;
 	std::vector<int> order_, len_;
 	std::vector<int> sv_;                        /* (consensus+1) x 5, column 0 unused (:931) */
 	std::vector<std::string> str_;               /* aligned strings, ORIGINAL index order       */

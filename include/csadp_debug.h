@@ -1,0 +1,38 @@
+/*
+ * csadp_debug.h -- test seam of libcsadp.so (NOT part of the drop-in surface).
+ *
+ * csadp_debug_align_with_filler runs the HOST logic of one task (ordering, profile
+ * seeding, border-refresh rule, traceback application, DeleteGappedColumns -- i.e.
+ * everything of dynamicprogramming.c:906-1171 that stays on the CPU) and asks the caller
+ * for every matrix fill + direction walk.  The CPU test-suite passes a filler built on
+ * the oracle so the host logic can be checked without a GPU; the library itself never
+ * supplies a filler: the product path fills matrices on the GPU only.
+ */
+#ifndef CSADP_DEBUG_H
+#define CSADP_DEBUG_H
+
+#include "csadp.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * One fill in the reference's own terms (dynamicprogramming.c:957-1049):
+ *   sv[(ncols+1)*5]   profile counts (column 0 unused), nprev = loop variable i
+ *   rowcodes[nrows]   0..3
+ *   top[ncols+1]      border row 0 as last refreshed, left_i: H[j][0] = -left_i*j
+ * outputs: ops[] = direction codes (0 'D', 1 'L', 2 'U') of the walk from (nrows,ncols)
+ * until a border is hit, *nops, rows/columns left (*remj,*remk), *score = H[nrows][ncols].
+ */
+typedef int (*csadp_debug_fill_fn)(void *user, int nrows, int ncols, int nprev, const int *sv,
+                                   const signed char *rowcodes, const int *top, int left_i,
+                                   unsigned char *ops, int *nops, int *remj, int *remk, int *score);
+
+int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fill, void *user,
+                                  csadp_result *result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

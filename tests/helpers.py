@@ -224,3 +224,56 @@ def random_family(rng, nseq, length, mut=0.15, indel=0.08, alphabet=b"ACGT"):
 
 def rng(seed):
     return random.Random(seed)
+
+
+# ---- oracle-backed matrix filler for the host-logic test seam (csadp_debug.h) -----------
+
+def oracle_filler():
+    """Returns a Python callable with the csadp_debug_fill_fn signature that fills the
+    matrix with the oracle's odp_fill and walks the directions (dynamicprogramming.c
+    :1037-1047).  Used ONLY by CPU tests of the product's host logic."""
+    lib = oracle_lib()
+
+    def fill(user, nrows, ncols, nprev, sv, rowcodes, top, left_i, ops, nops, remj, remk, score):
+        H = (ctypes.c_int * ((nrows + 1) * (ncols + 1)))()
+        D = ctypes.create_string_buffer((nrows + 1) * (ncols + 1))
+        rc = lib.odp_fill(nrows, ncols, rowcodes, sv, nprev, top, left_i, H, D)
+        if rc != 0:
+            return -5
+        j, k, n = nrows, ncols, 0
+        pitch = ncols + 1
+        raw = D.raw
+        while j > 0 and k > 0:
+            d = raw[j * pitch + k]
+            if d == 68:      # 'D'
+                ops[n] = 0
+                j -= 1
+                k -= 1
+            elif d == 76:    # 'L'
+                ops[n] = 1
+                k -= 1
+            else:            # 'U'
+                ops[n] = 2
+                j -= 1
+            n += 1
+        nops[0] = n
+        remj[0] = j
+        remk[0] = k
+        score[0] = H[nrows * pitch + ncols]
+        return 0
+
+    return fill
+
+
+def load_golden(name):
+    import json
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def golden_task(case):
+    return ([t.encode() for t in case["texts"]], case["rots"], case["starts"], case["ends"])
+
+
+def golden_aligned(case):
+    return [a.encode() if a is not None else None for a in case["aligned"]]

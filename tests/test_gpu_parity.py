@@ -1,0 +1,195 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI (libcsadp.so), against
+the committed golden vectors (generated from the compiled reference) and against the oracle
+on seeded inputs; at full size through size-independent properties.
+
+Bar: bit-exact -- integer scores, aligned strings byte for byte."""
+import pytest
+
+import csa_amd
+from helpers import (degap, fnv1a, golden_aligned, golden_task, load_golden, oracle_progressive,
+                     random_family, read_fasta, rng, rotated, sp_score, synth_pair, GOLDEN)
+import os
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    csa_amd.init(device=0)
+    yield
+
+
+def _check_case(case, got):
+    exp = golden_aligned(case)
+    assert got["status"] == 0
+    assert got["consensus"] == case["consensus"]
+    if all(e is None for e in exp):
+        assert got["aligned"] is None
+    else:
+        assert got["aligned"] == exp
+
+
+def test_tiny_pairs_golden():
+    cases = load_golden("tiny_pairs.json")
+    got = csa_amd.align_batch([golden_task(c) for c in cases])
+    for c, g in zip(cases, got):
+        _check_case(c, g)
+
+
+def test_tiny_families_golden():
+    """N=3..8 progressive tasks: profile mode of the kernel, stale borders (Q1),
+    DeleteGappedColumns on the host, zero-length regions."""
+    cases = load_golden("tiny_families.json")
+    got = csa_amd.align_batch([golden_task(c) for c in cases])
+    for c, g in zip(cases, got):
+        _check_case(c, g)
+
+
+def test_tiny_one_by_one_matches_batch():
+    cases = load_golden("tiny_pairs.json")[:40]
+    for c in cases:
+        _check_case(c, csa_amd.align_batch([golden_task(c)])[0])
+
+
+def test_score_equals_sp_for_pairs():
+    cases = [c for c in load_golden("tiny_pairs.json") if c["aligned"][0] is not None]
+    got = csa_amd.align_batch([golden_task(c) for c in cases])
+    for c, g in zip(cases, got):
+        if all(len(t) > 0 for t in g["aligned"]) and c["ends"][0] > c["starts"][0] and c["ends"][1] > c["starts"][1]:
+            assert g["score"] == sp_score(g["aligned"])
+
+
+@pytest.mark.parametrize("shape", [(63, 1000), (1000, 63), (1023, 1025), (1024, 1024), (1025, 1023),
+                                   (2049, 5000), (5000, 2049), (1, 3000), (3000, 1), (4097, 4095)])
+def test_ragged_shapes_vs_oracle(shape):
+    """Strip / tile boundary cases: lengths around multiples of 64*C and of the tile height."""
+    r = rng(shape[0] * 100003 + shape[1])
+    a = bytes(r.choice(b"ACGT") for _ in range(shape[0]))
+    b = random_family(r, 1, shape[1], mut=0.2, indel=0.05)[0] if shape[1] > 4 else b"ACG"[:shape[1]]
+    if shape[0] > 4 and shape[1] > 4:
+        # make them related so the path wanders but stays near the diagonal band
+        m = min(shape)
+        b = (a[:m] if len(a) >= m else a) + bytes(r.choice(b"ACGT") for _ in range(max(0, shape[1] - m)))
+        b = bytes(ch if r.random() > 0.1 else r.choice(b"ACGT") for ch in b)[:shape[1]]
+    rots = [r.randrange(len(a)), r.randrange(len(b))]
+    g = csa_amd.align_batch([([a, b], rots, None, None)])[0]
+    cons, strs, st = oracle_progressive([a, b], rots)
+    assert g["status"] == 0 and g["consensus"] == cons
+    assert g["aligned"] == strs
+    assert g["score"] == st.last_score
+
+
+def test_unrelated_pair_negative_scores():
+    a, b, ra, rb = synth_pair(3, length=3000, unrelated=True)
+    g = csa_amd.align_batch([([a, b], [ra, rb], None, None)])[0]
+    cons, strs, st = oracle_progressive([a, b], [ra, rb])
+    assert g["aligned"] == strs and g["score"] == st.last_score
+
+
+def test_families_vs_oracle_medium():
+    r = rng(99)
+    tasks = []
+    for n, length in [(3, 900), (5, 1500), (8, 700), (16, 300)]:
+        fam = random_family(r, n, length, mut=0.1, indel=0.06)
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["status"] == 0 and g["consensus"] == cons
+        assert g["aligned"] == strs
+        assert g["score"] == st.last_score
+        assert g["cells"] == st.cells and g["fills"] == st.fills
+
+
+def test_errors():
+    bad = csa_amd.align_batch([([b"ACGT", b"ACNT"], None, None, None), ([b"ACGT", b"ACGT"], None, None, None)])
+    assert bad[0]["status"] == csa_amd.ERR_ALPHABET
+    assert bad[1]["status"] == 0 and bad[1]["aligned"] == [b"ACGT", b"ACGT"]
+    bad = csa_amd.align_batch([([b"ACGT", b"ACGT"], [0, 0], [0, 0], [5, 4])])
+    assert bad[0]["status"] == csa_amd.ERR_ARG
+
+
+def _real_cases(setname, limit=None):
+    cases = [c for c in load_golden("real_pairs.json") if c["set"] == setname]
+    return cases[:limit] if limit else cases
+
+
+@pytest.mark.parametrize("setname", ["Primates", "Mammals"])
+def test_real_pairs_golden(setname):
+    """All whole-sequence pairs of the reference's example sets (config 2 + config 3):
+    alignment length, SP score and FNV-1a digest of the strings must equal the values the
+    compiled reference produced."""
+    _, seqs = read_fasta(os.path.join(GOLDEN, "data", setname + ".txt"))
+    cases = _real_cases(setname)
+    tasks = [([seqs[c["a"]], seqs[c["b"]]], c["rots"], None, None) for c in cases]
+    pb = csa_amd.PairBatch(tasks)
+    pb.run()
+    pb.sync()
+    got = pb.fetch()
+    pb.close()
+    for c, g in zip(cases, got):
+        assert g["status"] == 0
+        assert g["consensus"] == c["consensus"], (c["a"], c["b"])
+        assert g["score"] == c["sp"]
+        assert sp_score(g["aligned"]) == c["sp"]
+        assert "%08x" % fnv1a(g["aligned"]) == c["fnv1a"], (c["a"], c["b"])
+
+
+def test_config2_primates_pair_vs_survey_values():
+    """Config 2: Primates seq0 x seq1 with the reference's rotations 1947/1949:
+    16554 x 16563 cells, len 16589, SP 15197, digest 7ee50a99."""
+    _, seqs = read_fasta(os.path.join(GOLDEN, "data", "Primates.txt"))
+    g = csa_amd.align_batch([([seqs[0], seqs[1]], [1947, 1949], None, None)])[0]
+    assert g["consensus"] == 16589 and g["score"] == 15197
+    assert "%08x" % fnv1a(g["aligned"]) == "7ee50a99"
+    assert g["cells"] == 16554 * 16563
+
+
+def test_full_size_synthetic_properties():
+    """Config 4 shape (16 kbp synthetic circular pairs) at full size: de-gapped strings
+    equal the rotated inputs, equal lengths, SP(aligned) == DP score, the score is
+    invariant under exchanging the two sequences, and a repeated run is identical."""
+    pairs = [synth_pair(p) for p in range(6)]
+    tasks = [([a, b], [ra, rb], None, None) for a, b, ra, rb in pairs]
+    swapped = [([b, a], [rb, ra], None, None) for a, b, ra, rb in pairs]
+    pb = csa_amd.PairBatch(tasks + swapped)
+    pb.run()
+    pb.run()
+    pb.sync()
+    t = pb.timing()
+    got = pb.fetch()
+    pb.close()
+    assert t["cells"] == sum(len(a) * len(b) for a, b, _, _ in pairs) * 2
+    n = len(pairs)
+    for i, (a, b, ra, rb) in enumerate(pairs):
+        g, h = got[i], got[n + i]
+        assert g["status"] == 0 and h["status"] == 0
+        assert len(g["aligned"][0]) == len(g["aligned"][1]) == g["consensus"]
+        assert degap(g["aligned"][0]) == rotated(a, ra)
+        assert degap(g["aligned"][1]) == rotated(b, rb)
+        assert sp_score(g["aligned"]) == g["score"]
+        assert h["score"] == g["score"]
+    again = csa_amd.align_batch(tasks[:2])
+    for g, h in zip(got[:2], again):
+        assert g["aligned"] == h["aligned"] and g["score"] == h["score"]
+
+
+def test_full_size_pair_vs_oracle():
+    """One 16 kbp synthetic pair, full strings against the oracle."""
+    a, b, ra, rb = synth_pair(1)
+    g = csa_amd.align_batch([([a, b], [ra, rb], None, None)])[0]
+    cons, strs, st = oracle_progressive([a, b], [ra, rb])
+    assert g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
+
+
+def test_mixed_length_batch():
+    """Config 5 flavour at reduced scale: lengths spanning 100x in one batch."""
+    r = rng(2026)
+    tasks = []
+    for length in [120, 700, 2500, 9000, 300, 12000, 64, 5000]:
+        fam = random_family(r, 2, length, mut=0.1, indel=0.04)
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["aligned"] == strs and g["score"] == st.last_score
