@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the DP hot path on MI355X.
+
+Metric (BASELINE.json): DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, 1/2/4/8-GPU batch
+scaling.  Workload at every N: each GPU aligns its share of config 4 (1024 synthetic
+circular 16 kbp pairs sharded over 8 GPUs = 128 pairs per GPU, weak scaling); a "step" is
+one pass of the hot path -- matrix fill + direction traceback -- over that batch, inputs
+(packed sequences / profile tables) already resident in HBM.  One process per GPU
+(torch.distributed.run), no data-path collective; barriers and max-over-ranks timing only.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--len L]
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
+VALU_OPS_PER_CELL = 7                 # csadp_kernels.hip: bfe, lshl_add, add, add, min3, alignbit, and
+
+
+def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
+    """Time the CPU path on a bounded sample of the SAME workload on this host, 1 core:
+    the compiled reference (oracle/_ref, kind 'reference') when its prebuilt library
+    travelled with the repo, else the oracle port.  Also cross-checks the GPU strings."""
+    from helpers import have_ref, oracle_progressive, ref_progressive
+    try:  # keep freed matrix pages in the heap between calls (glibc would unmap and re-fault 1.4 GB per pair)
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-1, 1 << 30)   # M_TRIM_THRESHOLD
+        libc.mallopt(-3, 1 << 25)   # M_MMAP_THRESHOLD (32 MiB is the glibc maximum)
+    except Exception:
+        pass
+    kind = "reference" if have_ref() else "port"
+    run = ref_progressive if kind == "reference" else (lambda t, r: oracle_progressive(t, r))
+    cells = 0
+    secs = 0.0
+    n = 0
+    mismatches = 0
+    run(tasks[0][0], tasks[0][1])          # untimed warm-up: first touch of the 1.4 GB matrices
+    for t, g in zip(tasks, gpu_results):
+        t0 = time.perf_counter()
+        out = run(t[0], t[1])
+        dt = time.perf_counter() - t0
+        if kind == "reference":
+            dt = out[2]                    # wall time of ProgressiveDP alone, measured inside the shim
+        secs += dt
+        cells += len(t[0][0]) * len(t[0][1])
+        n += 1
+        if out[1] != g["aligned"]:
+            mismatches += 1
+        if secs > seconds_budget:
+            break
+    return {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
+            "sample": "%d of the step's 16 kbp pairs, whole ProgressiveDP (fill+traceback), %.1f s, "
+                      "GPU strings %s" % (n, secs, "identical" if mismatches == 0 else "MISMATCH x%d" % mismatches)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
+    ap.add_argument("--len", type=int, default=16384, dest="length")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import csa_amd
+    from csa_amd import dist as cdist
+    from csa_amd.synth import config4_tasks
+
+    rank, local_rank, world = cdist.env_world()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    csa_amd.init(device=local_rank)
+    group = cdist.Group(backend="nccl", device="cuda:%d" % local_rank)
+
+    # weak scaling: rank r owns global pairs [r*P, (r+1)*P) of the synthetic batch
+    tasks = config4_tasks(rank * args.pairs, args.pairs, args.length)
+    batch = csa_amd.PairBatch(tasks)            # validate, pack, upload: inputs now resident in HBM
+
+    def sync():
+        batch.sync()
+        torch.cuda.synchronize()
+
+    elapsed = cdist.timed_steps(group, batch.run, sync, args.steps, args.warmup)
+    tm = batch.timing()                          # HIP events of the last step, on the library stream
+    cells_step = group.sum(tm["cells"])
+    results = batch.fetch()
+    ok = all(r["status"] == 0 for r in results)
+
+    value = cells_step * args.steps / elapsed / 1e9
+    line = None
+    if rank == 0:
+        from helpers import degap, rotated, sp_score
+        # properties on this rank's first pairs: strings re-spell the inputs, SP == DP score
+        for t, r in list(zip(tasks, results))[:4]:
+            ok = ok and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
+            ok = ok and sp_score(r["aligned"]) == r["score"]
+        fill_s = tm["fill_ms"] / 1e3
+        launch_us = tm["fill_ms"] * 1e3 / max(tm["fill_launches"], 1)
+        alg_bytes = tm["dir_bytes"] + tm["border_bytes"]       # 0.25 B/cell directions + tile borders
+        achieved = alg_bytes / fill_s / 1e9
+        cups_fill = tm["cells"] / fill_s
+        line = {
+            "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, fill + traceback, whole job",
+            "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "data": "synthetic", "verified": bool(ok),
+            "per_gpu_gcups": round(value / args.gpus, 3),
+            "config": {"workload": "config 4 share: %d synthetic circular %d bp pairs per GPU "
+                                   "(global pairs rank*%d..), linear-gap NW fill + traceback, "
+                                   "bit-exact vs reference" % (args.pairs, args.length, args.pairs),
+                       "pairs_per_gpu": args.pairs, "seq_len": args.length,
+                       "cols_per_lane": int(os.environ.get("CSADP_COLS_PER_LANE", "16")),
+                       "tile_rows": int(os.environ.get("CSADP_TILE_ROWS", "128")),
+                       "parallelism": "tasks sharded over %d GPU(s), no collective" % args.gpus},
+            "kernel_ms": {"fill": round(tm["fill_ms"], 3), "traceback": round(tm["traceback_ms"], 3),
+                          "fill_launches": tm["fill_launches"], "fill_tiles": tm["fill_tiles"],
+                          "fill_gcups": round(cups_fill / 1e9, 2)},
+            "roofline": {"bound": "hbm", "kernel": "nw_fill_tiles", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                         "traffic": None,
+                         "bytes_per_launch": round(alg_bytes / max(tm["fill_launches"], 1)),
+                         "avg_launch_us": round(launch_us, 2),
+                         "note": "algorithmic bytes = 0.25 B/cell directions + tile borders (SURVEY 8d); "
+                                 "the binding roofline is integer VALU issue, see roofline_valu"},
+            "roofline_valu": {"bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL,
+                              "achieved": round(cups_fill * VALU_OPS_PER_CELL / 1e12, 3),
+                              "peak": round(VALU_PEAK_LANEOPS / 1e12, 2), "unit": "Tlane-op/s",
+                              "frac": round(cups_fill * VALU_OPS_PER_CELL / VALU_PEAK_LANEOPS, 4)},
+        }
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tasks, results)
+    batch.close()
+    group.barrier()
+    group.close()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

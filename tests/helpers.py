@@ -8,6 +8,7 @@ checker only, never by the product package (csa_amd).
 import ctypes
 import os
 import random
+import sys
 
 import numpy as np
 
@@ -161,46 +162,8 @@ def read_fasta(path):
 
 # ---- deterministic synthetic inputs -----------------
 
-MASK64 = (1 << 64) - 1
-
-
-class SplitMix64:
-    def __init__(self, seed):
-        self.s = seed & MASK64
-
-    def next(self):
-        self.s = (self.s + 0x9E3779B97F4A7C15) & MASK64
-        z = self.s
-        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
-        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
-        return z ^ (z >> 31)
-
-
-def synth_pair(p, length=16384, sub=0.10, ins=0.01, dele=0.01, unrelated=False):
-    """Pair p of the synthetic batch: (a, b_rotated, rot_a, rot_b).
-
-    a = uniform ACGT; b = a with per-base deletion, insertion, substitution
-    (draw order del, ins, sub), then left-rotated by r; the task rotations
-    {0, (len(b)-r) % len(b)} re-linearise the pair for the DP."""
-    g = SplitMix64(0x9E3779B97F4A7C15 * (p + 1))
-    a = bytes(b"ACGT"[g.next() & 3] for _ in range(length))
-    if unrelated:
-        b = bytes(b"ACGT"[g.next() & 3] for _ in range(length))
-    else:
-        out = bytearray()
-        scale = float(1 << 53)
-        for ch in a:
-            if (g.next() >> 11) / scale < dele:
-                continue
-            if (g.next() >> 11) / scale < ins:
-                out.append(b"ACGT"[g.next() & 3])
-            if (g.next() >> 11) / scale < sub:
-                ch = b"ACGT"[(b"ACGT".index(ch) + 1 + g.next() % 3) & 3]
-            out.append(ch)
-        b = bytes(out)
-    r = g.next() % len(b)
-    brot = b[r:] + b[:r]
-    return a, brot, 0, (len(b) - r) % len(b)
+sys.path.insert(0, ROOT)
+from csa_amd.synth import synth_pair  # noqa: E402,F401  (host-side workload generator, numpy)
 
 
 def random_family(rng, nseq, length, mut=0.15, indel=0.08, alphabet=b"ACGT"):
