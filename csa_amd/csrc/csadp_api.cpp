@@ -67,8 +67,7 @@ bool advance(Progressive &p)
 {
 	while (p.next_fill()) {
 		if (p.ncols() > 0) return true;
-		const int score = -p.border_i() * p.nrows();        /* dpmatrix[nrows][0], :967 */
-		if (p.apply_trace(nullptr, 0, p.nrows(), 0, score) != CSADP_OK) return false;
+		if (p.apply_trace(nullptr, 0, p.nrows(), 0) != CSADP_OK) return false;   /* score = dpmatrix[nrows][0], :967 */
 	}
 	return false;
 }
@@ -87,7 +86,7 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	if ((rc = fb.download()) != CSADP_OK) return rc;
 	for (size_t j = 0; j < active.size(); ++j) {
 		const int32_t *sm = fb.summary((int)j);
-		const int a = tasks[active[j]].apply_trace(fb.ops((int)j), sm[0], sm[1], sm[2], sm[3]);
+		const int a = tasks[active[j]].apply_trace(fb.ops((int)j), sm[0], sm[1], sm[2]);
 		if (a != CSADP_OK) status[active[j]] = a;
 	}
 	return CSADP_OK;
@@ -154,6 +153,7 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 		if (b->status[t] == CSADP_OK && advance(b->tasks[t])) b->active.push_back(t);
 	}
 	if (!b->active.empty()) {
+		b->fb.set_pipelined(true);
 		for (int t : b->active) b->fb.add(b->tasks[t].nrows(), b->tasks[t].ncols(), b->tasks[t].nprev(), b->tasks[t].border_i());
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
@@ -198,7 +198,7 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 		if (rc != CSADP_OK) return rc;
 		for (size_t j = 0; j < b->active.size(); ++j) {
 			const int32_t *sm = b->fb.summary((int)j);
-			const int a = b->tasks[b->active[j]].apply_trace(b->fb.ops((int)j), sm[0], sm[1], sm[2], sm[3]);
+			const int a = b->tasks[b->active[j]].apply_trace(b->fb.ops((int)j), sm[0], sm[1], sm[2]);
 			if (a != CSADP_OK) b->status[b->active[j]] = a;
 		}
 	}
@@ -235,7 +235,7 @@ int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fi
 			          ops.data(), &nops, &remj, &remk, &score);
 			if (rc != CSADP_OK) { result->status = rc; return rc; }
 		}
-		rc = p.apply_trace(ops.data(), nops, remj, remk, score);
+		rc = p.apply_trace(ops.data(), nops, remj, remk, &score);
 		if (rc != CSADP_OK) { result->status = rc; return rc; }
 	}
 	rc = p.finish(result);

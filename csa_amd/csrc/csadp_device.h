@@ -24,28 +24,27 @@ constexpr int kLanes = 64;           /* wave64 */
 enum : int { DIR_D = 0, DIR_L = 1, DIR_U = 2 };
 
 /* One matrix fill (one progressive step of one task).  Columns are owned by lanes:
- * global lane L = 64*strip + lane owns columns [L*C+1, L*C+C]; it computes row r at
- * global step T = (r-1) + L.  A tile is TR consecutive steps of one strip. */
+ * global lane L = 64*strip + lane owns columns [L*C+1, L*C+C]; at global step T it computes
+ * the R rows with 0-based index R*(T-L) .. R*(T-L)+R-1.  A tile is TR consecutive steps of
+ * one strip. */
 struct FillJob {
 	/* byte offsets into the batch arena (one hipMalloc); the kernels add them to their
 	 * arena kernel argument so every access is a global_* (not flat_*) instruction */
 	uint64_t coltab;          /* u32 [ncols_pad] f0 | f1<<6 | f2<<12 | f3<<18 | g<<24, f_c = i-sv[c], g = i-sv[4] */
-	uint64_t rowshift;        /* u8  [padl + steps_pad + 64] 6*code of row r at index padl + (r-1), zero padded   */
+	uint64_t rowshift;        /* u8  [padl + R*steps_pad + R*64] 6*code of row r at index padl + (r-1), zero padded */
 	uint64_t top;             /* i32 [ncols_pad + 1] cost of border row 0 (possibly stale, survey Q1)             */
-	uint64_t handoff;         /* i32 [nstrips][hpitch] right-edge cost of a strip after step T at index T+1       */
-	uint64_t state;           /* i32 [nstrips][C+2][64] lane registers between two tiles of a strip               */
-	uint64_t dirs;            /* u32 [nstrips][steps_pad][C/16][64] sixteen 2-bit codes per word                  */
-	uint64_t final_row;       /* i32 [C] costs of the lane owning column ncols after row nrows                   */
+	uint64_t handoff;         /* i32 [nstrips][hpitch][R] right-edge cost after step T, row q, at index R*(T+1)+q */
+	uint64_t state;           /* i32 [nstrips][C+1+R][64] lane registers between two tiles of a strip             */
+	uint64_t dirs;            /* u32 [nstrips][steps_pad][R][C/16][64] sixteen 2-bit codes per word               */
 	uint64_t ops;             /* u8  [nrows + ncols + 64] traceback ops, walk order (from (nrows,ncols) back)     */
-	uint64_t summary;         /* i32 [4] nops, remaining rows j, remaining cols k, H[nrows][ncols]                */
+	uint64_t summary;         /* i32 [4] nops, remaining rows j, remaining cols k, 0                              */
 	int32_t nrows, ncols;
 	int32_t nstrips;
 	int32_t steps_pad;        /* number of steps allocated per strip (multiple of TR)                         */
 	int32_t hpitch;           /* steps_pad + 64                                                               */
-	int32_t padl;             /* left padding of rowshift (multiple of 64, >= 64*nstrips + 64)                */
+	int32_t padl;             /* left padding of rowshift = R*(64*nstrips + 64)                               */
 	int32_t upc;              /* 8*i + 2                                                                       */
 	int32_t leftmul;          /* 4*(left_i + i): cost of border column 0 is leftmul * r                       */
-	int32_t tf, lf;           /* step and global lane of the final cell (nrows, ncols)                        */
 };
 
 struct TileRef {

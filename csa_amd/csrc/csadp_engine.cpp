@@ -64,10 +64,15 @@ int Engine::init(const csadp_config *cfg)
 	device_ = dev;
 	snprintf(name_, sizeof(name_), "%s (%s)", prop.name, prop.gcnArchName);
 	cus_ = prop.multiProcessorCount;
-	HIP_TRY(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+	slots_ = env_int("CSADP_SLOTS", 2);
+	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
+	for (int i = 0; i < slots_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
 	C_ = env_int("CSADP_COLS_PER_LANE", 16);
+	R_ = env_int("CSADP_ROWS_PER_STEP", 2);
 	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 128);
 	if (C_ != 16 && C_ != 32) return CSADP_ERR_ARG;
+	if (R_ != 1 && R_ != 2 && R_ != 4) return CSADP_ERR_ARG;
+	if (C_ == 32 && R_ == 4) return CSADP_ERR_ARG;
 	if (TR_ != 64 && TR_ != 128 && TR_ != 256) return CSADP_ERR_ARG;
 	verbose_ = cfg && cfg->verbose;
 	ready_ = true;
@@ -77,9 +82,11 @@ int Engine::init(const csadp_config *cfg)
 void Engine::shutdown()
 {
 	if (!ready_) return;
-	(void)hipStreamSynchronize(stream_);
-	(void)hipStreamDestroy(stream_);
-	stream_ = nullptr;
+	for (int i = 0; i < slots_; ++i) {
+		(void)hipStreamSynchronize(streams_[i]);
+		(void)hipStreamDestroy(streams_[i]);
+		streams_[i] = nullptr;
+	}
 	ready_ = false;
 }
 
@@ -90,8 +97,9 @@ FillBatch::~FillBatch()
 	if (arena_) (void)hipFree(arena_);
 	if (h_in_) (void)hipHostFree(h_in_);
 	if (h_res_) (void)hipHostFree(h_res_);
-	for (auto &e : ev_)
-		if (e) (void)hipEventDestroy(e);
+	for (auto &slot : ev_)
+		for (auto &e : slot)
+			if (e) (void)hipEventDestroy(e);
 }
 
 void FillBatch::clear()
@@ -121,7 +129,7 @@ int FillBatch::layout()
 {
 	Engine &E = Engine::get();
 	if (!E.ready()) return CSADP_ERR_NO_DEVICE;
-	const int C = E.C(), TR = E.TR(), W = C / 16;
+	const int C = E.C(), R = E.R(), TR = E.TR(), W = C / 16;
 	const int nj = (int)jobs_.size();
 	extra_.assign(nj, Extra());
 	cells_ = dir_bytes_ = border_bytes_ = 0;
@@ -137,20 +145,19 @@ int FillBatch::layout()
 		const int lanes = (J.ncols + C - 1) / C;
 		J.nstrips = (lanes + kLanes - 1) / kLanes;
 		extra_[j].ncols_pad = J.nstrips * kLanes * C;
-		J.steps_pad = (int)align_up((size_t)J.nrows + (size_t)kLanes * J.nstrips, TR);
+		const int rsteps = (J.nrows + R - 1) / R;                 /* lane-steps that hold real rows */
+		J.steps_pad = (int)align_up((size_t)rsteps + (size_t)kLanes * J.nstrips, TR);
 		J.hpitch = J.steps_pad + 64;
-		J.padl = kLanes * J.nstrips + 64;
-		J.lf = (J.ncols - 1) / C;
-		J.tf = J.nrows - 1 + J.lf;
+		J.padl = R * (kLanes * J.nstrips + 64);
 		for (int s = 0; s < J.nstrips; ++s) {
 			const int a0 = (kLanes * s) / TR;
-			const int a1 = (J.nrows - 1 + kLanes * s + 63) / TR;
+			const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
 			ndiag = std::max(ndiag, a1 + s + 1);
 			if ((int)diag_count.size() < a1 + s + 1) diag_count.resize(a1 + s + 1, 0);
 			for (int a = a0; a <= a1; ++a) diag_count[a + s]++;
 		}
 		cells_ += (long long)J.nrows * J.ncols;
-		dir_bytes_ += (long long)J.nrows * (long long)lanes * 4 * W;
+		dir_bytes_ += (long long)J.nrows * (long long)lanes * 4 * W;   /* 2 bit per cell, whole words */
 	}
 	diag_off_.assign((size_t)ndiag + 1, 0);
 	for (int d = 0; d < ndiag; ++d) diag_off_[d + 1] = diag_off_[d] + (size_t)diag_count[d];
@@ -159,9 +166,10 @@ int FillBatch::layout()
 		std::vector<size_t> cur(diag_off_.begin(), diag_off_.end() - 1);
 		for (int j = 0; j < nj; ++j) {
 			const FillJob &J = jobs_[j];
+			const int rsteps = (J.nrows + R - 1) / R;
 			for (int s = 0; s < J.nstrips; ++s) {
 				const int a0 = (kLanes * s) / TR;
-				const int a1 = (J.nrows - 1 + kLanes * s + 63) / TR;
+				const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
 				for (int a = a0; a <= a1; ++a) {
 					TileRef t;
 					t.job = j;
@@ -171,15 +179,19 @@ int FillBatch::layout()
 					tiles_[cur[a + s]++] = t;
 				}
 				/* hand-off ints written once and read once, lane state saved + restored per tile */
-				border_bytes_ += 2LL * 4 * (a1 - a0 + 1) * TR + 2LL * 4 * (a1 - a0 + 1) * (C + 2) * kLanes;
+				border_bytes_ += 2LL * 4 * (a1 - a0 + 1) * TR * R + 2LL * 4 * (a1 - a0 + 1) * (C + 1 + R) * kLanes;
 			}
 		}
 	}
 
-	/* arena offsets */
+	/* arena offsets: shared inputs, then one result + scratch set per slot */
+	nslots_ = pipelined_ ? E.slots() : 1;
+	next_slot_ = 0;
 	size_t off = 0;
-	jobs_off_ = off;
-	off = align_up(off + (size_t)nj * sizeof(FillJob), 256);
+	for (int sl = 0; sl < nslots_; ++sl) {
+		jobs_off_[sl] = off;
+		off = align_up(off + (size_t)nj * sizeof(FillJob), 256);
+	}
 	tiles_off_ = off;
 	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
 	for (int j = 0; j < nj; ++j) {
@@ -188,33 +200,34 @@ int FillBatch::layout()
 		X.in_coltab = J.coltab = off;
 		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
 		X.in_rowshift = J.rowshift = off;
-		off = align_up(off + (size_t)J.padl + J.steps_pad + 64, 256);
+		off = align_up(off + (size_t)J.padl + (size_t)R * J.steps_pad + (size_t)R * 64 + 64, 256);
 		X.in_top = J.top = off;
 		off = align_up(off + ((size_t)X.ncols_pad + 1) * 4, 256);
 	}
 	in_bytes_ = off;
-	res_off_ = off;
-	for (int j = 0; j < nj; ++j) {
-		FillJob &J = jobs_[j];
-		Extra &X = extra_[j];
-		J.summary = off;
-		X.res_summary = off - res_off_;
-		off += 64;
-		J.ops = off;
-		X.res_ops = off - res_off_;
-		off = align_up(off + (size_t)J.nrows + J.ncols + 64, 256);
-	}
-	res_bytes_ = off - res_off_;
-	for (int j = 0; j < nj; ++j) {
-		FillJob &J = jobs_[j];
-		J.final_row = off;
-		off = align_up(off + (size_t)C * 4, 256);
-		J.state = off;
-		off = align_up(off + (size_t)J.nstrips * (C + 2) * kLanes * 4, 256);
-		J.handoff = off;
-		off = align_up(off + (size_t)J.nstrips * J.hpitch * 4, 256);
-		J.dirs = off;
-		off = align_up(off + (size_t)J.nstrips * J.steps_pad * W * kLanes * 4, 256);
+	std::vector<std::vector<FillJob>> slot_jobs((size_t)nslots_, jobs_);
+	for (int sl = 0; sl < nslots_; ++sl) {
+		res_off_[sl] = off;
+		for (int j = 0; j < nj; ++j) {
+			FillJob &J = slot_jobs[(size_t)sl][(size_t)j];
+			Extra &X = extra_[j];
+			J.summary = off;
+			X.res_summary = off - res_off_[sl];
+			off += 64;
+			J.ops = off;
+			X.res_ops = off - res_off_[sl];
+			off = align_up(off + (size_t)J.nrows + J.ncols + 64, 256);
+		}
+		res_bytes_ = off - res_off_[sl];
+		for (int j = 0; j < nj; ++j) {
+			FillJob &J = slot_jobs[(size_t)sl][(size_t)j];
+			J.state = off;
+			off = align_up(off + (size_t)J.nstrips * (C + 1 + R) * kLanes * 4, 256);
+			J.handoff = off;
+			off = align_up(off + (size_t)J.nstrips * J.hpitch * R * 4, 256);
+			J.dirs = off;
+			off = align_up(off + (size_t)J.nstrips * J.steps_pad * R * W * kLanes * 4, 256);
+		}
 	}
 	total_bytes_ = off;
 
@@ -242,10 +255,13 @@ int FillBatch::layout()
 		HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
 		h_res_cap_ = res_bytes_;
 	}
-	for (auto &e : ev_)
-		if (!e) HIP_TRY(hipEventCreate(&e));
+	for (int sl = 0; sl < nslots_; ++sl)
+		for (auto &e : ev_[sl])
+			if (!e) HIP_TRY(hipEventCreate(&e));
 	memset(h_in_, 0, in_bytes_);
-	memcpy(h_in_ + jobs_off_, jobs_.data(), (size_t)nj * sizeof(FillJob));
+	for (int sl = 0; sl < nslots_; ++sl)
+		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(FillJob));
+	jobs_ = slot_jobs[0];
 	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
 	laid_out_ = true;
 	ran_ = false;
@@ -260,7 +276,10 @@ int FillBatch::ncols_pad(int j) const { return extra_[j].ncols_pad; }
 int FillBatch::upload()
 {
 	if (!laid_out_) return CSADP_ERR_STATE;
-	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, Engine::get().stream()));
+	/* every slot's stream must see the inputs: copy on slot 0 and wait (upload is not on the
+	 * timed path; run() calls may follow on any stream) */
+	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, Engine::get().stream(0)));
+	HIP_TRY(hipStreamSynchronize(Engine::get().stream(0)));
 	return CSADP_OK;
 }
 
@@ -268,33 +287,37 @@ int FillBatch::run()
 {
 	if (!laid_out_) return CSADP_ERR_STATE;
 	Engine &E = Engine::get();
-	hipStream_t st = E.stream();
-	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_);
+	const int sl = next_slot_;
+	next_slot_ = (next_slot_ + 1) % nslots_;
+	last_slot_ = sl;
+	hipStream_t st = E.stream(sl);
+	hipEvent_t *ev = ev_[sl];
+	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]);
 	const TileRef *dtiles = reinterpret_cast<const TileRef *>(arena_ + tiles_off_);
-	HIP_TRY(hipEventRecord(ev_[0], st));
+	HIP_TRY(hipEventRecord(ev[0], st));
 	const int ndiag = (int)diag_off_.size() - 1;
 	for (int d = 0; d < ndiag; ++d) {
 		const int cnt = (int)(diag_off_[d + 1] - diag_off_[d]);
-		HIP_TRY(launch_fill(E.C(), E.TR(), arena_, djobs, dtiles + diag_off_[d], cnt, st));
+		HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), arena_, djobs, dtiles + diag_off_[d], cnt, st));
 	}
-	HIP_TRY(hipEventRecord(ev_[1], st));
-	HIP_TRY(launch_traceback(E.C(), arena_, djobs, (int)jobs_.size(), st));
-	HIP_TRY(hipEventRecord(ev_[2], st));
+	HIP_TRY(hipEventRecord(ev[1], st));
+	HIP_TRY(launch_traceback(E.C(), E.R(), arena_, djobs, (int)jobs_.size(), st));
+	HIP_TRY(hipEventRecord(ev[2], st));
 	ran_ = true;
 	return CSADP_OK;
 }
 
 int FillBatch::sync()
 {
-	HIP_TRY(hipStreamSynchronize(Engine::get().stream()));
+	for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipStreamSynchronize(Engine::get().stream(sl)));
 	return CSADP_OK;
 }
 
 int FillBatch::download()
 {
 	if (!ran_) return CSADP_ERR_STATE;
-	hipStream_t st = Engine::get().stream();
-	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_, res_bytes_, hipMemcpyDeviceToHost, st));
+	hipStream_t st = Engine::get().stream(last_slot_);
+	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], res_bytes_, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	return CSADP_OK;
 }
@@ -306,10 +329,11 @@ int FillBatch::timing(csadp_timing *t)
 {
 	if (!ran_) return CSADP_ERR_STATE;
 	memset(t, 0, sizeof(*t));
-	HIP_TRY(hipEventSynchronize(ev_[2]));
-	HIP_TRY(hipEventElapsedTime(&t->fill_ms, ev_[0], ev_[1]));
-	HIP_TRY(hipEventElapsedTime(&t->traceback_ms, ev_[1], ev_[2]));
-	HIP_TRY(hipEventElapsedTime(&t->total_ms, ev_[0], ev_[2]));
+	hipEvent_t *ev = ev_[last_slot_];
+	HIP_TRY(hipEventSynchronize(ev[2]));
+	HIP_TRY(hipEventElapsedTime(&t->fill_ms, ev[0], ev[1]));
+	HIP_TRY(hipEventElapsedTime(&t->traceback_ms, ev[1], ev[2]));
+	HIP_TRY(hipEventElapsedTime(&t->total_ms, ev[0], ev[2]));
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;
 	t->fill_tiles = (long long)tiles_.size();

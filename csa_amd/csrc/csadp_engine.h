@@ -21,8 +21,11 @@ public:
 	int init(const csadp_config *cfg);
 	void shutdown();
 	bool ready() const { return ready_; }
-	hipStream_t stream() const { return stream_; }
+	static constexpr int kMaxSlots = 4;
+	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
+	int slots() const { return slots_; }
 	int C() const { return C_; }
+	int R() const { return R_; }
 	int TR() const { return TR_; }
 	int device() const { return device_; }
 	const char *name() const { return name_; }
@@ -33,10 +36,11 @@ private:
 	bool ready_ = false;
 	bool verbose_ = false;
 	int device_ = 0;
-	int C_ = 16, TR_ = 128;
+	int C_ = 16, R_ = 2, TR_ = 128;
 	int cus_ = 0;
 	char name_[256] = {0};
-	hipStream_t stream_ = nullptr;
+	int slots_ = 2;
+	hipStream_t streams_[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 /*
@@ -45,8 +49,12 @@ private:
  *
  * Arena layout in HBM (one allocation, offsets in FillJob):
  *   [ jobs | tiles | per-job inputs: coltab, rowshift, top ]   <- one H2D copy
- *   [ per-job results: summary, ops ]                          <- one D2H copy
- *   [ per-job scratch: final_row, state, handoff, dirs ]       <- never leaves the device
+ *   [ per-job results: summary, ops ]                          <- one D2H copy      } x slots
+ *   [ per-job scratch: state, handoff, dirs ]                  <- never leaves HBM  } x slots
+ *
+ * Slots: consecutive run() calls rotate over `slots` independent result+scratch sets, each
+ * on its own HIP stream, so the tail of one pass (few tiles per launch, then the latency-
+ * bound traceback) overlaps the head of the next.  Inputs are read-only and shared.
  */
 class FillBatch {
 public:
@@ -55,6 +63,8 @@ public:
 	FillBatch(const FillBatch &) = delete;
 	FillBatch &operator=(const FillBatch &) = delete;
 
+	/* pipelined = rotate run() calls over Engine::slots() result/scratch sets; otherwise one */
+	void set_pipelined(bool on) { pipelined_ = on; }
 	void clear();
 	/* register a fill; returns its job index */
 	int add(int nrows, int ncols, int nprev, int left_i);
@@ -67,11 +77,11 @@ public:
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
 	int upload();                    /* inputs -> HBM (async on the engine stream) */
-	int run();                       /* enqueue all fill launches + the traceback */
-	int sync();
-	int download();                  /* results -> host (blocking) */
+	int run();                       /* enqueue all fill launches + the traceback on the next slot */
+	int sync();                      /* wait for every slot */
+	int download();                  /* results of the LAST run() -> host (blocking) */
 	const uint8_t *ops(int j) const;
-	const int32_t *summary(int j) const;   /* nops, remj, remk, score */
+	const int32_t *summary(int j) const;   /* nops, remj, remk, 0 */
 	int timing(csadp_timing *t);
 
 private:
@@ -80,16 +90,18 @@ private:
 	std::vector<Extra> extra_;
 	std::vector<TileRef> tiles_;
 	std::vector<size_t> diag_off_;   /* tiles_ index of the first tile of each diagonal, +1 sentinel */
-	size_t in_bytes_ = 0, res_off_ = 0, res_bytes_ = 0, total_bytes_ = 0;
-	size_t jobs_off_ = 0, tiles_off_ = 0;
+	size_t in_bytes_ = 0, res_bytes_ = 0, total_bytes_ = 0;
+	size_t jobs_off_[Engine::kMaxSlots] = {0, 0, 0, 0}, res_off_[Engine::kMaxSlots] = {0, 0, 0, 0};
+	size_t tiles_off_ = 0;
+	int nslots_ = 1, next_slot_ = 0, last_slot_ = 0;
 	uint8_t *arena_ = nullptr;
 	size_t arena_cap_ = 0;
 	uint8_t *h_in_ = nullptr;        /* pinned mirror of the input region */
 	size_t h_in_cap_ = 0;
 	uint8_t *h_res_ = nullptr;       /* pinned mirror of the result region */
 	size_t h_res_cap_ = 0;
-	hipEvent_t ev_[3] = {nullptr, nullptr, nullptr};
-	bool laid_out_ = false, ran_ = false;
+	hipEvent_t ev_[Engine::kMaxSlots][3] = {};
+	bool laid_out_ = false, ran_ = false, pipelined_ = false;
 	long long cells_ = 0, dir_bytes_ = 0, border_bytes_ = 0;
 };
 

@@ -9,11 +9,11 @@
  *
  * Mapping.  A wave owns a strip of 64*C columns; lane l keeps the C cells of its columns of
  * the previous row in registers.  The wave is skewed: at global step T lane L (global lane
- * index over all strips) computes row T-L+1, so the left neighbour's value of the same row
- * was produced one step earlier and arrives with ONE cross-lane instruction
- * (v_mov_b32_dpp wave_shr:1); lane 0 takes the value of the previous strip (or the border
- * column) through the DPP "old" operand, pre-loaded from LDS.  A tile is TR consecutive
- * steps of one strip -- a parallelogram in (row, column) space, so there is no per-tile
+ * index over all strips) computes the R rows R*(T-L) .. R*(T-L)+R-1, so the left
+ * neighbour's values of the same rows were produced one step earlier and arrive with one
+ * cross-lane instruction per row (v_mov_b32_dpp wave_shr:1); lane 0 takes the values of the
+ * previous strip (or the border column) through the DPP "old" operand, pre-loaded from
+ * LDS.  A tile is TR consecutive steps of one strip -- a parallelogram in (row, column) space, so there is no per-tile
  * pipeline ramp; the ramp exists once per matrix.  Tile (a, s) needs tiles (a-1, s) [lane
  * registers, via FillJob::state] and (a, s-1), (a-1, s-1) [right edge, via
  * FillJob::handoff]: the host launches one grid per tile anti-diagonal a+s, for all tasks
@@ -22,8 +22,8 @@
  * Per cell: v_bfe_u32 (profile field) + v_lshl_add_u32 (diag) + 2 v_add (up, left) +
  * v_min3_i32 + v_alignbit_b32 (shift the 2-bit tag into the direction word) + v_and (clear
  * the tag) = 7 VALU instructions; see csadp_device.h for the cost/tag representation.
- * Directions are stored in the order they are produced (strip, step, lane): one coalesced
- * 256-byte store per wave and step; the traceback kernel addresses the same layout.
+ * Directions are stored in the order they are produced (strip, step, row, lane): coalesced
+ * 256-byte stores; the traceback kernel addresses the same layout.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,17 +35,107 @@ namespace csadp {
 
 #define DPP_WAVE_SHR1 0x138
 
-template <int C, int TR>
+/*
+ * TR steps of one strip.  One step = R consecutive rows x C columns per lane.  The R rows
+ * form R dependency chains that run one column apart (row rho works on column j while row
+ * rho+1 works on column j-1), so a single wave always has R independent instruction
+ * streams in flight -- the integer ops of the recurrence issue at one per ~9 cycles when
+ * dependent and one per 4-5 cycles when independent on gfx950 (tools/valu_microbench.hip).
+ *
+ * RAMP = the strip's first tile: lanes whose row index is still negative must keep the
+ * border values they were initialised with, so the cell block is predicated.  All other
+ * tiles (STEADY) run the cell block unconditionally: lanes that have passed the last row
+ * compute values nobody reads (dependencies only point up and left), which removes the
+ * per-step branch and the register copies it forces.  LDS operands of step t+1 (lane-0
+ * feed, row letters) are fetched during step t.
+ */
+template <int C, int R, int TR, bool RAMP>
+__device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32_t (&leftc)[C], int32_t (&hup)[C],
+                                           int32_t &diag_in, int32_t (&last)[R], const int32_t *feed,
+                                           const uint8_t *myrsh, int32_t *edge, uint32_t *dirs, int r0s,
+                                           int upc, int lane)
+{
+	constexpr int W = C / 16;
+	int32_t fnext[R];
+	uint32_t snext[R];
+#pragma unroll
+	for (int q = 0; q < R; ++q) {
+		fnext[q] = feed[q];
+		snext[q] = myrsh[q];
+	}
+#pragma unroll 2
+	for (int t = 0; t < TR; ++t) {
+		int32_t inl[R];
+		uint32_t sh[R];
+#pragma unroll
+		for (int q = 0; q < R; ++q) {
+			sh[q] = snext[q];
+			inl[q] = __builtin_amdgcn_update_dpp(fnext[q], last[q], DPP_WAVE_SHR1, 0xf, 0xf, false);
+		}
+#pragma unroll
+		for (int q = 0; q < R; ++q) {
+			fnext[q] = feed[(t + 1) * R + q];
+			snext[q] = myrsh[(t + 1) * R + q];
+		}
+		uint32_t acc[R][W];
+#pragma unroll
+		for (int q = 0; q < R; ++q)
+#pragma unroll
+			for (int w = 0; w < W; ++w) acc[q][w] = 0;
+		if (!RAMP || r0s + t >= 0) {
+			int32_t cd[R], cl[R];
+			cd[0] = diag_in;
+#pragma unroll
+			for (int q = 1; q < R; ++q) cd[q] = inl[q - 1];
+#pragma unroll
+			for (int q = 0; q < R; ++q) cl[q] = inl[q];
+			/* skewed sweep: iteration i touches cell (row q, column i - q) of every row */
+#pragma unroll
+			for (int i = 0; i < C + R - 1; ++i) {
+#pragma unroll
+				for (int q = 0; q < R; ++q) {
+					const int c = i - q;
+					if (c < 0 || c >= C) continue;
+					const uint32_t f = __builtin_amdgcn_ubfe(tab[c], sh[q], 6);
+					const int32_t dg = (int32_t)(f << 3) + cd[q];
+					const int32_t up = hup[c] + upc;
+					const int32_t lf = cl[q] + leftc[c];
+					int32_t h = min(min(dg, up), lf);
+					acc[q][c / 16] = __builtin_amdgcn_alignbit((uint32_t)h, acc[q][c / 16], 2);
+					cd[q] = hup[c];
+					h &= ~3;
+					hup[c] = h;
+					cl[q] = h;
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < R; ++q) last[q] = cl[q];
+		}
+		diag_in = inl[R - 1];
+#pragma unroll
+		for (int q = 0; q < R; ++q)
+#pragma unroll
+			for (int w = 0; w < W; ++w) dirs[((size_t)t * R + q) * (W * kLanes) + w * kLanes] = acc[q][w];
+		if (lane == kLanes - 1) {                              /* right edge of the strip */
+#pragma unroll
+			for (int q = 0; q < R; ++q) edge[t * R + q] = last[q];
+		}
+	}
+}
+
+template <int C, int R, int TR>
 __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
                                                     const FillJob *__restrict__ jobs,
                                                     const TileRef *__restrict__ tiles)
 {
 	static_assert(C % 16 == 0, "a lane-step must fill whole direction words");
-	static_assert(TR % 64 == 0, "hand-off words are flushed every 64 steps");
+	static_assert(TR % 64 == 0, "tile inputs are staged 64 lanes at a time");
+	static_assert(R == 1 || R == 2 || R == 4, "rows per step");
 	constexpr int W = C / 16;
 
-	__shared__ int32_t feed[TR];                                     /* lane-0 input per step   */
-	__shared__ __attribute__((aligned(16))) uint8_t rsh[TR + 64];    /* 6*code of the tile rows */
+	__shared__ __attribute__((aligned(16))) int32_t feed[R * (TR + 1) + 4];    /* lane-0 inputs        */
+	__shared__ __attribute__((aligned(16))) int32_t edge[R * TR];              /* lane-63 outputs      */
+	__shared__ __attribute__((aligned(16))) uint8_t rsh[R * (TR + 64) + 16];   /* 6*code of tile rows  */
 
 	const TileRef tr = tiles[blockIdx.x];
 	const FillJob &J = jobs[tr.job];
@@ -53,30 +143,30 @@ __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
 	const int s = tr.s;
 	const int T0 = tr.a * TR;
 	const int L = s * kLanes + lane;
-	const int nrows = J.nrows;
 	const int upc = J.upc;
 
 	/* ---- stage the tile inputs in LDS ------------------------------------------------ */
 	if (s == 0) {
-		const int lm = J.leftmul;
-		for (int t = lane; t < TR; t += kLanes) feed[t] = lm * (T0 + t + 1);
+		const int lm = J.leftmul;                 /* border column: cost[r][0] = leftmul * r */
+		for (int e = lane; e < R * TR; e += kLanes) feed[e] = lm * (R * T0 + e + 1);
 	} else {
-		const int32_t *h = reinterpret_cast<const int32_t *>(arena + J.handoff) + (size_t)(s - 1) * J.hpitch + T0;  /* value after step T-1 */
-		for (int t = lane; t < TR; t += kLanes) feed[t] = h[t];
+		/* value after step T-1 of row q sits at index R*T + q */
+		const int32_t *h = reinterpret_cast<const int32_t *>(arena + J.handoff) + ((size_t)(s - 1) * J.hpitch + T0) * R;
+		for (int e = lane; e < R * TR; e += kLanes) feed[e] = h[e];
 	}
 	{
-		/* rows r0 = T - L (0-based) for T in [T0, T0+TR), lanes 0..63:  rsh[j] holds row
-		 * T0 - 64*s - 64 + j, lane l at local step t reads j = t + 64 - l */
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowshift + (J.padl + T0 - s * kLanes - 64));
+		/* rsh[j] holds row R*(T0 - 64*s - 64) + j; lane l at local step t, row q reads
+		 * j = R*(t + 64 - l) + q */
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowshift + (J.padl + R * (T0 - s * kLanes - 64)));
 		uint32_t *dst = reinterpret_cast<uint32_t *>(rsh);
-		for (int j = lane; j < (TR + 64) / 4; j += kLanes) dst[j] = src[j];
+		for (int j = lane; j < R * (TR + 64) / 4; j += kLanes) dst[j] = src[j];
 	}
 
 	/* ---- per-lane column tables and the row above, in registers ----------------------- */
 	uint32_t tab[C];
 	int32_t leftc[C];
 	int32_t hup[C];
-	int32_t in_left, last_clean;
+	int32_t diag_in, last[R];
 	{
 		const uint32_t *ct = reinterpret_cast<const uint32_t *>(arena + J.coltab) + (size_t)L * C;
 #pragma unroll
@@ -85,172 +175,209 @@ __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
 			leftc[c] = (int32_t)(((tab[c] >> 24) & 63u) << 2) + 1;
 		}
 	}
-	int32_t *st = reinterpret_cast<int32_t *>(arena + J.state) + (size_t)s * (C + 2) * kLanes + lane;
+	int32_t *st = reinterpret_cast<int32_t *>(arena + J.state) + (size_t)s * (C + 1 + R) * kLanes + lane;
 	if (tr.first) {
 		const int32_t *tp = reinterpret_cast<const int32_t *>(arena + J.top) + (size_t)L * C;     /* tp[0] = column left of the lane's first */
-		in_left = tp[0];
+		diag_in = tp[0];
 #pragma unroll
 		for (int c = 0; c < C; ++c) hup[c] = tp[c + 1];
-		last_clean = hup[C - 1];
+#pragma unroll
+		for (int q = 0; q < R; ++q) last[q] = hup[C - 1];
 	} else {
 #pragma unroll
 		for (int c = 0; c < C; ++c) hup[c] = st[c * kLanes];
-		in_left = st[C * kLanes];
-		last_clean = st[(C + 1) * kLanes];
+		diag_in = st[C * kLanes];
+#pragma unroll
+		for (int q = 0; q < R; ++q) last[q] = st[(C + 1 + q) * kLanes];
 	}
 	__syncthreads();
 
-	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (W * kLanes) + lane;
-	int32_t *hand = reinterpret_cast<int32_t *>(arena + J.handoff) + (size_t)s * J.hpitch + T0 + 1 + lane;
-	const uint8_t *myrsh = rsh + 64 - lane;
-	const int tf_local = J.tf - T0;
-	int32_t coll = 0;
+	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (R * W * kLanes) + lane;
+	const uint8_t *myrsh = rsh + R * (64 - lane);
+	const int r0s = T0 - L;                           /* step-units row index of this lane at local step 0 */
 
-#pragma unroll 2
-	for (int t = 0; t < TR; ++t) {
-		const int r = T0 + t - L;                       /* 0-based row of this lane at this step */
-		const int32_t in_diag = in_left;
-		in_left = __builtin_amdgcn_update_dpp(feed[t], last_clean, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		uint32_t acc[W];
-#pragma unroll
-		for (int w = 0; w < W; ++w) acc[w] = 0;
-
-		if ((unsigned)r < (unsigned)nrows) {
-			const uint32_t sh = myrsh[t];
-			int32_t cd = in_diag;
-			int32_t cl = in_left;
-#pragma unroll
-			for (int c = 0; c < C; ++c) {
-				const uint32_t f = __builtin_amdgcn_ubfe(tab[c], sh, 6);
-				const int32_t dg = (int32_t)(f << 3) + cd;
-				const int32_t up = hup[c] + upc;
-				const int32_t lf = cl + leftc[c];
-				int32_t h = min(min(dg, up), lf);
-				acc[c / 16] = __builtin_amdgcn_alignbit((uint32_t)h, acc[c / 16], 2);
-				cd = hup[c];
-				h &= ~3;
-				hup[c] = h;
-				cl = h;
-			}
-			last_clean = cl;
-		}
-#pragma unroll
-		for (int w = 0; w < W; ++w) dirs[(size_t)t * (W * kLanes) + w * kLanes] = acc[w];
-
-		/* right edge of the strip: collect lane 63's value of 64 steps, store coalesced */
-		{
-			const int32_t edge = __builtin_amdgcn_readlane(last_clean, 63);
-			coll = (lane == (t & 63)) ? edge : coll;
-		}
-		if ((t & 63) == 63) hand[t - 63] = coll;
-
-		if (t == tf_local && L == J.lf) {
-			int32_t *fr = reinterpret_cast<int32_t *>(arena + J.final_row);
-#pragma unroll
-			for (int c = 0; c < C; ++c) fr[c] = hup[c];
-		}
-	}
+	if (tr.first)
+		fill_steps<C, R, TR, true>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, upc, lane);
+	else
+		fill_steps<C, R, TR, false>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, upc, lane);
 
 #pragma unroll
 	for (int c = 0; c < C; ++c) st[c * kLanes] = hup[c];
-	st[C * kLanes] = in_left;
-	st[(C + 1) * kLanes] = last_clean;
+	st[C * kLanes] = diag_in;
+#pragma unroll
+	for (int q = 0; q < R; ++q) st[(C + 1 + q) * kLanes] = last[q];
+	__syncthreads();
+	{
+		/* value after step T is read by the next strip at index R*(T+1) + q */
+		int32_t *hand = reinterpret_cast<int32_t *>(arena + J.handoff) + ((size_t)s * J.hpitch + T0 + 1) * R;
+		for (int e = lane; e < R * TR; e += kLanes) hand[e] = edge[e];
+	}
 }
 
 /*
- * K2.  One wave per fill.  The wave pulls a window of 64 steps x 64 lanes of direction
- * words of the current strip into LDS with coalesced loads and all lanes replay the same
- * serial walk on it (uniform control flow, LDS broadcast reads).  Each visited cell emits
- * one op byte; 64 ops are gathered in registers and stored with one coalesced store.
+ * K2.  One wave per fill.  The walk of dynamicprogramming.c:1037-1047 is serial, but on real
+ * sequences it is dominated by long diagonal runs, and a diagonal run is predictable: its
+ * i-th cell is (r-i, k-i).  Every iteration lane i looks up the direction code of that cell
+ * (in a TALL, NARROW LDS window of WT steps x 16 direction-word columns -- in (step, word)
+ * storage coordinates a diagonal is almost vertical) and a ballot finds the first lane whose
+ * cell is not 'D' (or lies outside the window / on a border): all cells before it are
+ * emitted as one coalesced run of 'D' ops; a single 'L' or 'U' op is then taken by lane 0's
+ * code.  Cost is per RUN, not per cell.
  */
-template <int C>
+template <int C, int R>
 __global__ __launch_bounds__(64) void nw_traceback(uint8_t *__restrict__ arena,
                                                    const FillJob *__restrict__ jobs)
 {
-	constexpr int W = C / 16;
-	constexpr int WIN = 64;
-	__shared__ uint32_t win[WIN * W * kLanes];
+	constexpr int W = C / 16;          /* direction words per lane and row                  */
+	constexpr int WQ = 16;             /* word columns per window (16 matrix columns each)   */
+	constexpr int RW = R * WQ;         /* words per window step                              */
+	constexpr int WT = 16384 / RW;     /* steps per window: 64 KiB of direction words        */
+	/* The window is skewed along the main diagonal: d cells down a perfect diagonal the step
+	 * drops by d/R + d/(16W) and the word column by d/16, so window step i starts
+	 * skew(i) = i*R / (16W + R) word columns further left (rounded down to a multiple of 4 to
+	 * keep 16-byte loads aligned).  The current cell enters 8..11 columns from the left
+	 * edge, leaving +-128 matrix columns of slack for indels before a reload. */
+	__shared__ __attribute__((aligned(16))) uint32_t win[WT * RW];
 
 	const FillJob &J = jobs[blockIdx.x];
 	uint8_t *ops = arena + J.ops;
 	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
+	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
 	const int lane = threadIdx.x;
+	const size_t strip_words = (size_t)J.steps_pad * (R * W * kLanes);
+	const int qmax = J.nstrips * kLanes * W;               /* allocated word columns */
 	int r = J.nrows, k = J.ncols;
 	int n = 0;
-	uint32_t myop = 0;
 
 	while (r > 0 && k > 0) {
-		const int Lg = (k - 1) / C;
-		const int s = Lg >> 6;
-		const int Ttop = r - 1 + Lg;                           /* newest step in the window */
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.dirs) + (size_t)s * J.steps_pad * (W * kLanes) + lane;
-		for (int j = 0; j < WIN; ++j) {
-			const int T = Ttop - j;
+		const int q0 = (k - 1) >> 4;                       /* word column of the current cell */
+		const int Ttop = (r - 1) / R + q0 / W;             /* its step                         */
+		const int qbase = (q0 & ~3) - 8;
+		if constexpr (W == 1) {
+			/* 16-byte loads: unit u = (step i, row, group of 4 word columns) */
+			constexpr int UNITS = WT * RW / 4;
+			constexpr int BATCH = 16;
+			for (int b0 = 0; b0 < UNITS / kLanes; b0 += BATCH) {
+				uint4 v[BATCH];
 #pragma unroll
-			for (int w = 0; w < W; ++w)
-				win[(j * W + w) * kLanes + lane] = (T >= 0) ? src[((size_t)T * W + w) * kLanes] : 0u;
+				for (int b = 0; b < BATCH; ++b) {
+					const int u = (b0 + b) * kLanes + lane;
+					const int i = u / (4 * R);
+					const int row = (u / 4) % R;
+					const int T = Ttop - i;
+					const int q = qbase - (((i * R) / (16 * W + R)) & ~3) + 4 * (u % 4);
+					v[b] = make_uint4(0, 0, 0, 0);
+					if (T >= 0 && q >= 0 && q < qmax)
+						v[b] = *reinterpret_cast<const uint4 *>(dirs + (size_t)(q >> 6) * strip_words +
+						                                        ((size_t)T * R + row) * kLanes + (q & 63));
+				}
+#pragma unroll
+				for (int b = 0; b < BATCH; ++b)
+					reinterpret_cast<uint4 *>(win)[(b0 + b) * kLanes + lane] = v[b];
+			}
+		} else {
+			for (int it = 0; it < WT * RW / kLanes; ++it) {
+				const int e = it * kLanes + lane;
+				const int i = e / RW;
+				const int T = Ttop - i;
+				const int row = (e / WQ) % R;
+				const int q = qbase - (((i * R) / (16 * W + R)) & ~3) + e % WQ;
+				uint32_t v = 0;
+				if (T >= 0 && q >= 0 && q < qmax) {
+					const int Lg = q / W;
+					v = dirs[(size_t)(Lg >> 6) * strip_words + (((size_t)T * R + row) * W + (q - Lg * W)) * kLanes + (Lg & 63)];
+				}
+				win[e] = v;
+			}
 		}
 		__syncthreads();
-		while (r > 0 && k > 0) {
-			const int kc = k - 1;
-			const int Lc = kc / C;
-			const int nc = kc - Lc * C;
-			if ((Lc >> 6) != s) break;
-			const int j = Ttop - (r - 1 + Lc);
-			if (j >= WIN) break;
-			const uint32_t word = win[(j * W + (nc >> 4)) * kLanes + (Lc & 63)];
-			const uint32_t code = (word >> (2 * (nc & 15))) & 3u;
-			if (lane == (n & 63)) myop = code;
+		for (;;) {
+			/* lane i inspects the i-th cell of the diagonal through (r, k) */
+			const int ri = r - lane, ki = k - lane;
+			uint32_t code = 3;                             /* 3 = stop: border or outside window */
+			if (ri > 0 && ki > 0) {
+				const int kc = ki - 1;
+				const int q = kc >> 4;
+				const int i = Ttop - ((ri - 1) / R + q / W);
+				if (i >= 0 && i < WT) {
+					const int j = q - (qbase - (((i * R) / (16 * W + R)) & ~3));
+					if (j >= 0 && j < WQ) {
+						const uint32_t word = win[(i * R + (ri - 1) % R) * WQ + j];
+						code = (word >> (2 * (kc & 15))) & 3u;
+					}
+				}
+			}
+			const unsigned long long stop = __ballot(code != DIR_D);
+			const int run = stop ? __builtin_ctzll(stop) : kLanes;
+			if (run > 0) {
+				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+				n += run;
+				r -= run;
+				k -= run;
+				continue;
+			}
+			const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
+			if (c0 == 3) break;                            /* border reached or window exhausted */
+			if (lane == 0) ops[n] = (uint8_t)c0;
 			++n;
-			if ((n & 63) == 0) ops[n - 64 + lane] = (uint8_t)myop;
-			if (code == DIR_D) { --r; --k; }
-			else if (code == DIR_L) { --k; }
-			else { --r; }
+			if (c0 == DIR_L) --k; else --r;
 		}
 		__syncthreads();
 	}
-	if (lane < (n & 63)) ops[(n & ~63) + lane] = (uint8_t)myop;
 	if (lane == 0) {
-		/* cost of the final cell -> H[nrows][ncols] (csadp_device.h) */
-		const int nf = (J.ncols - 1) % C;
-		const int i8 = J.upc - 2;                                /* 8*i */
-		const int cost = (J.ncols > 0 && J.nrows > 0) ? reinterpret_cast<const int32_t *>(arena + J.final_row)[nf] : 0;
 		summary[0] = n;
 		summary[1] = r;
 		summary[2] = k;
-		summary[3] = ((i8 >> 1) * J.nrows - cost) / 4;
+		summary[3] = 0;
 	}
 }
 
 /* ---- launch wrappers (host) ----------------------------------------------------------- */
 
-template <int C, int TR>
+template <int C, int R, int TR>
 static hipError_t launch_fill_t(uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
 {
-	hipLaunchKernelGGL((nw_fill_tiles<C, TR>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	hipLaunchKernelGGL((nw_fill_tiles<C, R, TR>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
 	return hipGetLastError();
 }
 
-hipError_t launch_fill(int C, int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles,
-                       hipStream_t st)
+template <int C, int R>
+static hipError_t launch_fill_r(int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
 {
-	if (ntiles <= 0) return hipSuccess;
-	if (C == 16 && TR == 64) return launch_fill_t<16, 64>(arena, jobs, tiles, ntiles, st);
-	if (C == 16 && TR == 128) return launch_fill_t<16, 128>(arena, jobs, tiles, ntiles, st);
-	if (C == 16 && TR == 256) return launch_fill_t<16, 256>(arena, jobs, tiles, ntiles, st);
-	if (C == 32 && TR == 64) return launch_fill_t<32, 64>(arena, jobs, tiles, ntiles, st);
-	if (C == 32 && TR == 128) return launch_fill_t<32, 128>(arena, jobs, tiles, ntiles, st);
-	if (C == 32 && TR == 256) return launch_fill_t<32, 256>(arena, jobs, tiles, ntiles, st);
+	if (TR == 64) return launch_fill_t<C, R, 64>(arena, jobs, tiles, ntiles, st);
+	if (TR == 128) return launch_fill_t<C, R, 128>(arena, jobs, tiles, ntiles, st);
+	if (TR == 256) return launch_fill_t<C, R, 256>(arena, jobs, tiles, ntiles, st);
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_traceback(int C, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st)
+hipError_t launch_fill(int C, int R, int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles,
+                       hipStream_t st)
+{
+	if (ntiles <= 0) return hipSuccess;
+	if (C == 16 && R == 1) return launch_fill_r<16, 1>(TR, arena, jobs, tiles, ntiles, st);
+	if (C == 16 && R == 2) return launch_fill_r<16, 2>(TR, arena, jobs, tiles, ntiles, st);
+	if (C == 16 && R == 4) return launch_fill_r<16, 4>(TR, arena, jobs, tiles, ntiles, st);
+	if (C == 32 && R == 1) return launch_fill_r<32, 1>(TR, arena, jobs, tiles, ntiles, st);
+	if (C == 32 && R == 2) return launch_fill_r<32, 2>(TR, arena, jobs, tiles, ntiles, st);
+	return hipErrorInvalidValue;
+}
+
+template <int C, int R>
+static hipError_t launch_tb_t(uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st)
+{
+	hipLaunchKernelGGL((nw_traceback<C, R>), dim3(njobs), dim3(kLanes), 0, st, arena, jobs);
+	return hipGetLastError();
+}
+
+hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	if (C == 16) hipLaunchKernelGGL((nw_traceback<16>), dim3(njobs), dim3(kLanes), 0, st, arena, jobs);
-	else if (C == 32) hipLaunchKernelGGL((nw_traceback<32>), dim3(njobs), dim3(kLanes), 0, st, arena, jobs);
-	else return hipErrorInvalidValue;
-	return hipGetLastError();
+	if (C == 16 && R == 1) return launch_tb_t<16, 1>(arena, jobs, njobs, st);
+	if (C == 16 && R == 2) return launch_tb_t<16, 2>(arena, jobs, njobs, st);
+	if (C == 16 && R == 4) return launch_tb_t<16, 4>(arena, jobs, njobs, st);
+	if (C == 32 && R == 1) return launch_tb_t<32, 1>(arena, jobs, njobs, st);
+	if (C == 32 && R == 2) return launch_tb_t<32, 2>(arena, jobs, njobs, st);
+	return hipErrorInvalidValue;
 }
 
 }  // namespace csadp

@@ -165,7 +165,7 @@ void Progressive::debug_rowcodes(signed char *out) const
 }
 
 /* Traceback application, :1033-1155, driven by the op list instead of dpdirs. */
-int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, int score)
+int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score)
 {
 	if (!pending_) return CSADP_ERR_STATE;
 	const int i = step_;
@@ -211,20 +211,27 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, i
 			(*svp)[(size_t)(mm + 1) * kSym + kGap]++;
 		}
 	};
+	long long score = 0;                                    /* sum of move scores, :993-998 */
 	for (int t = 0; t < nops; ++t, --m) {                   /* :1072-1114 */
 		const int op = ops[t];
 		if (op == DIR_D) {
-			if (!inplace) copy_column(k, m);
 			const char ch = char_at(pos, n);
+			const int c = code_of(ch);
+			const int *col = &sv_[(size_t)k * kSym];
+			score += kMatch * col[c] + kIndel * col[kGap] + kMismatch * (i - (col[c] + col[kGap]));
+			if (!inplace) copy_column(k, m);
 			cur[m] = ch;
-			(*svp)[(size_t)(m + 1) * kSym + code_of(ch)]++;
+			(*svp)[(size_t)(m + 1) * kSym + c]++;
 			--pos; --j; --k;
 		} else if (op == DIR_L) {
+			const int g = sv_[(size_t)k * kSym + kGap];
+			score += kDoubleGap * g + kIndel * (i - g);
 			if (!inplace) copy_column(k, m);
 			cur[m] = '-';
 			(*svp)[(size_t)(m + 1) * kSym + kGap]++;
 			--k;
 		} else {
+			score += kIndel * i;
 			if (!inplace) new_column(m);
 			const char ch = char_at(pos, n);
 			cur[m] = ch;
@@ -232,6 +239,9 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, i
 			--pos; --j;
 		}
 	}
+	/* the walk stopped on a border cell: H[j][0] = -border_i*j (:967) or H[0][k] (:972) */
+	score += (j > 0) ? -(long long)border_i_ * j : (long long)border_top_[(size_t)k];
+	if (expect_score && *expect_score != (int)score) return CSADP_ERR_HIP;
 	for (; j > 0; --j, --m) {                               /* :1115-1127 */
 		new_column(m);
 		const char ch = char_at(pos, n);
@@ -252,7 +262,7 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, i
 	have_[n] = 1;
 	prevconsensus_ = ncols;                                 /* :1033 */
 	consensus_ = newcons;
-	last_score_ = score;
+	last_score_ = (int)score;
 	cells_ += (long long)nrows * (long long)ncols;
 	++fills_;
 	if (i > 1) delete_gapped_columns(i + 1, (i + 1) / 2);   /* :1157 */

@@ -40,8 +40,10 @@ public:
 	void write_tables(uint32_t *coltab, int ncols_pad, uint8_t *rowshift, int32_t *top) const;
 
 	/* Apply the GPU traceback of the pending fill: ops in walk order (DIR_* codes, from cell
-	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border. */
-	int apply_trace(const uint8_t *ops, int nops, int remj, int remk, int score);
+	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border.
+	 * The DP score H[nrows][ncols] is re-derived on the way as border value + sum of the move
+	 * scores along the path; if expect_score is given it must agree (test seam). */
+	int apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score = nullptr);
 
 	/* Publish the result (malloc'd strings, original index order). */
 	int finish(csadp_result *res);

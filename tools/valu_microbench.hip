@@ -1,0 +1,112 @@
+// VALU issue-rate microbenchmark for gfx950: cycles per wave64 instruction per SIMD for the
+// integer ops the DP fill kernel is made of, at 1/2/4/8 waves per SIMD, independent (8
+// accumulators) and dependent (1 accumulator) chains.  Build: hipcc --offload-arch=gfx950
+// -O3 tools/valu_microbench.hip -o build/valu_microbench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+constexpr int ITERS = 4096;
+constexpr int UNROLL = 8;
+
+#define DEF_KERNEL(NAME, ASM_INDEP, ASM_DEP)                                                          \
+__global__ void k_##NAME(int *out, int seed, int dep) {                                               \
+	extern __shared__ int pad[];                                                                       \
+	int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13,   \
+	    a6 = a0 * 17, a7 = a0 * 19;                                                                    \
+	int b = seed * 31 + 6, c = seed | 3;                                                               \
+	if (dep) {                                                                                         \
+		for (int i = 0; i < ITERS; ++i) {                                                              \
+			_Pragma("unroll") for (int u = 0; u < UNROLL; ++u) { asm volatile(ASM_DEP : "+v"(a0) : "v"(b), "v"(c)); } \
+		}                                                                                              \
+	} else {                                                                                           \
+		for (int i = 0; i < ITERS; ++i) {                                                              \
+			asm volatile(ASM_INDEP : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c)); \
+		}                                                                                              \
+	}                                                                                                  \
+	if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 == 0x7fffffff) out[0] = pad[0];                          \
+}
+
+#define OP8(fmt) fmt("%0") "\n" fmt("%1") "\n" fmt("%2") "\n" fmt("%3") "\n" fmt("%4") "\n" fmt("%5") "\n" fmt("%6") "\n" fmt("%7")
+
+#define F_ADD(r) "v_add_u32 " r ", %8, " r
+#define F_AND(r) "v_and_b32 " r ", %8, " r
+#define F_MIN3(r) "v_min3_i32 " r ", " r ", %8, %9"
+#define F_BFE(r) "v_bfe_u32 " r ", " r ", %8, 6"
+#define F_LSHLADD(r) "v_lshl_add_u32 " r ", " r ", 3, %8"
+#define F_ALIGN(r) "v_alignbit_b32 " r ", " r ", %8, 2"
+#define F_FMA(r) "v_fma_f32 " r ", " r ", %8, %9"
+#define F_PKADD(r) "v_pk_add_i16 " r ", " r ", %8"
+#define F_PKMIN(r) "v_pk_min_i16 " r ", " r ", %8"
+#define F_PKFMA(r) "v_pk_add_u16 " r ", " r ", %8"
+#define F_DPP(r) "v_mov_b32_dpp " r ", " r " wave_shr:1 row_mask:0xf bank_mask:0xf"
+#define F_MIN(r) "v_min_i32 " r ", %8, " r
+#define F_ADD3(r) "v_add3_u32 " r ", " r ", %8, %9"
+#define F_MAX3(r) "v_max3_i32 " r ", " r ", %8, %9"
+#define F_SUBB(r) "v_sub_u32 " r ", " r ", %8"
+
+DEF_KERNEL(add, OP8(F_ADD), "v_add_u32 %0, %1, %0")
+DEF_KERNEL(and, OP8(F_AND), "v_and_b32 %0, %1, %0")
+DEF_KERNEL(min3, OP8(F_MIN3), "v_min3_i32 %0, %0, %1, %2")
+DEF_KERNEL(bfe, OP8(F_BFE), "v_bfe_u32 %0, %0, %1, 6")
+DEF_KERNEL(lshladd, OP8(F_LSHLADD), "v_lshl_add_u32 %0, %0, 3, %1")
+DEF_KERNEL(alignbit, OP8(F_ALIGN), "v_alignbit_b32 %0, %0, %1, 2")
+DEF_KERNEL(fma, OP8(F_FMA), "v_fma_f32 %0, %0, %1, %2")
+DEF_KERNEL(pkadd16, OP8(F_PKADD), "v_pk_add_i16 %0, %0, %1")
+DEF_KERNEL(pkmin16, OP8(F_PKMIN), "v_pk_min_i16 %0, %0, %1")
+DEF_KERNEL(min, OP8(F_MIN), "v_min_i32 %0, %1, %0")
+DEF_KERNEL(add3, OP8(F_ADD3), "v_add3_u32 %0, %0, %1, %2")
+DEF_KERNEL(dpp, OP8(F_DPP), "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
+
+typedef void (*kern_t)(int *, int, int);
+
+static void run(const char *name, kern_t k, int ncu, double ghz_hint)
+{
+	int *out;
+	CHECK(hipMalloc(&out, 64));
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0));
+	CHECK(hipEventCreate(&e1));
+	for (int dep = 0; dep <= 1; ++dep) {
+		printf("%-9s %s:", name, dep ? "dep  " : "indep");
+		for (int wps = 1; wps <= 8; wps *= 2) {
+			const int threads = 64 * 4 * wps;                  // wps waves on each of the 4 SIMDs
+			if (threads > 1024) {                              // 2 blocks of 1024 per CU
+				// 8 waves/SIMD: two 1024-thread blocks per CU, 32 KB LDS each
+			}
+			const int blocks = (threads > 1024) ? ncu * 2 : ncu;
+			const int tpb = (threads > 1024) ? 1024 : threads;
+			const size_t lds = (threads > 1024) ? 70 * 1024 : 100 * 1024;   // pins blocks per CU
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(tpb), lds, 0, out, 1, dep);   // warm-up
+			CHECK(hipDeviceSynchronize());
+			CHECK(hipEventRecord(e0));
+			hipLaunchKernelGGL(k, dim3(blocks), dim3(tpb), lds, 0, out, 1, dep);
+			CHECK(hipEventRecord(e1));
+			CHECK(hipEventSynchronize(e1));
+			float ms;
+			CHECK(hipEventElapsedTime(&ms, e0, e1));
+			const double instr_per_simd = (double)ITERS * UNROLL * wps;    // wave-instructions per SIMD
+			const double ns_per = ms * 1e6 / instr_per_simd;
+			printf("  w%d %.3f ns (%.2f cyc@%.1fGHz)", wps, ns_per, ns_per * ghz_hint, ghz_hint);
+		}
+		printf("\n");
+	}
+	CHECK(hipFree(out));
+}
+
+int main()
+{
+	hipDeviceProp_t p;
+	CHECK(hipGetDeviceProperties(&p, 0));
+	const int ncu = p.multiProcessorCount;
+	const double ghz = p.clockRate / 1e6;
+	printf("device %s CUs %d clock %.2f GHz; numbers = time per wave64 instruction per SIMD\n", p.gcnArchName, ncu, ghz);
+	CHECK(hipFuncSetAttribute((const void *)k_add, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+#define RUN(n) CHECK(hipFuncSetAttribute((const void *)k_##n, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); run(#n, k_##n, ncu, ghz)
+	RUN(fma); RUN(add); RUN(and); RUN(min); RUN(min3); RUN(add3); RUN(bfe); RUN(lshladd); RUN(alignbit);
+	RUN(pkadd16); RUN(pkmin16); RUN(dpp);
+	return 0;
+}
