@@ -24,8 +24,25 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-VALU_PEAK_LANEOPS = 256 * 4 * 32 * 2.4e9   # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 lane-ops/s
-VALU_OPS_PER_CELL = 7                 # csadp_kernels.hip: bfe, lshl_add, add, add, min3, alignbit, and
+# VALU issue roofline of the fill kernel.  Per cell the kernel issues 7 VALU instructions
+# (csadp_kernels.hip): v_add_u32 x2 and v_and_b32 are full rate (2 issue cycles per wave64
+# instruction on a SIMD), v_bfe_u32, v_lshl_add_u32, v_min3_i32 and v_alignbit_b32 are half
+# rate (4 cycles) on gfx950 -- measured by tools/valu_microbench.hip,
+# profiles/r01_valu_microbench.txt.  3*2 + 4*4 = 22 issue cycles per 64 cells per SIMD.
+VALU_OPS_PER_CELL = 7
+VALU_ISSUE_CYCLES_PER_CELL_WAVE = 22
+VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9     # 7.15e12 cells/s
+
+
+def pmc_traffic_per_launch():
+    """HBM bytes per fill launch from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE /
+    FETCH_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            k = json.load(f)["nw_fill_tiles"]
+        return int(k["hbm_write_bytes_per_launch"] + k["hbm_read_bytes_per_launch_x2_corrected"])
+    except Exception:
+        return None
 
 
 def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
@@ -88,20 +105,24 @@ def main():
 
     # weak scaling: rank r owns global pairs [r*P, (r+1)*P) of the synthetic batch
     tasks = config4_tasks(rank * args.pairs, args.pairs, args.length)
+    t_c0 = time.perf_counter()
     batch = csa_amd.PairBatch(tasks)            # validate, pack, upload: inputs now resident in HBM
+    create_s = time.perf_counter() - t_c0
 
     def sync():
         batch.sync()
         torch.cuda.synchronize()
 
     elapsed = cdist.timed_steps(group, batch.run, sync, args.steps, args.warmup)
-    # kernel-level figures for the roofline: ONE more pass run alone (no overlap with a
-    # neighbouring pass), timed with HIP events on the stream it is launched on
+    tm_pipe = batch.timing()                     # HIP events of the LAST timed pass, on its own stream
+    # the same pass once more, alone (no neighbouring pass in flight)
     batch.run()
     sync()
     tm = batch.timing()
     cells_step = group.sum(tm["cells"])
-    results = batch.fetch()
+    t_f0 = time.perf_counter()
+    results = batch.fetch()                      # ops D2H + aligned strings built on the host
+    fetch_s = time.perf_counter() - t_f0
     ok = all(r["status"] == 0 for r in results)
 
     value = cells_step * args.steps / elapsed / 1e9
@@ -112,11 +133,15 @@ def main():
         for t, r in list(zip(tasks, results))[:4]:
             ok = ok and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
             ok = ok and sp_score(r["aligned"]) == r["score"]
-        fill_s = tm["fill_ms"] / 1e3
-        launch_us = tm["fill_ms"] * 1e3 / max(tm["fill_launches"], 1)
-        alg_bytes = tm["dir_bytes"] + tm["border_bytes"]       # 0.25 B/cell directions + tile borders
-        achieved = alg_bytes / fill_s / 1e9
-        cups_fill = tm["cells"] / fill_s
+        launches = max(tm["fill_launches"], 1)
+        alg_bytes = tm["dir_bytes"] + tm["border_bytes"]       # 0.25 B/cell directions + tile borders, per pass
+        # the fill kernel is in flight during the whole timed region (passes overlap on
+        # `slots` streams, the traceback of a pass hides under the next pass' fill), so its
+        # sustained rate is: work of all timed passes / wall time of the timed region
+        rank_cells = tm["cells"]
+        eff_bytes_s = alg_bytes * args.steps / elapsed
+        eff_cups = rank_cells * args.steps / elapsed
+        slots = int(os.environ.get("CSADP_SLOTS", "2"))
         line = {
             "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, fill + traceback, whole job",
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
@@ -131,23 +156,34 @@ def main():
                        "cols_per_lane": int(os.environ.get("CSADP_COLS_PER_LANE", "16")),
                        "rows_per_step": int(os.environ.get("CSADP_ROWS_PER_STEP", "2")),
                        "tile_steps": int(os.environ.get("CSADP_TILE_ROWS", "128")),
-                       "pipelined_passes": int(os.environ.get("CSADP_SLOTS", "2")),
+                       "pipelined_passes": slots,
                        "parallelism": "tasks sharded over %d GPU(s), no collective" % args.gpus},
-            "kernel_ms": {"note": "one pass run alone after the timed region",
-                          "fill": round(tm["fill_ms"], 3), "traceback": round(tm["traceback_ms"], 3),
+            "kernel_ms": {"fill_pipelined": round(tm_pipe["fill_ms"], 3),
+                          "traceback_pipelined": round(tm_pipe["traceback_ms"], 3),
+                          "fill_alone": round(tm["fill_ms"], 3), "traceback_alone": round(tm["traceback_ms"], 3),
                           "fill_launches": tm["fill_launches"], "fill_tiles": tm["fill_tiles"],
-                          "fill_gcups": round(cups_fill / 1e9, 2)},
-            "roofline": {"bound": "hbm", "kernel": "nw_fill_tiles", "achieved": round(achieved, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": None,
-                         "bytes_per_launch": round(alg_bytes / max(tm["fill_launches"], 1)),
-                         "avg_launch_us": round(launch_us, 2),
-                         "note": "algorithmic bytes = 0.25 B/cell directions + tile borders (SURVEY 8d); "
-                                 "the binding roofline is integer VALU issue, see roofline_valu"},
-            "roofline_valu": {"bound": "valu", "ops_per_cell": VALU_OPS_PER_CELL,
-                              "achieved": round(cups_fill * VALU_OPS_PER_CELL / 1e12, 3),
-                              "peak": round(VALU_PEAK_LANEOPS / 1e12, 2), "unit": "Tlane-op/s",
-                              "frac": round(cups_fill * VALU_OPS_PER_CELL / VALU_PEAK_LANEOPS, 4)},
+                          "fill_alone_gcups": round(tm["cells"] / tm["fill_ms"] / 1e6, 2)},
+            "host_boundary_ms": {"create_pack_upload": round(create_s * 1e3, 2), "fetch_download_strings": round(fetch_s * 1e3, 2),
+                                 "pcie_inclusive_gcups": round(rank_cells / (create_s + fetch_s + tm["total_ms"] / 1e3) / 1e9, 1),
+                                 "note": "not part of value: one batch from host buffers to host strings, unpipelined"},
+            "roofline": {"bound": "hbm", "kernel": "nw_fill_tiles",
+                         "achieved": round(eff_bytes_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(eff_bytes_s / 1e9 / HBM_PEAK_GBS, 6),
+                         "traffic": pmc_traffic_per_launch(),
+                         "bytes_per_launch": round(alg_bytes / launches),
+                         "avg_launch_us": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
+                         "avg_launch_us_alone": round(tm["fill_ms"] * 1e3 / launches, 2),
+                         "concurrent_streams": slots,
+                         "note": "algorithmic bytes = 0.25 B/cell directions + tile borders (SURVEY 8d). achieved = "
+                                 "algorithmic bytes of all timed passes / timed wall time (launches of consecutive "
+                                 "passes overlap on separate streams, so bytes_per_launch / avg_launch_us understates "
+                                 "it by the overlap). The binding roofline is integer VALU issue: roofline_valu"},
+            "roofline_valu": {"bound": "valu-issue", "ops_per_cell": VALU_OPS_PER_CELL,
+                              "issue_cycles_per_64_cells": VALU_ISSUE_CYCLES_PER_CELL_WAVE,
+                              "achieved": round(eff_cups / 1e9, 1), "peak": round(VALU_PEAK_CUPS / 1e9, 1),
+                              "unit": "GCUPS", "frac": round(eff_cups / VALU_PEAK_CUPS, 4),
+                              "note": "peak = 1024 SIMDs x 64 cells / 22 issue cycles x 2.4 GHz; per-op issue "
+                                      "rates measured on this chip (profiles/r01_valu_microbench.txt)"},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)

@@ -1,0 +1,124 @@
+"""CPU tests of the PRODUCT's host side: C-ABI surface, error behaviour without a device,
+the progressive host logic (through the csadp_debug seam, with an oracle-backed matrix
+filler supplied by the test), partitioning, FASTA loader, workload generator."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+import csa_amd
+from csa_amd.synth import config5_lengths, synth_pair
+from helpers import (GOLDEN, ROOT, golden_aligned, golden_task, load_golden, oracle_filler, oracle_progressive,
+                     random_family, read_fasta, rng, rotated, degap)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = csa_amd.lib()
+    for name in csa_amd.EXPORTS:
+        assert hasattr(lib, name), name
+    # every function declared in the public headers is in EXPORTS
+    import re
+    declared = set()
+    for hdr in ("csadp.h", "csadp_debug.h"):
+        text = open(os.path.join(ROOT, "include", hdr)).read()
+        declared |= set(re.findall(r"\b(csadp_[a-z_0-9]+)\s*\(", text))
+    declared -= {"csadp_debug_fill_fn"}
+    assert declared == set(csa_amd.EXPORTS)
+    assert lib.csadp_version() == 100
+
+
+def test_dropin_object_defines_progressivedp():
+    obj = os.path.join(ROOT, "csa_amd", "csadp_dropin.o")
+    assert os.path.exists(obj)
+    syms = subprocess.check_output(["nm", obj]).decode()
+    assert " T ProgressiveDP" in syms
+    for undefined in ("numberofseqs", "texts", "textsizes", "rotations", "csadp_align_batch"):
+        assert (" U %s" % undefined) in syms
+
+
+def test_no_cpu_fallback_without_device():
+    """On a machine without a GPU every compute entry point must fail loudly."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(csa_amd.CsadpError) as e:
+        csa_amd.init()
+    assert e.value.code == csa_amd.ERR_NO_DEVICE
+    with pytest.raises(csa_amd.CsadpError):
+        csa_amd.align_batch([([b"ACGT", b"ACGT"], None, None, None)])
+    with pytest.raises(csa_amd.CsadpError):
+        csa_amd.PairBatch([([b"ACGT", b"ACGT"], None, None, None)])
+
+
+@pytest.mark.parametrize("name", ["tiny_pairs.json", "tiny_families.json"])
+def test_host_logic_matches_golden(name):
+    """Ordering, seeding, stale-border rule, traceback application, DeleteGappedColumns and the
+    path-derived DP score of the product's host code, fills supplied by the oracle."""
+    fill = oracle_filler()
+    for c in load_golden(name):
+        got = csa_amd.debug_align_with_filler(golden_task(c), fill)
+        exp = golden_aligned(c)
+        assert got["status"] == 0
+        assert got["consensus"] == c["consensus"]
+        assert got["aligned"] == (exp if exp[0] is not None else None)
+
+
+def test_host_logic_medium_families_vs_oracle():
+    fill = oracle_filler()
+    r = rng(123)
+    for n, length in [(4, 120), (7, 90), (12, 60), (3, 200)]:
+        fam = random_family(r, n, length, mut=0.12, indel=0.08)
+        rots = [r.randrange(len(f)) for f in fam]
+        got = csa_amd.debug_align_with_filler((fam, rots, None, None), fill)
+        cons, strs, st = oracle_progressive(fam, rots)
+        assert got["aligned"] == strs and got["consensus"] == cons
+        assert got["score"] == st.last_score and got["cells"] == st.cells and got["fills"] == st.fills
+
+
+def test_host_logic_rejects_bad_input():
+    fill = oracle_filler()
+    assert csa_amd.debug_align_with_filler(([b"ACGT", b"ACXT"], None, None, None), fill)["status"] == csa_amd.ERR_ALPHABET
+    assert csa_amd.debug_align_with_filler(([b"ACGT"], None, None, None), fill)["status"] == csa_amd.ERR_ARG
+    assert csa_amd.debug_align_with_filler(([b"ACGT", b"ACGT"], [0, 9], None, None), fill)["status"] == csa_amd.ERR_ARG
+    # IUPAC letter outside the aligned region is fine (the reference never reads it)
+    ok = csa_amd.debug_align_with_filler(([b"ACGTN", b"ACGT"], [0, 0], [0, 0], [4, 4]), fill)
+    assert ok["status"] == 0 and ok["aligned"] == [b"ACGT", b"ACGT"]
+
+
+def test_partition_lpt():
+    costs = [9, 7, 6, 5, 4, 3, 2, 2, 1]
+    assign, maxload = csa_amd.partition_lpt(costs, 3)
+    loads = [sum(c for c, a in zip(costs, assign) if a == p) for p in range(3)]
+    assert max(loads) == maxload == 13 and sum(loads) == sum(costs)
+    assert csa_amd.partition_lpt([], 4) == ([], 0)
+    # config-5 style spread: 256 tasks over 8 GPUs within 5 % of the mean
+    la, lb = config5_lengths(256)
+    costs = [a * b for a, b in zip(la, lb)]
+    assign, maxload = csa_amd.partition_lpt(costs, 8)
+    assert maxload <= 1.05 * sum(costs) / 8
+
+
+def test_fasta_loader_matches_reference_rules(tmp_path):
+    for name in ("Primates", "Mammals"):
+        path = os.path.join(GOLDEN, "data", name + ".txt")
+        got = csa_amd.load_fasta(path)
+        _, seqs = read_fasta(path)
+        assert [t for _, t in got] == seqs
+    p = tmp_path / "odd.fa"
+    p.write_bytes(b"junk\n>one desc\nac gt-\r\nNNry\n>bad\nACG*T\n>empty\n\n>two\nTTTT\n")
+    got = csa_amd.load_fasta(str(p))
+    assert got == [("one desc", b"ACGTNNRY"), ("two", b"TTTT")]
+    p.write_bytes(b">only\nACGT\n")
+    with pytest.raises(csa_amd.CsadpError):
+        csa_amd.load_fasta(str(p))
+
+
+def test_synthetic_pairs_are_deterministic_and_related():
+    a, b, ra, rb = synth_pair(7, length=2000)
+    a2, b2, ra2, rb2 = synth_pair(7, length=2000)
+    assert (a, b, ra, rb) == (a2, b2, ra2, rb2)
+    assert synth_pair(8, length=2000)[0] != a
+    cons, strs, st = oracle_progressive([a, b], [ra, rb])
+    assert degap(strs[0]) == rotated(a, ra) and degap(strs[1]) == rotated(b, rb)
+    assert st.last_score > 0.5 * len(a)          # ~10 % substitutions, 2 % indels

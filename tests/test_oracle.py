@@ -1,0 +1,102 @@
+"""CPU tests of the CHECKER: the oracle (oracle/csa_dp_oracle.c) against the golden vectors
+generated from the compiled reference, against the reference library itself when it is
+present (oracle/_ref, build container / prebuilt on the GPU box), and against the values
+quoted in SURVEY.md 8(c)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, fnv1a, golden_aligned, golden_task, have_ref, load_golden, oracle_lib,
+                     oracle_progressive, random_family, read_fasta, ref_progressive, rng, sp_score)
+
+
+@pytest.mark.parametrize("name", ["tiny_pairs.json", "tiny_families.json"])
+def test_oracle_matches_golden_strings(name):
+    cases = load_golden(name)
+    assert len(cases) >= 160
+    for c in cases:
+        texts, rots, starts, ends = golden_task(c)
+        cons, strs, _ = oracle_progressive(texts, rots, starts, ends)
+        assert cons == c["consensus"]
+        assert strs == golden_aligned(c)
+
+
+def test_oracle_real_pair_survey_values():
+    """Primates seq0 x seq1, rotations 1947/1949: len 16589, SP 15197, FNV-1a 7ee50a99."""
+    _, seqs = read_fasta(os.path.join(GOLDEN, "data", "Primates.txt"))
+    cons, strs, st = oracle_progressive([seqs[0], seqs[1]], [1947, 1949])
+    assert cons == 16589 and st.last_score == 15197 and sp_score(strs) == 15197
+    assert "%08x" % fnv1a(strs) == "7ee50a99"
+    assert st.cells == 16554 * 16563 and st.fills == 1 and st.stale_border_fills == 0
+    gold = [c for c in load_golden("real_pairs.json") if c["set"] == "Primates" and (c["a"], c["b"]) == (0, 1)
+            and c["rots"] == [1947, 1949]][0]
+    assert gold["consensus"] == cons and gold["sp"] == 15197 and gold["fnv1a"] == "7ee50a99"
+
+
+def test_golden_real_pairs_complete():
+    real = load_golden("real_pairs.json")
+    assert sum(1 for c in real if c["set"] == "Primates") == 121      # 120 pairs + (0,1) unrotated
+    assert sum(1 for c in real if c["set"] == "Mammals") == 66
+    cells = sum(c["len_a"] * c["len_b"] for c in real if c["set"] == "Mammals")
+    assert cells == 18593884141
+
+
+def test_oracle_alphabet_and_argument_errors():
+    assert oracle_progressive([b"ACGT", b"ACNT"])[0] == -2
+    assert oracle_progressive([b"ACGT", b"ACGT"], [0, 0], [0, 0], [5, 4])[0] == -1
+    cons, strs, _ = oracle_progressive([b"ACGT", b"ACGT"], [0, 0], [2, 1], [2, 1])
+    assert cons == 0 and strs == [None, None]
+
+
+def test_oracle_stale_border_quirk_is_exercised():
+    """Equal-length regions trigger the un-refreshed borders of dynamicprogramming.c:957."""
+    r = rng(3)
+    stale = 0
+    for _ in range(30):
+        fam = random_family(r, 5, 40, mut=0.2, indel=0.0)
+        _, _, st = oracle_progressive(fam)
+        stale += st.stale_border_fills
+    assert stale > 0
+
+
+def test_odp_fill_direction_priority():
+    """diag >= up && diag >= left -> D; else left >= up -> L; else U (:1014-1025)."""
+    lib = oracle_lib()
+    nrows, ncols = 3, 3
+    sv = (ctypes.c_int * ((ncols + 1) * 5))()
+    for k, ch in enumerate(b"ACG", start=1):
+        sv[k * 5 + b"ACGT".index(ch)] = 1
+    rows = (ctypes.c_byte * nrows)(0, 1, 2)
+    H = (ctypes.c_int * 16)()
+    D = ctypes.create_string_buffer(16)
+    assert lib.odp_fill(nrows, ncols, rows, sv, 1, None, 1, H, D) == 0
+    Hm = np.array(list(H)).reshape(4, 4)
+    assert Hm[3, 3] == 3 and D.raw[5] == ord("D") and D.raw[10] == ord("D") and D.raw[15] == ord("D")
+    assert list(Hm[0]) == [0, -1, -2, -3] and list(Hm[:, 0]) == [0, -1, -2, -3]
+    assert D.raw[6] == ord("L") or D.raw[6] == ord("D")   # (1,2): diag -1-1=-2, left 1-1=0 -> L
+    assert D.raw[6] == ord("L")
+    assert D.raw[9] == ord("U")                            # (2,1): up 1-1=0 beats diag -2 and left -3
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref/libcsa_ref.so not built (needs /root/reference)")
+def test_oracle_vs_compiled_reference_fuzz():
+    r = rng(11)
+    for it in range(400):
+        n = r.choice([2, 2, 3, 4, 5, 6, 8])
+        length = r.choice([0, 1, 2, 3, 5, 8, 13, 21, 40, 64])
+        fam = random_family(r, n, length, mut=r.choice([0.0, 0.1, 0.3, 0.9]), indel=r.choice([0.0, 0.1, 0.3]))
+        fam = [f if f else b"A" for f in fam]
+        rots = [r.randrange(len(f)) for f in fam]
+        starts, ends = [], []
+        for f in fam:
+            a = r.randrange(len(f) + 1)
+            b = r.randrange(a, len(f) + 1)
+            if r.random() < 0.6:
+                a, b = 0, len(f)
+            starts.append(a)
+            ends.append(b)
+        c1, s1, _ = oracle_progressive(fam, rots, starts, ends)
+        c2, s2, _ = ref_progressive(fam, rots, starts, ends)
+        assert c1 == c2 and s1 == s2, (it, fam, rots, starts, ends)
