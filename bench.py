@@ -141,7 +141,7 @@ def main():
         rank_cells = tm["cells"]
         eff_bytes_s = alg_bytes * args.steps / elapsed
         eff_cups = rank_cells * args.steps / elapsed
-        slots = int(os.environ.get("CSADP_SLOTS", "2"))
+        slots = int(os.environ.get("CSADP_SLOTS", "4"))
         line = {
             "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, fill + traceback, whole job",
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
@@ -155,7 +155,7 @@ def main():
                        "pairs_per_gpu": args.pairs, "seq_len": args.length,
                        "cols_per_lane": int(os.environ.get("CSADP_COLS_PER_LANE", "16")),
                        "rows_per_step": int(os.environ.get("CSADP_ROWS_PER_STEP", "2")),
-                       "tile_steps": int(os.environ.get("CSADP_TILE_ROWS", "128")),
+                       "tile_steps": int(os.environ.get("CSADP_TILE_ROWS", "64")),
                        "pipelined_passes": slots,
                        "parallelism": "tasks sharded over %d GPU(s), no collective" % args.gpus},
             "kernel_ms": {"fill_pipelined": round(tm_pipe["fill_ms"], 3),

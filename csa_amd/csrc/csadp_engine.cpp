@@ -64,12 +64,12 @@ int Engine::init(const csadp_config *cfg)
 	device_ = dev;
 	snprintf(name_, sizeof(name_), "%s (%s)", prop.name, prop.gcnArchName);
 	cus_ = prop.multiProcessorCount;
-	slots_ = env_int("CSADP_SLOTS", 2);
+	slots_ = env_int("CSADP_SLOTS", 4);
 	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
 	for (int i = 0; i < slots_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
 	C_ = env_int("CSADP_COLS_PER_LANE", 16);
 	R_ = env_int("CSADP_ROWS_PER_STEP", 2);
-	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 128);
+	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 64);
 	if (C_ != 16 && C_ != 32) return CSADP_ERR_ARG;
 	if (R_ != 1 && R_ != 2 && R_ != 4) return CSADP_ERR_ARG;
 	if (C_ == 32 && R_ == 4) return CSADP_ERR_ARG;

@@ -21,7 +21,7 @@ public:
 	int init(const csadp_config *cfg);
 	void shutdown();
 	bool ready() const { return ready_; }
-	static constexpr int kMaxSlots = 4;
+	static constexpr int kMaxSlots = 8;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
 	int slots() const { return slots_; }
 	int C() const { return C_; }
@@ -40,7 +40,7 @@ private:
 	int cus_ = 0;
 	char name_[256] = {0};
 	int slots_ = 2;
-	hipStream_t streams_[kMaxSlots] = {nullptr, nullptr, nullptr, nullptr};
+	hipStream_t streams_[kMaxSlots] = {};
 };
 
 /*
@@ -91,7 +91,7 @@ private:
 	std::vector<TileRef> tiles_;
 	std::vector<size_t> diag_off_;   /* tiles_ index of the first tile of each diagonal, +1 sentinel */
 	size_t in_bytes_ = 0, res_bytes_ = 0, total_bytes_ = 0;
-	size_t jobs_off_[Engine::kMaxSlots] = {0, 0, 0, 0}, res_off_[Engine::kMaxSlots] = {0, 0, 0, 0};
+	size_t jobs_off_[Engine::kMaxSlots] = {}, res_off_[Engine::kMaxSlots] = {};
 	size_t tiles_off_ = 0;
 	int nslots_ = 1, next_slot_ = 0, last_slot_ = 0;
 	uint8_t *arena_ = nullptr;

@@ -67,6 +67,12 @@ __device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32
 	for (int t = 0; t < TR; ++t) {
 		int32_t inl[R];
 		uint32_t sh[R];
+		/* right edge of the strip after the PREVIOUS step: written first so that the wait for
+		 * this step's LDS reads (issued next, consumed a whole step later) also covers it */
+		if (t > 0 && lane == kLanes - 1) {
+#pragma unroll
+			for (int q = 0; q < R; ++q) edge[(t - 1) * R + q] = last[q];
+		}
 #pragma unroll
 		for (int q = 0; q < R; ++q) {
 			sh[q] = snext[q];
@@ -116,10 +122,10 @@ __device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32
 		for (int q = 0; q < R; ++q)
 #pragma unroll
 			for (int w = 0; w < W; ++w) dirs[((size_t)t * R + q) * (W * kLanes) + w * kLanes] = acc[q][w];
-		if (lane == kLanes - 1) {                              /* right edge of the strip */
+	}
+	if (lane == kLanes - 1) {
 #pragma unroll
-			for (int q = 0; q < R; ++q) edge[t * R + q] = last[q];
-		}
+		for (int q = 0; q < R; ++q) edge[(TR - 1) * R + q] = last[q];
 	}
 }
 

@@ -10,6 +10,8 @@ Outputs (all data, no reference source text):
   tiny_families.json   N=3..8 progressive cases (DeleteGappedColumns, Q1), full strings
   real_pairs.json      whole-sequence pairs of Primates/Mammals: length, SP score,
                        FNV-1a digest (the values quoted in SURVEY.md 8c included)
+  pipeline.json        (--pipeline) md5 of <set>-Aligned.fasta / -Rotated.fasta written by the
+                       unmodified reference program in mode N (oracle/_ref/CSA_ref)
 
 usage: python tests/golden/make_golden.py [--all-pairs]
 """
@@ -115,6 +117,31 @@ def real_pairs(all_pairs):
     return out
 
 
+def pipeline():
+    """Whole-program goldens: run the UNMODIFIED reference binary (oracle/_ref/CSA_ref, built by
+    `make -C oracle _dropin`) in mode N on the example sets and record the md5 of its outputs."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    ref = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "CSA_ref")
+    out = {}
+    for name in ("Primates", "Mammals"):
+        with tempfile.TemporaryDirectory() as tmp:
+            shutil.copy(os.path.join(HERE, "data", name + ".txt"), tmp)
+            with open(os.devnull) as devnull:
+                log = subprocess.run([ref, name + ".txt"], cwd=tmp, stdin=devnull, stdout=subprocess.PIPE,
+                                     stderr=subprocess.STDOUT).stdout.decode(errors="replace")
+            rec = {}
+            for kind in ("Aligned", "Rotated"):
+                with open(os.path.join(tmp, "%s-%s.fasta" % (name, kind)), "rb") as f:
+                    rec[kind.lower() + "_md5"] = hashlib.md5(f.read()).hexdigest()
+            rec["dp_calls"] = log.count("[(")
+            out[name] = rec
+            print(name, rec, flush=True)
+    return out
+
+
 def copy_data():
     os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
     for name in ("Primates", "Mammals"):
@@ -127,6 +154,10 @@ def copy_data():
 def main():
     all_pairs = "--all-pairs" in sys.argv
     copy_data()
+    if "--pipeline" in sys.argv:
+        with open(os.path.join(HERE, "pipeline.json"), "w") as f:
+            json.dump(pipeline(), f, indent=1)
+        return
     if "--only-real" not in sys.argv:
         with open(os.path.join(HERE, "tiny_pairs.json"), "w") as f:
             json.dump(tiny_pairs(), f, indent=0)

@@ -60,6 +60,69 @@ DEF_KERNEL(pkmin16, OP8(F_PKMIN), "v_pk_min_i16 %0, %0, %1")
 DEF_KERNEL(min, OP8(F_MIN), "v_min_i32 %0, %1, %0")
 DEF_KERNEL(add3, OP8(F_ADD3), "v_add3_u32 %0, %0, %1, %2")
 DEF_KERNEL(dpp, OP8(F_DPP), "v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf")
+#define F_SDWA(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1"
+#define F_CNDM(r) "v_cndmask_b32_e64 " r ", " r ", %8, s[20:21]"
+#define F_CNDV(r) "v_cndmask_b32_e32 " r ", " r ", %8, vcc"
+#define F_PERM(r) "v_perm_b32 " r ", " r ", %8, %9"
+#define F_LSHL(r) "v_lshlrev_b32 " r ", 1, " r
+#define F_LSHR(r) "v_lshrrev_b32 " r ", %8, " r
+#define F_OR(r) "v_or_b32 " r ", %8, " r
+#define F_XOR(r) "v_xor_b32 " r ", %8, " r
+#define F_SUB(r) "v_sub_u32 " r ", " r ", %8"
+#define F_MINF(r) "v_min_f32 " r ", %8, " r
+#define F_MIN3F(r) "v_min3_f32 " r ", " r ", %8, %9"
+#define F_ADDF(r) "v_add_f32 " r ", %8, " r
+#define F_CMP(r) "v_cmp_lt_i32 vcc, %8, " r
+#define F_ANDOR(r) "v_and_or_b32 " r ", " r ", %8, %9"
+#define F_BFI(r) "v_bfi_b32 " r ", %8, " r ", %9"
+#define F_MAD24(r) "v_mad_i32_i24 " r ", " r ", %8, %9"
+#define F_MUL24(r) "v_mul_u32_u24 " r ", %8, " r
+#define F_MINU16(r) "v_min_u16 " r ", %8, " r
+#define F_MOV(r) "v_mov_b32 " r ", %8"
+#define F_ADDC(r) "v_addc_co_u32 " r ", vcc, " r ", %8, vcc"
+#define F_LSHLOR(r) "v_lshl_or_b32 " r ", " r ", 2, %8"
+#define F_MED3(r) "v_med3_i32 " r ", " r ", %8, %9"
+#define F_ADDSDWAW(r) "v_add_u32_sdwa " r ", " r ", %8 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+DEF_KERNEL(add_sdwa, OP8(F_SDWA), "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1")
+DEF_KERNEL(add_sdwaw, OP8(F_ADDSDWAW), "v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1")
+DEF_KERNEL(cndmask64, OP8(F_CNDM), "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+DEF_KERNEL(cndmask32, OP8(F_CNDV), "v_cndmask_b32_e32 %0, %0, %1, vcc")
+DEF_KERNEL(perm, OP8(F_PERM), "v_perm_b32 %0, %0, %1, %2")
+DEF_KERNEL(lshl, OP8(F_LSHL), "v_lshlrev_b32 %0, 1, %0")
+DEF_KERNEL(lshr, OP8(F_LSHR), "v_lshrrev_b32 %0, %1, %0")
+DEF_KERNEL(or, OP8(F_OR), "v_or_b32 %0, %1, %0")
+DEF_KERNEL(xor, OP8(F_XOR), "v_xor_b32 %0, %1, %0")
+DEF_KERNEL(sub, OP8(F_SUB), "v_sub_u32 %0, %0, %1")
+DEF_KERNEL(minf, OP8(F_MINF), "v_min_f32 %0, %1, %0")
+DEF_KERNEL(min3f, OP8(F_MIN3F), "v_min3_f32 %0, %0, %1, %2")
+DEF_KERNEL(addf, OP8(F_ADDF), "v_add_f32 %0, %1, %0")
+DEF_KERNEL(cmp, OP8(F_CMP), "v_cmp_lt_i32 vcc, %1, %0")
+DEF_KERNEL(andor, OP8(F_ANDOR), "v_and_or_b32 %0, %0, %1, %2")
+DEF_KERNEL(bfi, OP8(F_BFI), "v_bfi_b32 %0, %1, %0, %2")
+DEF_KERNEL(mad24, OP8(F_MAD24), "v_mad_i32_i24 %0, %0, %1, %2")
+DEF_KERNEL(mul24, OP8(F_MUL24), "v_mul_u32_u24 %0, %1, %0")
+DEF_KERNEL(minu16, OP8(F_MINU16), "v_min_u16 %0, %1, %0")
+DEF_KERNEL(mov, OP8(F_MOV), "v_mov_b32 %0, %1")
+DEF_KERNEL(addc, OP8(F_ADDC), "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+DEF_KERNEL(lshlor, OP8(F_LSHLOR), "v_lshl_or_b32 %0, %0, 2, %1")
+DEF_KERNEL(med3, OP8(F_MED3), "v_med3_i32 %0, %0, %1, %2")
+
+// in-kernel clock under an all-CU integer VALU load: shader cycles (s_memtime) per 100 MHz
+// reference tick (s_memrealtime), MI355X_MICROARCH.md 'DVFS give-back' item 6
+__global__ void k_clockprobe(unsigned long long *out, int seed, int iters) {
+	int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, b = seed * 31 + 6, c = seed | 3;
+	const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+	const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+	for (int i = 0; i < iters; ++i) {
+		asm volatile("v_min3_i32 %0, %0, %4, %5\n v_add_u32 %1, %4, %1\n v_bfe_u32 %2, %2, %4, 6\n v_alignbit_b32 %3, %3, %4, 2\n"
+		             "v_min3_i32 %0, %0, %4, %5\n v_add_u32 %1, %4, %1\n v_and_b32 %2, %4, %2\n v_lshl_add_u32 %3, %3, 3, %4"
+		             : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(b), "v"(c));
+	}
+	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+	const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+	if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = r1 - r0; }
+	if (a0 + a1 + a2 + a3 == 0x7fffffff) out[0] = 0;
+}
 
 typedef void (*kern_t)(int *, int, int);
 
@@ -104,9 +167,30 @@ int main()
 	const int ncu = p.multiProcessorCount;
 	const double ghz = p.clockRate / 1e6;
 	printf("device %s CUs %d clock %.2f GHz; numbers = time per wave64 instruction per SIMD\n", p.gcnArchName, ncu, ghz);
+	{
+		unsigned long long *d, h[2 * 2048];
+		CHECK(hipMalloc(&d, sizeof(h)));
+		for (int wps = 2; wps <= 8; wps *= 2) {
+			const int blocks = ncu * wps / 2;                       // 512-thread blocks: 2 waves per SIMD each
+			for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(k_clockprobe, dim3(blocks), dim3(512), 0, 0, d, 1, 400000);
+			CHECK(hipDeviceSynchronize());
+			CHECK(hipMemcpy(h, d, sizeof(unsigned long long) * 2 * blocks, hipMemcpyDeviceToHost));
+			double lo = 1e9, hi = 0, sum = 0;
+			for (int b = 0; b < blocks; ++b) {
+				const double g = (double)h[2 * b] / (double)h[2 * b + 1] * 0.1;   // GHz
+				lo = g < lo ? g : lo; hi = g > hi ? g : hi; sum += g;
+			}
+			printf("clockprobe int-VALU mix, %d waves/SIMD: in-kernel clock mean %.3f GHz (min %.3f max %.3f), %.1f ms per launch\n",
+			       wps, sum / blocks, lo, hi, (double)h[1] / 1e5);
+		}
+		CHECK(hipFree(d));
+	}
 	CHECK(hipFuncSetAttribute((const void *)k_add, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
 #define RUN(n) CHECK(hipFuncSetAttribute((const void *)k_##n, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024)); run(#n, k_##n, ncu, ghz)
 	RUN(fma); RUN(add); RUN(and); RUN(min); RUN(min3); RUN(add3); RUN(bfe); RUN(lshladd); RUN(alignbit);
 	RUN(pkadd16); RUN(pkmin16); RUN(dpp);
+	RUN(add_sdwa); RUN(add_sdwaw); RUN(cndmask64); RUN(cndmask32); RUN(perm); RUN(lshl); RUN(lshr); RUN(or); RUN(xor);
+	RUN(sub); RUN(minf); RUN(min3f); RUN(addf); RUN(cmp); RUN(andor); RUN(bfi); RUN(mad24); RUN(mul24); RUN(minu16);
+	RUN(mov); RUN(addc); RUN(lshlor); RUN(med3);
 	return 0;
 }
