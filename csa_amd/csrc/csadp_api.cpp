@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -17,6 +18,24 @@
 using csadp::Engine;
 using csadp::FillBatch;
 using csadp::Progressive;
+
+namespace {
+
+/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) alive
+ * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per
+ * input set) and must not pay hipMalloc/hipHostMalloc every time.  Released by
+ * csadp_shutdown(); deliberately not a static object (no HIP calls at process exit). */
+std::mutex g_batch_mutex;
+FillBatch *g_batch = nullptr;
+
+void release_cached_batch()
+{
+	std::lock_guard<std::mutex> lock(g_batch_mutex);
+	delete g_batch;
+	g_batch = nullptr;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -38,7 +57,11 @@ const char *csadp_strerror(int code)
 }
 
 int csadp_init(const csadp_config *cfg) { return Engine::get().init(cfg); }
-void csadp_shutdown(void) { Engine::get().shutdown(); }
+void csadp_shutdown(void)
+{
+	release_cached_batch();
+	Engine::get().shutdown();
+}
 
 int csadp_device_info(char *name, int namelen, int *compute_units)
 {
@@ -117,14 +140,18 @@ int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results
 		memset(&results[t], 0, sizeof(results[t]));
 		status[t] = prog[t].init(tasks[t]);
 	}
-	FillBatch fb;
-	for (;;) {
-		std::vector<int> active;
-		for (int t = 0; t < ntasks; ++t)
-			if (status[t] == CSADP_OK && advance(prog[t])) active.push_back(t);
-		if (active.empty()) break;
-		const int rc = run_round(prog, active, fb, status);
-		if (rc != CSADP_OK) return rc;
+	{
+		std::lock_guard<std::mutex> lock(g_batch_mutex);
+		if (!g_batch) g_batch = new (std::nothrow) FillBatch;
+		if (!g_batch) return CSADP_ERR_NOMEM;
+		for (;;) {
+			std::vector<int> active;
+			for (int t = 0; t < ntasks; ++t)
+				if (status[t] == CSADP_OK && advance(prog[t])) active.push_back(t);
+			if (active.empty()) break;
+			const int rc = run_round(prog, active, *g_batch, status);
+			if (rc != CSADP_OK) return rc;
+		}
 	}
 	int worst = CSADP_OK;
 	for (int t = 0; t < ntasks; ++t) {

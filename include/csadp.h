@@ -21,6 +21,9 @@ extern "C" {
 
 #define CSADP_VERSION 100
 
+/* only the C-ABI below is exported from libcsadp.so */
+#define CSADP_API __attribute__((visibility("default")))
+
 #define CSADP_OK              0
 #define CSADP_ERR_ARG        -1   /* NULL / out-of-range argument                         */
 #define CSADP_ERR_ALPHABET   -2   /* region holds a letter other than A,C,G,T (see below)  */
@@ -40,12 +43,12 @@ typedef struct csadp_config {
 	int verbose;       /* 1 = print the reference's progress tokens in the drop-in adapter */
 } csadp_config;
 
-int csadp_init(const csadp_config *cfg);      /* idempotent; NULL = defaults */
-void csadp_shutdown(void);
-int csadp_version(void);
-const char *csadp_strerror(int code);
+CSADP_API int csadp_init(const csadp_config *cfg);      /* idempotent; NULL = defaults */
+CSADP_API void csadp_shutdown(void);
+CSADP_API int csadp_version(void);
+CSADP_API const char *csadp_strerror(int code);
 /* name of the device in use, number of compute units; CSADP_ERR_NO_DEVICE before init */
-int csadp_device_info(char *name, int namelen, int *compute_units);
+CSADP_API int csadp_device_info(char *name, int namelen, int *compute_units);
 
 /* ---- one alignment task = one ProgressiveDP call ---------------------------------- */
 
@@ -96,8 +99,8 @@ typedef struct csadp_result {
 
 /* Align ntasks independent tasks (any nseq each) on the device: upload, fill, traceback,
  * progressive profile update.  results[t].status carries per-task errors. */
-int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results);
-void csadp_free_result(csadp_result *r, int nseq);
+CSADP_API int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results);
+CSADP_API void csadp_free_result(csadp_result *r, int nseq);
 
 /* ---- device-resident pair batches (the benchmarked path) --------------------------- */
 
@@ -109,11 +112,11 @@ void csadp_free_result(csadp_result *r, int nseq);
  */
 typedef struct csadp_pairbatch csadp_pairbatch;
 
-int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
-int csadp_pairs_run(csadp_pairbatch *b);
-int csadp_pairs_sync(csadp_pairbatch *b);
-int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results);
-void csadp_pairs_destroy(csadp_pairbatch *b);
+CSADP_API int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
+CSADP_API int csadp_pairs_run(csadp_pairbatch *b);
+CSADP_API int csadp_pairs_sync(csadp_pairbatch *b);
+CSADP_API int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results);
+CSADP_API void csadp_pairs_destroy(csadp_pairbatch *b);
 
 typedef struct csadp_timing {
 	long long cells;        /* DP cells of one run()                                      */
@@ -126,19 +129,19 @@ typedef struct csadp_timing {
 	long long border_bytes; /* tile hand-off bytes written + read by one run()            */
 } csadp_timing;
 
-int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);
+CSADP_API int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);
 
 /* ---- host helpers ------------------------------------------------------------------ */
 
 /* Longest-processing-time partition of n task costs over nparts devices.
  * assign[i] receives the part of task i; returns the maximum part load via *maxload. */
-int csadp_partition_lpt(const long long *cost, int n, int nparts, int *assign, long long *maxload);
+CSADP_API int csadp_partition_lpt(const long long *cost, int n, int nparts, int *assign, long long *maxload);
 
 /* FASTA loader following the reference's rules (csamsa.c:433-519): skips \n \r NUL '-'
  * and space, uppercases, admits IUPAC letters, drops a record holding any other byte,
  * at most CSADP_MAX_SEQS records.  texts/descs/sizes are malloc'd arrays of *nseq entries. */
-int csadp_load_fasta(const char *path, char ***texts, char ***descs, int **sizes, int *nseq);
-void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq);
+CSADP_API int csadp_load_fasta(const char *path, char ***texts, char ***descs, int **sizes, int *nseq);
+CSADP_API void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq);
 
 #ifdef __cplusplus
 }

@@ -29,7 +29,7 @@ typedef int (*csadp_debug_fill_fn)(void *user, int nrows, int ncols, int nprev, 
                                    const signed char *rowcodes, const int *top, int left_i,
                                    unsigned char *ops, int *nops, int *remj, int *remk, int *score);
 
-int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fill, void *user,
+CSADP_API int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fill, void *user,
                                   csadp_result *result);
 
 #ifdef __cplusplus

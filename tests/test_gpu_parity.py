@@ -193,3 +193,40 @@ def test_mixed_length_batch():
     for t, g in zip(tasks, got):
         cons, strs, st = oracle_progressive(t[0], t[1])
         assert g["aligned"] == strs and g["score"] == st.last_score
+
+
+def test_long_pair_properties_100kbp():
+    """Config 5 upper range: one ~100 kbp x 100 kbp pair (1e10 cells, 2.5 GB of directions; the
+    reference would need 50 GB of matrices).  No CPU oracle at this size: check the
+    size-independent properties -- strings re-spell the inputs, equal lengths, SP(aligned)
+    equals the DP score the host re-derives along the path, swapping the sequences keeps it."""
+    a, b, ra, rb = synth_pair(4242, length=100000)
+    got = csa_amd.align_batch([([a, b], [ra, rb], None, None), ([b, a], [rb, ra], None, None)])
+    g, h = got
+    assert g["status"] == 0 and h["status"] == 0
+    assert g["cells"] == len(a) * len(b)
+    assert len(g["aligned"][0]) == len(g["aligned"][1]) == g["consensus"]
+    assert degap(g["aligned"][0]) == rotated(a, ra) and degap(g["aligned"][1]) == rotated(b, rb)
+    assert sp_score(g["aligned"]) == g["score"] == h["score"]
+    assert g["score"] > 50000
+
+
+def test_config5_mixed_lengths_sample():
+    """A deterministic sample of config 5's length distribution (1 k .. 200 k), lengths capped
+    so the CPU oracle can confirm the shorter ones string-for-string."""
+    from csa_amd.synth import config5_lengths
+    la, _ = config5_lengths(256)
+    lengths = sorted(la)[::16][:12]            # 12 tasks spanning the distribution's lower 3/4
+    tasks = []
+    for i, length in enumerate(lengths):
+        a, b, ra, rb = synth_pair(9000 + i, length=int(length))
+        tasks.append(([a, b], [ra, rb], None, None))
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        assert g["status"] == 0
+        assert degap(g["aligned"][0]) == rotated(t[0][0], t[1][0])
+        assert degap(g["aligned"][1]) == rotated(t[0][1], t[1][1])
+        assert sp_score(g["aligned"]) == g["score"]
+        if len(t[0][0]) <= 6000:
+            cons, strs, st = oracle_progressive(t[0], t[1])
+            assert g["aligned"] == strs and g["score"] == st.last_score
