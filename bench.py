@@ -89,6 +89,10 @@ def main():
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
     ap.add_argument("--len", type=int, default=16384, dest="length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for barriers/reductions; 'gloo' + --share-device rehearses the "
+                         "N>1 flow on a one-GPU box")
+    ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
 
     import torch
@@ -99,9 +103,10 @@ def main():
     rank, local_rank, world = cdist.env_world()
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
-    torch.cuda.set_device(local_rank)
-    csa_amd.init(device=local_rank)
-    group = cdist.Group(backend="nccl", device="cuda:%d" % local_rank)
+    dev = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev)
+    csa_amd.init(device=dev)
+    group = cdist.Group(backend=args.backend, device="cuda:%d" % dev)
 
     # weak scaling: rank r owns global pairs [r*P, (r+1)*P) of the synthetic batch
     tasks = config4_tasks(rank * args.pairs, args.pairs, args.length)

@@ -41,6 +41,11 @@ class Result(ctypes.Structure):
                 ("aligned", ctypes.POINTER(ctypes.c_void_p))]
 
 
+class SpStats(ctypes.Structure):
+    _fields_ = [("consensus", ctypes.c_int), ("total_gaps", ctypes.c_longlong),
+                ("conserved_columns", ctypes.c_int), ("sp_score", ctypes.c_longlong)]
+
+
 class Timing(ctypes.Structure):
     _fields_ = [("cells", ctypes.c_longlong), ("fill_launches", ctypes.c_int),
                 ("fill_tiles", ctypes.c_longlong), ("fill_ms", ctypes.c_float),
@@ -55,6 +60,7 @@ EXPORTS = [
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
     "csadp_partition_lpt", "csadp_load_fasta", "csadp_free_fasta",
+    "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations",
     "csadp_debug_align_with_filler",
 ]
 
@@ -219,6 +225,34 @@ def load_fasta(path):
     out = [(descs[i].decode(errors="replace"), bytes(texts[i])) for i in range(n.value)]
     L.csadp_free_fasta(texts, descs, sizes, n.value)
     return out
+
+
+def sp_score(aligned):
+    """csadp_sp_score: column statistics of aligned strings on the GPU (tools.c:194-293)."""
+    n = len(aligned)
+    arr = (ctypes.c_char_p * n)(*aligned)
+    st = SpStats()
+    L = lib()
+    L.csadp_sp_score.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int, ctypes.POINTER(SpStats)]
+    _check(L.csadp_sp_score(arr, n, ctypes.byref(st)), "csadp_sp_score")
+    return {k: getattr(st, k) for k, _ in SpStats._fields_}
+
+
+def write_rotated_fasta(path, records, rotations):
+    """records = [(desc, text_bytes)], csadp_write_rotated_fasta (csamsa.c:416-431)."""
+    n = len(records)
+    descs = (ctypes.c_char_p * n)(*[d.encode() for d, _ in records])
+    texts = (ctypes.c_char_p * n)(*[t for _, t in records])
+    sizes = (ctypes.c_int * n)(*[len(t) for _, t in records])
+    rots = (ctypes.c_int * n)(*rotations)
+    _check(lib().csadp_write_rotated_fasta(path.encode(), descs, texts, sizes, rots, n), "csadp_write_rotated_fasta")
+
+
+def read_rotations(path, nmax=64):
+    rots = (ctypes.c_int * nmax)()
+    n = ctypes.c_int()
+    _check(lib().csadp_read_rotations(path.encode(), rots, nmax, ctypes.byref(n)), "csadp_read_rotations")
+    return list(rots[:n.value])
 
 
 def debug_align_with_filler(task, filler):

@@ -12,7 +12,10 @@
 
 #include "csadp.h"
 #include "csadp_debug.h"
+#include <hip/hip_runtime_api.h>
+
 #include "csadp_engine.h"
+#include "csadp_kernels.h"
 #include "csadp_progressive.h"
 
 using csadp::Engine;
@@ -239,6 +242,42 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 }
 
 void csadp_pairs_destroy(csadp_pairbatch *b) { delete b; }
+
+int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out)
+{
+	if (!aligned || !out || nseq < 2 || !aligned[0]) return CSADP_ERR_ARG;
+	if (!Engine::get().ready()) {
+		const int rc = csadp_init(NULL);
+		if (rc != CSADP_OK) return rc;
+	}
+	const size_t len = strlen(aligned[0]);
+	for (int s = 1; s < nseq; ++s)
+		if (!aligned[s] || strlen(aligned[s]) != len) return CSADP_ERR_ARG;   /* tools.c:248-254 */
+	memset(out, 0, sizeof(*out));
+	out->consensus = (int)len;
+	if (len == 0) return CSADP_OK;
+	std::vector<char> host((size_t)nseq * len);
+	for (int s = 0; s < nseq; ++s) memcpy(&host[(size_t)s * len], aligned[s], len);
+	hipStream_t st = Engine::get().stream(0);
+	uint8_t *d_chars = nullptr;
+	long long *d_out = nullptr;
+	long long h_out[3] = {0, 0, 0};
+	int rc = CSADP_ERR_HIP;
+	if (hipMalloc((void **)&d_chars, host.size()) == hipSuccess && hipMalloc((void **)&d_out, sizeof(h_out)) == hipSuccess &&
+	    hipMemcpyAsync(d_chars, host.data(), host.size(), hipMemcpyHostToDevice, st) == hipSuccess &&
+	    hipMemsetAsync(d_out, 0, sizeof(h_out), st) == hipSuccess &&
+	    csadp::launch_sp_columns(d_chars, nseq, (int)len, d_out, st) == hipSuccess &&
+	    hipMemcpyAsync(h_out, d_out, sizeof(h_out), hipMemcpyDeviceToHost, st) == hipSuccess &&
+	    hipStreamSynchronize(st) == hipSuccess) {
+		out->total_gaps = h_out[0];
+		out->conserved_columns = (int)h_out[1];
+		out->sp_score = h_out[2];
+		rc = CSADP_OK;
+	}
+	if (d_chars) (void)hipFree(d_chars);
+	if (d_out) (void)hipFree(d_out);
+	return rc;
+}
 
 /* ---- test seam: run the HOST logic of one task with a caller-supplied matrix filler ------- */
 

@@ -93,6 +93,52 @@ int csadp_load_fasta(const char *path, char ***texts, char ***descs, int **sizes
 	return CSADP_OK;
 }
 
+/* saveRotatedSequences, csamsa.c:416-431 */
+int csadp_write_rotated_fasta(const char *path, const char *const *descs, const char *const *texts,
+                              const int *sizes, const int *rotations, int nseq)
+{
+	if (!path || !descs || !texts || !sizes || !rotations || nseq < 1) return CSADP_ERR_ARG;
+	for (int i = 0; i < nseq; ++i)
+		if (rotations[i] < 0 || rotations[i] > sizes[i]) return CSADP_ERR_ARG;
+	FILE *f = fopen(path, "wb");
+	if (!f) return CSADP_ERR_ARG;
+	for (int i = 0; i < nseq; ++i) {
+		fprintf(f, ">%s @ %d\n", descs[i], rotations[i]);
+		fwrite(texts[i] + rotations[i], 1, (size_t)(sizes[i] - rotations[i]), f);
+		fwrite(texts[i], 1, (size_t)rotations[i], f);
+		fputc('\n', f);
+	}
+	return fclose(f) == 0 ? CSADP_OK : CSADP_ERR_ARG;
+}
+
+int csadp_read_rotations(const char *path, int *rotations, int nmax, int *nread)
+{
+	if (!path || !rotations || !nread || nmax < 0) return CSADP_ERR_ARG;
+	FILE *f = fopen(path, "rb");
+	if (!f) return CSADP_ERR_ARG;
+	std::string line;
+	int n = 0, c;
+	bool header = false, any = false;
+	while ((c = fgetc(f)) != EOF) {
+		if (!any && c != '>') continue;              /* only a '>' opens a header (first byte of a line) */
+		if (c == '>' && !header) { header = true; any = true; line.clear(); continue; }
+		if (header) {
+			if (c == '\n' || c == '\r') {
+				header = false;
+				const size_t at = line.rfind(" @ ");
+				if (at == std::string::npos) { fclose(f); return CSADP_ERR_ARG; }
+				if (n < nmax) rotations[n] = atoi(line.c_str() + at + 3);
+				++n;
+			} else {
+				line.push_back((char)c);
+			}
+		}
+	}
+	fclose(f);
+	*nread = n < nmax ? n : nmax;
+	return n > 0 ? CSADP_OK : CSADP_ERR_ARG;
+}
+
 void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq)
 {
 	for (int i = 0; i < nseq; ++i) {

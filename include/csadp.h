@@ -131,6 +131,18 @@ typedef struct csadp_timing {
 
 CSADP_API int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);
 
+/* ---- alignment statistics on the device (tools.c:194-293, CalculateSumOfPairsScore) ---- */
+
+typedef struct csadp_sp_stats {
+	int consensus;            /* common length of the aligned strings ("Consensus size")        */
+	long long total_gaps;     /* '-' characters over all sequences (the tool prints gaps/nseq)   */
+	int conserved_columns;    /* columns whose characters are identical in every sequence        */
+	long long sp_score;       /* sum over columns and sequence pairs: gap/gap 0, equal +1, else -1 */
+} csadp_sp_stats;
+
+/* aligned[0..nseq) are NUL-terminated strings of equal length (else CSADP_ERR_ARG). */
+CSADP_API int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out);
+
 /* ---- host helpers ------------------------------------------------------------------ */
 
 /* Longest-processing-time partition of n task costs over nparts devices.
@@ -142,6 +154,14 @@ CSADP_API int csadp_partition_lpt(const long long *cost, int n, int nparts, int 
  * at most CSADP_MAX_SEQS records.  texts/descs/sizes are malloc'd arrays of *nseq entries. */
 CSADP_API int csadp_load_fasta(const char *path, char ***texts, char ***descs, int **sizes, int *nseq);
 CSADP_API void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq);
+
+/* "<base>-Rotated.fasta" wire format of saveRotatedSequences (csamsa.c:416-431): one record per
+ * sequence, header ">desc @ rot", the text rotated left by rot on ONE line.  The reader returns
+ * the rotation offsets of such a file (how a caller feeds the reference's mode-R output to the
+ * DP); at most nmax records, *nread receives the count. */
+CSADP_API int csadp_write_rotated_fasta(const char *path, const char *const *descs, const char *const *texts,
+                                        const int *sizes, const int *rotations, int nseq);
+CSADP_API int csadp_read_rotations(const char *path, int *rotations, int nmax, int *nread);
 
 #ifdef __cplusplus
 }

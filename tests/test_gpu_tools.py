@@ -1,0 +1,65 @@
+"""GPU tests (-m gpu) of the pieces around the DP: the C harness csa_pairs (host in C over the
+C-ABI, configs 1-3 of SURVEY.md 8d) and the column-statistics kernel (tools.c:194-293)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+import csa_amd
+from helpers import GOLDEN, ROOT, load_golden, random_family, rng, sp_score
+
+pytestmark = pytest.mark.gpu
+
+HARNESS = os.path.join(ROOT, "csa_amd", "csa_pairs")
+ROT = {"Primates": "1947,1949,1950,2530,1952,1946,1951,1952,1975,1955,1954,2475,1948,1947,1940,1948",
+       "Mammals": "1283,1304,1263,1640,1277,1722,1295,1272,1851,1273,1266,1273"}
+
+
+def _run(args):
+    out = subprocess.run([HARNESS] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0, out.stdout.decode()
+    return out.stdout.decode()
+
+
+def test_csa_pairs_config1_single_pair():
+    """Config 1/2: Primates pair (0,1) with fixture rotations -> len 16589 / SP 15197 / 7ee50a99."""
+    log = _run([os.path.join(GOLDEN, "data", "Primates.txt"), "--rot", ROT["Primates"], "--pair", "0,1"])
+    assert "pair 0 1 len 16589 SP 15197 score 15197 fnv1a 7ee50a99" in log
+
+
+def test_csa_pairs_config3_mammals_all_vs_all(tmp_path):
+    """Config 3: all 66 Mammals pairs, rotations read back from a -Rotated.fasta the harness wrote."""
+    fasta = os.path.join(GOLDEN, "data", "Mammals.txt")
+    rotated = str(tmp_path / "Mammals-Rotated.fasta")
+    _run([fasta, "--rot", ROT["Mammals"], "--pair", "0,1", "--write-rotated", rotated])
+    log = _run([fasta, "--rotated", rotated])
+    gold = {(c["a"], c["b"]): c for c in load_golden("real_pairs.json") if c["set"] == "Mammals"}
+    seen = 0
+    for m in re.finditer(r"pair (\d+) (\d+) len (\d+) SP (-?\d+) score (-?\d+) fnv1a ([0-9a-f]{8})", log):
+        a, b = int(m.group(1)), int(m.group(2))
+        g = gold[(a, b)]
+        assert (int(m.group(3)), int(m.group(4)), int(m.group(5)), m.group(6)) == (g["consensus"], g["sp"], g["sp"], g["fnv1a"])
+        seen += 1
+    assert seen == 66
+    assert "18593884141 cells" in log
+
+
+def test_sp_score_kernel_matches_tools_rule():
+    csa_amd.init(device=0)
+    r = rng(5)
+    # aligned strings from real progressive tasks (gaps, conserved columns) ...
+    cases = [c for c in load_golden("tiny_families.json") if c["aligned"][0]][:40]
+    for c in cases:
+        strs = [a.encode() for a in c["aligned"]]
+        st = csa_amd.sp_score(strs)
+        assert st["sp_score"] == sp_score(strs)
+        assert st["consensus"] == len(strs[0])
+        assert st["total_gaps"] == sum(s.count(b"-") for s in strs)
+        assert st["conserved_columns"] == sum(1 for col in zip(*strs) if len(set(col)) == 1)
+    # ... and a long random one with IUPAC letters (compared by character, tools.c:276-278)
+    fam = [bytes(r.choice(b"ACGT-N") for _ in range(30000)) for _ in range(12)]
+    st = csa_amd.sp_score(fam)
+    assert st["sp_score"] == sp_score(fam)
+    with pytest.raises(csa_amd.CsadpError):
+        csa_amd.sp_score([b"ACGT", b"ACG"])

@@ -122,3 +122,24 @@ def test_synthetic_pairs_are_deterministic_and_related():
     cons, strs, st = oracle_progressive([a, b], [ra, rb])
     assert degap(strs[0]) == rotated(a, ra) and degap(strs[1]) == rotated(b, rb)
     assert st.last_score > 0.5 * len(a)          # ~10 % substitutions, 2 % indels
+
+
+def test_rotated_fasta_wire_format(tmp_path):
+    """csadp_write_rotated_fasta reproduces the reference's <base>-Rotated.fasta byte for byte
+    (md5 recorded from the unmodified reference program, tests/golden/pipeline.json) and
+    csadp_read_rotations recovers the offsets from its headers."""
+    import hashlib
+    import json
+    sys_path = os.path.join(GOLDEN, "make_golden.py")
+    assert os.path.exists(sys_path)
+    rot = {"Primates": [1947, 1949, 1950, 2530, 1952, 1946, 1951, 1952, 1975, 1955, 1954, 2475, 1948, 1947, 1940, 1948],
+           "Mammals": [1283, 1304, 1263, 1640, 1277, 1722, 1295, 1272, 1851, 1273, 1266, 1273]}
+    with open(os.path.join(GOLDEN, "pipeline.json")) as f:
+        gold = json.load(f)
+    for name in ("Primates", "Mammals"):
+        recs = csa_amd.load_fasta(os.path.join(GOLDEN, "data", name + ".txt"))
+        out = str(tmp_path / (name + "-Rotated.fasta"))
+        csa_amd.write_rotated_fasta(out, recs, rot[name])
+        with open(out, "rb") as f:
+            assert hashlib.md5(f.read()).hexdigest() == gold[name]["rotated_md5"]
+        assert csa_amd.read_rotations(out) == rot[name]
