@@ -24,14 +24,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU issue roofline of the fill kernel.  Per cell the kernel issues 7 VALU instructions
-# (csadp_kernels.hip): v_add_u32 x2 and v_and_b32 are full rate (2 issue cycles per wave64
-# instruction on a SIMD), v_bfe_u32, v_lshl_add_u32, v_min3_i32 and v_alignbit_b32 are half
-# rate (4 cycles) on gfx950 -- measured by tools/valu_microbench.hip,
-# profiles/r01_valu_microbench.txt.  3*2 + 4*4 = 22 issue cycles per 64 cells per SIMD.
-VALU_OPS_PER_CELL = 7
-VALU_ISSUE_CYCLES_PER_CELL_WAVE = 22
-VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9     # 7.15e12 cells/s
+# VALU issue roofline of the fill kernel (gain form, csadp_device.h): 6 VALU instructions per
+# cell -- v_bfe_u32, v_max3_i32, v_alignbit_b32 (half rate: 4 issue cycles per wave64
+# instruction per SIMD) and v_add_u32 x2, v_and_b32 (full rate: 2 cycles), measured one kind at
+# a time by tools/valu_microbench.hip (profiles/r01_valu_microbench.txt).  Priced one by one
+# that is 3*4 + 3*2 = 18 issue cycles per 64 cells per SIMD -> 8.7 TCUPS at 2.4 GHz: the
+# `peak` below.  The same microbenchmark shows that in a MIXED stream every instruction costs
+# ~4.2-4.4 cycles whatever the order ("order ..." and "cellmix" lines): this exact 6-op
+# recurrence, registers only, no memory, sustains 25.0 cycles per 64 cells = 6.3 TCUPS per
+# GPU -- reported as `mix_ceiling`.
+VALU_OPS_PER_CELL = 6
+VALU_ISSUE_CYCLES_PER_CELL_WAVE = 18
+VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9     # 8.74e12 cells/s
+VALU_MIX_CEILING_CUPS = 6.30e12       # cellmix microbenchmark, 4 waves per SIMD
 
 
 def pmc_traffic_per_launch():
@@ -187,8 +192,11 @@ def main():
                               "issue_cycles_per_64_cells": VALU_ISSUE_CYCLES_PER_CELL_WAVE,
                               "achieved": round(eff_cups / 1e9, 1), "peak": round(VALU_PEAK_CUPS / 1e9, 1),
                               "unit": "GCUPS", "frac": round(eff_cups / VALU_PEAK_CUPS, 4),
-                              "note": "peak = 1024 SIMDs x 64 cells / 22 issue cycles x 2.4 GHz; per-op issue "
-                                      "rates measured on this chip (profiles/r01_valu_microbench.txt)"},
+                              "mix_ceiling": round(VALU_MIX_CEILING_CUPS / 1e9, 1),
+                              "frac_of_mix_ceiling": round(eff_cups / VALU_MIX_CEILING_CUPS, 4),
+                              "note": "peak = 1024 SIMDs x 64 cells / 18 issue cycles x 2.4 GHz with per-op issue rates "
+                                      "measured one kind at a time; mix_ceiling = the same 6-op recurrence in registers "
+                                      "only, as measured on this chip (profiles/r01_valu_microbench.txt)"},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)

@@ -121,6 +121,7 @@ int main(int argc, char **argv)
 			p++;
 		}
 	}
+	setenv("CSADP_SLOTS", "1", 0);      /* one pass only: no need for pipelined scratch sets */
 	if ((rc = csadp_init(NULL)) != CSADP_OK) die("init", rc);
 	t0 = now_s();
 	if ((rc = csadp_pairs_create(tasks, npairs, &batch)) != CSADP_OK) die("pairs_create", rc);

@@ -5,9 +5,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "csadp.h"
@@ -30,6 +32,32 @@ namespace {
  * csadp_shutdown(); deliberately not a static object (no HIP calls at process exit). */
 std::mutex g_batch_mutex;
 FillBatch *g_batch = nullptr;
+
+/* Per-task host work (validation, table packing, traceback application, string building) is
+ * independent across tasks: spread it over host threads (CSADP_HOST_THREADS, default
+ * min(16, hardware threads)); n small -> run inline. */
+template <class F>
+void parallel_for(int n, F &&fn)
+{
+	static const int nthreads = [] {
+		const char *e = getenv("CSADP_HOST_THREADS");
+		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
+		return t < 1 ? 1 : (t > 16 ? 16 : t);
+	}();
+	const int workers = n < 4 ? 1 : (nthreads < n ? nthreads : n);
+	if (workers <= 1) {
+		for (int i = 0; i < n; ++i) fn(i);
+		return;
+	}
+	std::atomic<int> next(0);
+	auto body = [&]() {
+		for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+	};
+	std::vector<std::thread> pool;
+	for (int w = 1; w < workers; ++w) pool.emplace_back(body);
+	body();
+	for (auto &t : pool) t.join();
+}
 
 void release_cached_batch()
 {
@@ -105,16 +133,17 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	for (int t : active) fb.add(tasks[t].nrows(), tasks[t].ncols(), tasks[t].nprev(), tasks[t].border_i());
 	int rc = fb.layout();
 	if (rc != CSADP_OK) return rc;
-	for (size_t j = 0; j < active.size(); ++j)
-		tasks[active[j]].write_tables(fb.coltab((int)j), fb.ncols_pad((int)j), fb.rowshift((int)j), fb.top((int)j));
+	parallel_for((int)active.size(), [&](int j) {
+		tasks[active[(size_t)j]].write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
+	});
 	if ((rc = fb.upload()) != CSADP_OK) return rc;
 	if ((rc = fb.run()) != CSADP_OK) return rc;
 	if ((rc = fb.download()) != CSADP_OK) return rc;
-	for (size_t j = 0; j < active.size(); ++j) {
-		const int32_t *sm = fb.summary((int)j);
-		const int a = tasks[active[j]].apply_trace(fb.ops((int)j), sm[0], sm[1], sm[2]);
-		if (a != CSADP_OK) status[active[j]] = a;
-	}
+	parallel_for((int)active.size(), [&](int j) {
+		const int32_t *sm = fb.summary(j);
+		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2]);
+		if (a != CSADP_OK) status[active[(size_t)j]] = a;
+	});
 	return CSADP_OK;
 }
 
@@ -139,10 +168,10 @@ int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results
 	}
 	std::vector<Progressive> prog((size_t)ntasks);
 	std::vector<int> status((size_t)ntasks, CSADP_OK);
-	for (int t = 0; t < ntasks; ++t) {
+	parallel_for(ntasks, [&](int t) {
 		memset(&results[t], 0, sizeof(results[t]));
-		status[t] = prog[t].init(tasks[t]);
-	}
+		status[(size_t)t] = prog[(size_t)t].init(tasks[t]);
+	});
 	{
 		std::lock_guard<std::mutex> lock(g_batch_mutex);
 		if (!g_batch) g_batch = new (std::nothrow) FillBatch;
@@ -156,13 +185,10 @@ int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results
 			if (rc != CSADP_OK) return rc;
 		}
 	}
-	int worst = CSADP_OK;
-	for (int t = 0; t < ntasks; ++t) {
-		if (status[t] == CSADP_OK) status[t] = prog[t].finish(&results[t]);
-		results[t].status = status[t];
-		if (status[t] != CSADP_OK) worst = status[t];
-	}
-	(void)worst;
+	parallel_for(ntasks, [&](int t) {
+		if (status[(size_t)t] == CSADP_OK) status[(size_t)t] = prog[(size_t)t].finish(&results[t]);
+		results[t].status = status[(size_t)t];
+	});
 	return CSADP_OK;
 }
 
@@ -177,19 +203,25 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 	if (!b) return CSADP_ERR_NOMEM;
 	b->tasks = std::vector<Progressive>((size_t)ntasks);
 	b->status.assign((size_t)ntasks, CSADP_OK);
-	for (int t = 0; t < ntasks; ++t) {
+	for (int t = 0; t < ntasks; ++t)
 		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
-		b->status[t] = b->tasks[t].init(tasks[t]);
-		if (b->status[t] == CSADP_OK && advance(b->tasks[t])) b->active.push_back(t);
-	}
+	std::vector<char> pending((size_t)ntasks, 0);
+	csadp_pairbatch *bp = b.get();
+	parallel_for(ntasks, [&](int t) {
+		bp->status[(size_t)t] = bp->tasks[(size_t)t].init(tasks[t]);
+		pending[(size_t)t] = (bp->status[(size_t)t] == CSADP_OK && advance(bp->tasks[(size_t)t])) ? 1 : 0;
+	});
+	for (int t = 0; t < ntasks; ++t)
+		if (pending[(size_t)t]) b->active.push_back(t);
 	if (!b->active.empty()) {
 		b->fb.set_pipelined(true);
 		for (int t : b->active) b->fb.add(b->tasks[t].nrows(), b->tasks[t].ncols(), b->tasks[t].nprev(), b->tasks[t].border_i());
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
-		for (size_t j = 0; j < b->active.size(); ++j)
-			b->tasks[b->active[j]].write_tables(b->fb.coltab((int)j), b->fb.ncols_pad((int)j), b->fb.rowshift((int)j),
-			                                    b->fb.top((int)j));
+		parallel_for((int)b->active.size(), [&](int j) {
+			bp->tasks[(size_t)bp->active[(size_t)j]].write_tables(bp->fb.coltab(j), bp->fb.leftc(j), bp->fb.ncols_pad(j),
+			                                                    bp->fb.rowshift(j), bp->fb.top(j), bp->fb.wide());
+		});
 		if ((rc = b->fb.upload()) != CSADP_OK) return rc;
 		if ((rc = b->fb.sync()) != CSADP_OK) return rc;
 	}
@@ -226,17 +258,18 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 	if (!b->active.empty()) {
 		const int rc = b->fb.download();
 		if (rc != CSADP_OK) return rc;
-		for (size_t j = 0; j < b->active.size(); ++j) {
-			const int32_t *sm = b->fb.summary((int)j);
-			const int a = b->tasks[b->active[j]].apply_trace(b->fb.ops((int)j), sm[0], sm[1], sm[2]);
-			if (a != CSADP_OK) b->status[b->active[j]] = a;
-		}
+		parallel_for((int)b->active.size(), [&](int j) {
+			const int32_t *sm = b->fb.summary(j);
+			const size_t t = (size_t)b->active[(size_t)j];
+			const int a = b->tasks[t].apply_trace(b->fb.ops(j), sm[0], sm[1], sm[2]);
+			if (a != CSADP_OK) b->status[t] = a;
+		});
 	}
-	for (size_t t = 0; t < b->tasks.size(); ++t) {
+	parallel_for((int)b->tasks.size(), [&](int t) {
 		memset(&results[t], 0, sizeof(results[t]));
-		if (b->status[t] == CSADP_OK) b->status[t] = b->tasks[t].finish(&results[t]);
-		results[t].status = b->status[t];
-	}
+		if (b->status[(size_t)t] == CSADP_OK) b->status[(size_t)t] = b->tasks[(size_t)t].finish(&results[t]);
+		results[t].status = b->status[(size_t)t];
+	});
 	b->fetched = true;
 	return CSADP_OK;
 }

@@ -1,15 +1,16 @@
 /*
  * csadp_device.h -- device-side data layout shared by the HIP kernels and the host engine.
  *
- * Cost representation used on the device (all int32):
- *     cost[r][k] = -4 * H[r][k] + 4 * i * r            (low 2 bits: direction tag)
+ * Score representation used on the device (all int32), "gain form":
+ *     X[r][k] = 4 * H[r][k] + 4 * i * r                (low 2 bits: direction tag)
  * where H is the reference's dpmatrix (dynamicprogramming.c:996-1025) and i the number of
- * already aligned sequences.  The three candidate moves then cost
- *     diag : + 8 * (i - sv[k][c])         tag 0   ('D')
- *     left : + 4 * (i - sv[k][4]) + 1     tag 1   ('L')
- *     up   : + 8 * i              + 2     tag 2   ('U')
- * and min3 over (cost | tag) picks the reference's direction with the reference's
- * tie-break (D >= L >= U, :1014-1025) in one instruction.
+ * already aligned sequences.  Adding 4*i per row cancels the row-gap score, so the three
+ * candidate moves become
+ *     up   : + 0                              tag 0   ('U')   -- no instruction at all
+ *     left : + 4 * (sv[k][4] - i)  + 1        tag 1   ('L')
+ *     diag : + 8 * sv[k][c]        + 2        tag 2   ('D')
+ * and max3 over (X | tag) picks the reference's H and the reference's direction with the
+ * reference's tie-break (D >= L >= U, :1014-1025) in one instruction.
  */
 #ifndef CSADP_DEVICE_H
 #define CSADP_DEVICE_H
@@ -21,7 +22,7 @@ namespace csadp {
 constexpr int kLanes = 64;           /* wave64 */
 
 /* direction codes stored 2 bit per cell */
-enum : int { DIR_D = 0, DIR_L = 1, DIR_U = 2 };
+enum : int { DIR_U = 0, DIR_L = 1, DIR_D = 2 };
 
 /* One matrix fill (one progressive step of one task).  Columns are owned by lanes:
  * global lane L = 64*strip + lane owns columns [L*C+1, L*C+C]; at global step T it computes
@@ -30,9 +31,12 @@ enum : int { DIR_D = 0, DIR_L = 1, DIR_U = 2 };
 struct FillJob {
 	/* byte offsets into the batch arena (one hipMalloc); the kernels add them to their
 	 * arena kernel argument so every access is a global_* (not flat_*) instruction */
-	uint64_t coltab;          /* u32 [ncols_pad] f0 | f1<<6 | f2<<12 | f3<<18 | g<<24, f_c = i-sv[c], g = i-sv[4] */
-	uint64_t rowshift;        /* u8  [padl + R*steps_pad + R*64] 6*code of row r at index padl + (r-1), zero padded */
-	uint64_t top;             /* i32 [ncols_pad + 1] cost of border row 0 (possibly stale, survey Q1)             */
+	uint64_t coltab;          /* u32 [ncols_pad] diag gains per row letter: bytes 8*sv[c]+2 (narrow, i <= 31) or    */
+	                          /*     6-bit fields sv[c] (wide, i <= 63)                                            */
+	uint64_t leftc;           /* i32 [ncols_pad] left gain 4*(sv[4]-i) + 1                                        */
+	uint64_t rowshift;        /* u8  [padl + R*steps_pad + R*64] bfe offset of row r's letter (8*code narrow,     */
+	                          /*     6*code wide) at index padl + (r-1), zero padded                               */
+	uint64_t top;             /* i32 [ncols_pad + 1] X of border row 0 = 4*H[0][k] (possibly stale, survey Q1)    */
 	uint64_t handoff;         /* i32 [nstrips][hpitch][R] right-edge cost after step T, row q, at index R*(T+1)+q */
 	uint64_t state;           /* i32 [nstrips][C+1+R][64] lane registers between two tiles of a strip             */
 	uint64_t dirs;            /* u32 [nstrips][steps_pad][R][C/16][64] sixteen 2-bit codes per word               */
@@ -43,8 +47,8 @@ struct FillJob {
 	int32_t steps_pad;        /* number of steps allocated per strip (multiple of TR)                         */
 	int32_t hpitch;           /* steps_pad + 64                                                               */
 	int32_t padl;             /* left padding of rowshift = R*(64*nstrips + 64)                               */
-	int32_t upc;              /* 8*i + 2                                                                       */
-	int32_t leftmul;          /* 4*(left_i + i): cost of border column 0 is leftmul * r                       */
+	int32_t nprev;            /* i                                                                             */
+	int32_t leftmul;          /* 4*(i - left_i): X of border column 0 is leftmul * r (0 on fresh borders)      */
 };
 
 struct TileRef {

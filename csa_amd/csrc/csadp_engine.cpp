@@ -79,9 +79,36 @@ int Engine::init(const csadp_config *cfg)
 	return CSADP_OK;
 }
 
+void Engine::give_arena(uint8_t *ptr, size_t bytes)
+{
+	if (!ptr) return;
+	if (!ready_ || bytes <= cached_bytes_) { (void)hipFree(ptr); return; }
+	if (cached_arena_) (void)hipFree(cached_arena_);
+	cached_arena_ = ptr;
+	cached_bytes_ = bytes;
+}
+
+uint8_t *Engine::take_arena(size_t need, size_t *got)
+{
+	if (!cached_arena_ || cached_bytes_ < need) return nullptr;
+	uint8_t *p = cached_arena_;
+	*got = cached_bytes_;
+	cached_arena_ = nullptr;
+	cached_bytes_ = 0;
+	return p;
+}
+
+void Engine::drop_arena_cache()
+{
+	if (cached_arena_) (void)hipFree(cached_arena_);
+	cached_arena_ = nullptr;
+	cached_bytes_ = 0;
+}
+
 void Engine::shutdown()
 {
 	if (!ready_) return;
+	drop_arena_cache();
 	for (int i = 0; i < slots_; ++i) {
 		(void)hipStreamSynchronize(streams_[i]);
 		(void)hipStreamDestroy(streams_[i]);
@@ -94,7 +121,7 @@ void Engine::shutdown()
 
 FillBatch::~FillBatch()
 {
-	if (arena_) (void)hipFree(arena_);
+	if (arena_) Engine::get().give_arena(arena_, arena_cap_);
 	if (h_in_) (void)hipHostFree(h_in_);
 	if (h_res_) (void)hipHostFree(h_res_);
 	for (auto &slot : ev_)
@@ -118,8 +145,8 @@ int FillBatch::add(int nrows, int ncols, int nprev, int left_i)
 	memset(&j, 0, sizeof(j));
 	j.nrows = nrows;
 	j.ncols = ncols;
-	j.upc = 8 * nprev + 2;
-	j.leftmul = 4 * (left_i + nprev);
+	j.nprev = nprev;
+	j.leftmul = 4 * (nprev - left_i);
 	jobs_.push_back(j);
 	laid_out_ = false;
 	return (int)jobs_.size() - 1;
@@ -133,6 +160,7 @@ int FillBatch::layout()
 	const int nj = (int)jobs_.size();
 	extra_.assign(nj, Extra());
 	cells_ = dir_bytes_ = border_bytes_ = 0;
+	wide_ = false;
 
 	/* geometry + tile schedule */
 	int ndiag = 0;
@@ -140,8 +168,10 @@ int FillBatch::layout()
 	for (int j = 0; j < nj; ++j) {
 		FillJob &J = jobs_[j];
 		if (J.nrows <= 0 || J.ncols <= 0) return CSADP_ERR_ARG;
-		const long long nprev = (J.upc - 2) / 8;
+		const long long nprev = J.nprev;
+		if (nprev < 1 || nprev > 63) return CSADP_ERR_ARG;
 		if (nprev * (2LL * J.nrows + J.ncols) * 4 + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
+		if (nprev > 31) wide_ = true;
 		const int lanes = (J.ncols + C - 1) / C;
 		J.nstrips = (lanes + kLanes - 1) / kLanes;
 		extra_[j].ncols_pad = J.nstrips * kLanes * C;
@@ -199,6 +229,8 @@ int FillBatch::layout()
 		Extra &X = extra_[j];
 		X.in_coltab = J.coltab = off;
 		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
+		X.in_leftc = J.leftc = off;
+		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
 		X.in_rowshift = J.rowshift = off;
 		off = align_up(off + (size_t)J.padl + (size_t)R * J.steps_pad + (size_t)R * 64 + 64, 256);
 		X.in_top = J.top = off;
@@ -232,7 +264,11 @@ int FillBatch::layout()
 	total_bytes_ = off;
 
 	if (total_bytes_ > arena_cap_) {
-		if (arena_) { (void)hipFree(arena_); arena_ = nullptr; arena_cap_ = 0; }
+		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
+		arena_ = E.take_arena(total_bytes_, &arena_cap_);
+	}
+	if (total_bytes_ > arena_cap_) {
+		E.drop_arena_cache();
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
 		if (total_bytes_ + (256u << 20) > free_b) {
@@ -269,6 +305,7 @@ int FillBatch::layout()
 }
 
 uint32_t *FillBatch::coltab(int j) { return reinterpret_cast<uint32_t *>(h_in_ + extra_[j].in_coltab); }
+int32_t *FillBatch::leftc(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_leftc); }
 uint8_t *FillBatch::rowshift(int j) { return h_in_ + extra_[j].in_rowshift + jobs_[j].padl; }
 int32_t *FillBatch::top(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_top); }
 int FillBatch::ncols_pad(int j) const { return extra_[j].ncols_pad; }
@@ -298,7 +335,7 @@ int FillBatch::run()
 	const int ndiag = (int)diag_off_.size() - 1;
 	for (int d = 0; d < ndiag; ++d) {
 		const int cnt = (int)(diag_off_[d + 1] - diag_off_[d]);
-		HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), arena_, djobs, dtiles + diag_off_[d], cnt, st));
+		HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, dtiles + diag_off_[d], cnt, st));
 	}
 	HIP_TRY(hipEventRecord(ev[1], st));
 	HIP_TRY(launch_traceback(E.C(), E.R(), arena_, djobs, (int)jobs_.size(), st));

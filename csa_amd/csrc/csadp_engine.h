@@ -31,6 +31,11 @@ public:
 	const char *name() const { return name_; }
 	int compute_units() const { return cus_; }
 	bool verbose() const { return verbose_; }
+	/* one-entry cache of the last released HBM arena: consecutive batches of similar size
+	 * (bench steps, csa_pairs runs, the drop-in's ~50 calls) skip hipMalloc/hipFree */
+	void give_arena(uint8_t *ptr, size_t bytes);
+	uint8_t *take_arena(size_t need, size_t *got);
+	void drop_arena_cache();
 
 private:
 	bool ready_ = false;
@@ -41,6 +46,8 @@ private:
 	char name_[256] = {0};
 	int slots_ = 2;
 	hipStream_t streams_[kMaxSlots] = {};
+	uint8_t *cached_arena_ = nullptr;
+	size_t cached_bytes_ = 0;
 };
 
 /*
@@ -73,6 +80,8 @@ public:
 	int layout();
 	/* host staging pointers for the inputs of job j (valid after layout) */
 	uint32_t *coltab(int j);
+	int32_t *leftc(int j);
+	bool wide() const { return wide_; }   /* table format of this batch (csadp_device.h) */
 	uint8_t *rowshift(int j);        /* points at row 1 (index padl) */
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
@@ -85,7 +94,7 @@ public:
 	int timing(csadp_timing *t);
 
 private:
-	struct Extra { int ncols_pad; size_t in_coltab, in_rowshift, in_top, res_summary, res_ops; };
+	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
 	std::vector<FillJob> jobs_;
 	std::vector<Extra> extra_;
 	std::vector<TileRef> tiles_;
@@ -101,7 +110,7 @@ private:
 	uint8_t *h_res_ = nullptr;       /* pinned mirror of the result region */
 	size_t h_res_cap_ = 0;
 	hipEvent_t ev_[Engine::kMaxSlots][3] = {};
-	bool laid_out_ = false, ran_ = false, pipelined_ = false;
+	bool laid_out_ = false, ran_ = false, pipelined_ = false, wide_ = false;
 	long long cells_ = 0, dir_bytes_ = 0, border_bytes_ = 0;
 };
 

@@ -10,8 +10,9 @@ namespace csadp {
 
 /* Launch one tile anti-diagonal: ntiles single-wave workgroups.  C = columns per lane
  * (16 or 32), R = rows per lane-step (1, 2 or 4), TR = steps per tile (64, 128 or 256). */
-hipError_t launch_fill(int C, int R, int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles,
-                       hipStream_t st);
+/* wide = 6-bit count fields (needed when some job has i >= 32), else pre-scaled bytes */
+hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles,
+                       int ntiles, hipStream_t st);
 
 /* Launch the direction walk: one wave per job. */
 hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st);

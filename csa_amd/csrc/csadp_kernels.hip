@@ -19,9 +19,10 @@
  * FillJob::handoff]: the host launches one grid per tile anti-diagonal a+s, for all tasks
  * of a batch at once; no workgroup waits on another inside a launch.
  *
- * Per cell: v_bfe_u32 (profile field) + v_lshl_add_u32 (diag) + 2 v_add (up, left) +
- * v_min3_i32 + v_alignbit_b32 (shift the 2-bit tag into the direction word) + v_and (clear
- * the tag) = 7 VALU instructions; see csadp_device.h for the cost/tag representation.
+ * Per cell: v_bfe_u32 (diag gain of the row letter) + 2 v_add (diag, left; the up move is
+ * free in the gain form of csadp_device.h) + v_max3_i32 + v_alignbit_b32 (shift the 2-bit
+ * tag into the direction word) + v_and (clear the tag) = 6 VALU instructions, 18 issue
+ * cycles per 64 cells on gfx950 (bfe/max3/alignbit are half rate: tools/valu_microbench.hip).
  * Directions are stored in the order they are produced (strip, step, row, lane): coalesced
  * 256-byte stores; the traceback kernel addresses the same layout.
  */
@@ -49,11 +50,11 @@ namespace csadp {
  * per-step branch and the register copies it forces.  LDS operands of step t+1 (lane-0
  * feed, row letters) are fetched during step t.
  */
-template <int C, int R, int TR, bool RAMP>
+template <int C, int R, int TR, bool WIDE, bool RAMP>
 __device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32_t (&leftc)[C], int32_t (&hup)[C],
                                            int32_t &diag_in, int32_t (&last)[R], const int32_t *feed,
                                            const uint8_t *myrsh, int32_t *edge, uint32_t *dirs, int r0s,
-                                           int upc, int lane)
+                                           int lane)
 {
 	constexpr int W = C / 16;
 	int32_t fnext[R];
@@ -102,11 +103,15 @@ __device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32
 				for (int q = 0; q < R; ++q) {
 					const int c = i - q;
 					if (c < 0 || c >= C) continue;
-					const uint32_t f = __builtin_amdgcn_ubfe(tab[c], sh[q], 6);
-					const int32_t dg = (int32_t)(f << 3) + cd[q];
-					const int32_t up = hup[c] + upc;
+					int32_t dg;
+					if constexpr (WIDE) {      /* i >= 32: 6-bit counts, gain = 8*sv + 2 */
+						const uint32_t f = __builtin_amdgcn_ubfe(tab[c], sh[q], 6);
+						dg = (int32_t)(f << 3) + cd[q] + 2;
+					} else {                   /* pre-scaled byte 8*sv + 2 */
+						dg = cd[q] + (int32_t)__builtin_amdgcn_ubfe(tab[c], sh[q], 8);
+					}
 					const int32_t lf = cl[q] + leftc[c];
-					int32_t h = min(min(dg, up), lf);
+					int32_t h = max(max(dg, hup[c]), lf);
 					acc[q][c / 16] = __builtin_amdgcn_alignbit((uint32_t)h, acc[q][c / 16], 2);
 					cd[q] = hup[c];
 					h &= ~3;
@@ -129,7 +134,7 @@ __device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32
 	}
 }
 
-template <int C, int R, int TR>
+template <int C, int R, int TR, bool WIDE>
 __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
                                                     const FillJob *__restrict__ jobs,
                                                     const TileRef *__restrict__ tiles)
@@ -149,11 +154,10 @@ __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
 	const int s = tr.s;
 	const int T0 = tr.a * TR;
 	const int L = s * kLanes + lane;
-	const int upc = J.upc;
 
 	/* ---- stage the tile inputs in LDS ------------------------------------------------ */
 	if (s == 0) {
-		const int lm = J.leftmul;                 /* border column: cost[r][0] = leftmul * r */
+		const int lm = J.leftmul;                 /* border column: X[r][0] = leftmul * r */
 		for (int e = lane; e < R * TR; e += kLanes) feed[e] = lm * (R * T0 + e + 1);
 	} else {
 		/* value after step T-1 of row q sits at index R*T + q */
@@ -175,10 +179,11 @@ __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
 	int32_t diag_in, last[R];
 	{
 		const uint32_t *ct = reinterpret_cast<const uint32_t *>(arena + J.coltab) + (size_t)L * C;
+		const int32_t *lc = reinterpret_cast<const int32_t *>(arena + J.leftc) + (size_t)L * C;
 #pragma unroll
 		for (int c = 0; c < C; ++c) {
 			tab[c] = ct[c];
-			leftc[c] = (int32_t)(((tab[c] >> 24) & 63u) << 2) + 1;
+			leftc[c] = lc[c];
 		}
 	}
 	int32_t *st = reinterpret_cast<int32_t *>(arena + J.state) + (size_t)s * (C + 1 + R) * kLanes + lane;
@@ -203,9 +208,9 @@ __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
 	const int r0s = T0 - L;                           /* step-units row index of this lane at local step 0 */
 
 	if (tr.first)
-		fill_steps<C, R, TR, true>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, upc, lane);
+		fill_steps<C, R, TR, WIDE, true>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, lane);
 	else
-		fill_steps<C, R, TR, false>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, upc, lane);
+		fill_steps<C, R, TR, WIDE, false>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, lane);
 
 #pragma unroll
 	for (int c = 0; c < C; ++c) st[c * kLanes] = hup[c];
@@ -383,30 +388,31 @@ hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long lo
 /* ---- launch wrappers (host) ----------------------------------------------------------- */
 
 template <int C, int R, int TR>
-static hipError_t launch_fill_t(uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+static hipError_t launch_fill_t(bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
 {
-	hipLaunchKernelGGL((nw_fill_tiles<C, R, TR>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	if (wide) hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, true>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	else hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, false>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
 	return hipGetLastError();
 }
 
 template <int C, int R>
-static hipError_t launch_fill_r(int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+static hipError_t launch_fill_r(int TR, bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
 {
-	if (TR == 64) return launch_fill_t<C, R, 64>(arena, jobs, tiles, ntiles, st);
-	if (TR == 128) return launch_fill_t<C, R, 128>(arena, jobs, tiles, ntiles, st);
-	if (TR == 256) return launch_fill_t<C, R, 256>(arena, jobs, tiles, ntiles, st);
+	if (TR == 64) return launch_fill_t<C, R, 64>(wide, arena, jobs, tiles, ntiles, st);
+	if (TR == 128) return launch_fill_t<C, R, 128>(wide, arena, jobs, tiles, ntiles, st);
+	if (TR == 256) return launch_fill_t<C, R, 256>(wide, arena, jobs, tiles, ntiles, st);
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_fill(int C, int R, int TR, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles,
-                       hipStream_t st)
+hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles,
+                       int ntiles, hipStream_t st)
 {
 	if (ntiles <= 0) return hipSuccess;
-	if (C == 16 && R == 1) return launch_fill_r<16, 1>(TR, arena, jobs, tiles, ntiles, st);
-	if (C == 16 && R == 2) return launch_fill_r<16, 2>(TR, arena, jobs, tiles, ntiles, st);
-	if (C == 16 && R == 4) return launch_fill_r<16, 4>(TR, arena, jobs, tiles, ntiles, st);
-	if (C == 32 && R == 1) return launch_fill_r<32, 1>(TR, arena, jobs, tiles, ntiles, st);
-	if (C == 32 && R == 2) return launch_fill_r<32, 2>(TR, arena, jobs, tiles, ntiles, st);
+	if (C == 16 && R == 1) return launch_fill_r<16, 1>(TR, wide, arena, jobs, tiles, ntiles, st);
+	if (C == 16 && R == 2) return launch_fill_r<16, 2>(TR, wide, arena, jobs, tiles, ntiles, st);
+	if (C == 16 && R == 4) return launch_fill_r<16, 4>(TR, wide, arena, jobs, tiles, ntiles, st);
+	if (C == 32 && R == 1) return launch_fill_r<32, 1>(TR, wide, arena, jobs, tiles, ntiles, st);
+	if (C == 32 && R == 2) return launch_fill_r<32, 2>(TR, wide, arena, jobs, tiles, ntiles, st);
 	return hipErrorInvalidValue;
 }
 

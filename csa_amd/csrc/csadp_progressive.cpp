@@ -139,22 +139,25 @@ bool Progressive::next_fill()
 	return false;
 }
 
-void Progressive::write_tables(uint32_t *coltab, int ncols_pad, uint8_t *rowshift, int32_t *top) const
+void Progressive::write_tables(uint32_t *coltab, int32_t *leftc, int ncols_pad, uint8_t *rowshift, int32_t *top,
+                               bool wide) const
 {
 	const int i = step_;
 	const int ncols = consensus_;
 	for (int k = 1; k <= ncols; ++k) {
 		const int *col = &sv_[(size_t)k * kSym];
 		uint32_t w = 0;
-		for (int c = 0; c < 4; ++c) w |= (uint32_t)((i - col[c]) & 63) << (6 * c);
-		w |= (uint32_t)((i - col[kGap]) & 63) << 24;
+		for (int c = 0; c < 4; ++c)
+			w |= wide ? (uint32_t)(col[c] & 63) << (6 * c) : (uint32_t)((8 * col[c] + 2) & 255) << (8 * c);
 		coltab[k - 1] = w;
+		leftc[k - 1] = 4 * (col[kGap] - i) + 1;
 	}
-	for (int k = ncols; k < ncols_pad; ++k) coltab[k] = 0;
+	for (int k = ncols; k < ncols_pad; ++k) { coltab[k] = 0; leftc[k] = 0; }
 	const int n = order_[step_];
 	const int start = starts_[n];
-	for (int j = 0; j < nrows_; ++j) rowshift[j] = (uint8_t)(6 * code_of(char_at(start + j, n)));
-	for (int k = 0; k <= ncols; ++k) top[k] = -4 * border_top_[k];
+	const int width = wide ? 6 : 8;
+	for (int j = 0; j < nrows_; ++j) rowshift[j] = (uint8_t)(width * code_of(char_at(start + j, n)));
+	for (int k = 0; k <= ncols; ++k) top[k] = 4 * border_top_[k];
 	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
 }
 

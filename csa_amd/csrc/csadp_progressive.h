@@ -33,11 +33,12 @@ public:
 	int border_i() const { return border_i_; }     /* i in force when the borders were last refreshed */
 	bool stale_borders() const { return stale_; }
 
-	/* Device-format inputs of the pending fill (layouts: csadp_device.h).
-	 *   coltab[0..ncols_pad)      packed profile fields, zero beyond ncols
-	 *   rowshift[0..nrows)        6*code of each row letter
-	 *   top[0..ncols_pad]         cost of border row 0 = -4*H[0][k]; beyond ncols: last value */
-	void write_tables(uint32_t *coltab, int ncols_pad, uint8_t *rowshift, int32_t *top) const;
+	/* Device-format inputs of the pending fill (gain form, csadp_device.h).
+	 *   coltab[0..ncols_pad)      diag gains: bytes 8*sv[c]+2 (narrow) or 6-bit sv[c] (wide); 0 beyond ncols
+	 *   leftc[0..ncols_pad)       left gain 4*(sv[4]-i)+1; 0 beyond ncols
+	 *   rowshift[0..nrows)        bfe offset of each row letter: 8*code (narrow) / 6*code (wide)
+	 *   top[0..ncols_pad]         X of border row 0 = 4*H[0][k]; beyond ncols: last value */
+	void write_tables(uint32_t *coltab, int32_t *leftc, int ncols_pad, uint8_t *rowshift, int32_t *top, bool wide) const;
 
 	/* Apply the GPU traceback of the pending fill: ops in walk order (DIR_* codes, from cell
 	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border.

@@ -22,7 +22,7 @@ extern "C" {
  *   sv[(ncols+1)*5]   profile counts (column 0 unused), nprev = loop variable i
  *   rowcodes[nrows]   0..3
  *   top[ncols+1]      border row 0 as last refreshed, left_i: H[j][0] = -left_i*j
- * outputs: ops[] = direction codes (0 'D', 1 'L', 2 'U') of the walk from (nrows,ncols)
+ * outputs: ops[] = direction codes (2 'D', 1 'L', 0 'U') of the walk from (nrows,ncols)
  * until a border is hit, *nops, rows/columns left (*remj,*remk), *score = H[nrows][ncols].
  */
 typedef int (*csadp_debug_fill_fn)(void *user, int nrows, int ncols, int nprev, const int *sv,

@@ -209,14 +209,14 @@ def oracle_filler():
         while j > 0 and k > 0:
             d = raw[j * pitch + k]
             if d == 68:      # 'D'
-                ops[n] = 0
+                ops[n] = 2
                 j -= 1
                 k -= 1
             elif d == 76:    # 'L'
                 ops[n] = 1
                 k -= 1
             else:            # 'U'
-                ops[n] = 2
+                ops[n] = 0
                 j -= 1
             n += 1
         nops[0] = n

@@ -230,3 +230,19 @@ def test_config5_mixed_lengths_sample():
         if len(t[0][0]) <= 6000:
             cons, strs, st = oracle_progressive(t[0], t[1])
             assert g["aligned"] == strs and g["score"] == st.last_score
+
+
+@pytest.mark.parametrize("nseq", [33, 40, 64])
+def test_wide_profile_more_than_32_sequences(nseq):
+    """i >= 32 switches the batch to the 6-bit-count table format (csadp_device.h); 64 is the
+    reference's MAXNUMBEROFSEQS (csamsa.c:23)."""
+    r = rng(1000 + nseq)
+    fam = random_family(r, nseq, 150, mut=0.08, indel=0.05)
+    rots = [r.randrange(len(f)) for f in fam]
+    small = random_family(r, 3, 400)
+    got = csa_amd.align_batch([(fam, rots, None, None), (small, None, None, None)])
+    for task, g in zip([(fam, rots), (small, None)], got):
+        cons, strs, st = oracle_progressive(task[0], task[1])
+        assert g["status"] == 0 and g["consensus"] == cons
+        assert g["aligned"] == strs
+        assert g["score"] == st.last_score and g["fills"] == st.fills

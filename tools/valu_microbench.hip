@@ -124,6 +124,64 @@ __global__ void k_clockprobe(unsigned long long *out, int seed, int iters) {
 	if (a0 + a1 + a2 + a3 == 0x7fffffff) out[0] = 0;
 }
 
+// the fill kernel's cell recurrence (gain form, R = 2 rows x C = 16 columns per step) with
+// registers only: how many issue cycles per 64 cells does the instruction MIX sustain?
+__global__ void k_cellmix(int *out, const unsigned *in, int iters) {
+	unsigned tab[16]; int leftc[16], hup[16];
+	for (int c = 0; c < 16; ++c) { tab[c] = in[threadIdx.x * 16 + c]; leftc[c] = (int)(in[c] & 31) - 40; hup[c] = c * 4; }
+	int last0 = 0, last1 = 4, diag_in = 0;
+	unsigned acc0 = 0, acc1 = 0, sh0 = (in[3] & 3) * 8, sh1 = (in[5] & 3) * 8;
+	for (int t = 0; t < iters; ++t) {
+		int cd0 = diag_in, cd1 = last0, cl0 = last0 + t, cl1 = last1 + t;
+		diag_in = cl1;
+#pragma unroll
+		for (int i = 0; i < 17; ++i) {
+#pragma unroll
+			for (int q = 0; q < 2; ++q) {
+				const int c = i - q;
+				if (c < 0 || c >= 16) continue;
+				int &cd = q ? cd1 : cd0; int &cl = q ? cl1 : cl0; unsigned &acc = q ? acc1 : acc0;
+				const int dg = cd + (int)__builtin_amdgcn_ubfe(tab[c], q ? sh1 : sh0, 8);
+				const int lf = cl + leftc[c];
+				int h = max(max(dg, hup[c]), lf);
+				acc = __builtin_amdgcn_alignbit((unsigned)h, acc, 2);
+				cd = hup[c];
+				h &= ~3;
+				hup[c] = h; cl = h;
+			}
+		}
+		last0 = cl0; last1 = cl1;
+		sh0 = (sh0 + (acc0 & 8)) & 24; sh1 = (sh1 + (acc1 & 8)) & 24;
+	}
+	int sum = last0 + last1 + (int)acc0 + (int)acc1;
+	for (int c = 0; c < 16; ++c) sum += hup[c];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = sum;
+}
+
+// does a full-rate op keep its 2-cycle issue when it sits between half-rate ops?
+// 12 independent ops per iteration on 12 accumulators, in different orders
+#define ORDER_KERNEL(NAME, BODY)                                                                      \
+__global__ void k_order_##NAME(int *out, int seed, int iters) {                                       \
+	int a0 = seed + threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13,      \
+	    a6 = a0 * 17, a7 = a0 * 19, a8 = a0 * 23, a9 = a0 * 29, a10 = a0 * 31, a11 = a0 * 37;           \
+	int b = seed * 31 + 6, c = seed | 3;                                                               \
+	for (int t = 0; t < iters; ++t) {                                                                  \
+		asm volatile(BODY BODY BODY BODY : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6),  \
+		             "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), "+v"(a11) : "v"(b), "v"(c));                  \
+	}                                                                                                  \
+	if (a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + a8 + a9 + a10 + a11 == 0x7fffffff) out[0] = a0;        \
+}
+#define H1(r) "v_max3_i32 " r ", " r ", %12, %13\n"
+#define H2(r) "v_bfe_u32 " r ", " r ", %12, 8\n"
+#define H3(r) "v_alignbit_b32 " r ", " r ", %12, 2\n"
+#define F1(r) "v_add_u32 " r ", %12, " r "\n"
+#define F2(r) "v_and_b32 " r ", %12, " r "\n"
+ORDER_KERNEL(alt, H2("%0") F1("%1") H1("%2") F1("%3") H3("%4") F2("%5") H2("%6") F1("%7") H1("%8") F1("%9") H3("%10") F2("%11"))
+ORDER_KERNEL(grp, H2("%0") H1("%2") H3("%4") H2("%6") H1("%8") H3("%10") F1("%1") F1("%3") F2("%5") F1("%7") F1("%9") F2("%11"))
+ORDER_KERNEL(pair, H2("%0") H1("%2") F1("%1") F1("%3") H3("%4") H2("%6") F2("%5") F1("%7") H1("%8") H3("%10") F1("%9") F2("%11"))
+ORDER_KERNEL(allf, F1("%0") F1("%1") F2("%2") F1("%3") F1("%4") F2("%5") F1("%6") F1("%7") F2("%8") F1("%9") F1("%10") F2("%11"))
+ORDER_KERNEL(allh, H2("%0") H1("%1") H3("%2") H2("%3") H1("%4") H3("%5") H2("%6") H1("%7") H3("%8") H2("%9") H1("%10") H3("%11"))
+
 typedef void (*kern_t)(int *, int, int);
 
 static void run(const char *name, kern_t k, int ncu, double ghz_hint)
@@ -167,6 +225,53 @@ int main()
 	const int ncu = p.multiProcessorCount;
 	const double ghz = p.clockRate / 1e6;
 	printf("device %s CUs %d clock %.2f GHz; numbers = time per wave64 instruction per SIMD\n", p.gcnArchName, ncu, ghz);
+	{
+		// cell-mix: blocks of 64*4*wps threads, one block per CU (LDS-pinned)
+		int *o; unsigned *inp;
+		CHECK(hipMalloc(&o, 256 * 2048 * sizeof(int)));
+		CHECK(hipMalloc(&inp, 2048 * 16 * sizeof(unsigned)));
+		CHECK(hipMemset(inp, 0x5a, 2048 * 16 * sizeof(unsigned)));
+		hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+		CHECK(hipFuncSetAttribute((const void *)k_cellmix, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+		for (int wps = 1; wps <= 4; wps *= 2) {
+			const int iters = 20000;
+			const int tpb = 64 * 4 * wps;
+			hipLaunchKernelGGL(k_cellmix, dim3(ncu), dim3(tpb), 100 * 1024, 0, o, inp, iters);
+			CHECK(hipDeviceSynchronize());
+			CHECK(hipEventRecord(e0));
+			hipLaunchKernelGGL(k_cellmix, dim3(ncu), dim3(tpb), 100 * 1024, 0, o, inp, iters);
+			CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+			float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+			const double cellwaves_per_simd = (double)iters * 32 * wps;    // 32 cells per step per wave
+			printf("cellmix (6 ops/cell, 2 chains) %d waves/SIMD: %.2f ns per 64 cells per SIMD = %.1f cyc@2.4GHz -> chip %.2f TCUPS\n",
+			       wps, ms * 1e6 / cellwaves_per_simd, ms * 1e6 / cellwaves_per_simd * 2.4,
+			       (double)iters * 32 * 64 * wps * 4 * ncu / (ms * 1e-3) / 1e12);
+		}
+		CHECK(hipFree(o)); CHECK(hipFree(inp));
+	}
+	{
+		int *o; CHECK(hipMalloc(&o, 64));
+		hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+		struct { const char *name; void (*k)(int *, int, int); } orders[] = {
+			{"alternating H F H F..", k_order_alt}, {"grouped 6H then 6F   ", k_order_grp}, {"pairs HH FF HH FF    ", k_order_pair},
+			{"12 full-rate         ", k_order_allf}, {"12 half-rate         ", k_order_allh}};
+		for (auto &od : orders) {
+			CHECK(hipFuncSetAttribute((const void *)od.k, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+			printf("order %s:", od.name);
+			for (int wps = 1; wps <= 4; wps *= 2) {
+				const int iters = 50000;
+				hipLaunchKernelGGL(od.k, dim3(ncu), dim3(64 * 4 * wps), 100 * 1024, 0, o, 1, iters);
+				CHECK(hipDeviceSynchronize());
+				CHECK(hipEventRecord(e0));
+				hipLaunchKernelGGL(od.k, dim3(ncu), dim3(64 * 4 * wps), 100 * 1024, 0, o, 1, iters);
+				CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+				float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+				printf("  w%d %.2f cyc/instr", wps, ms * 1e6 / ((double)iters * 48 * wps) * 2.4);
+			}
+			printf("   (6 half-rate + 6 full-rate per 12; ideal 3.0)\n");
+		}
+		CHECK(hipFree(o));
+	}
 	{
 		unsigned long long *d, h[2 * 2048];
 		CHECK(hipMalloc(&d, sizeof(h)));
