@@ -24,19 +24,21 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU issue roofline of the fill kernel (gain form, csadp_device.h): 6 VALU instructions per
-# cell -- v_bfe_u32, v_max3_i32, v_alignbit_b32 (half rate: 4 issue cycles per wave64
-# instruction per SIMD) and v_add_u32 x2, v_and_b32 (full rate: 2 cycles), measured one kind at
-# a time by tools/valu_microbench.hip (profiles/r01_valu_microbench.txt).  Priced one by one
-# that is 3*4 + 3*2 = 18 issue cycles per 64 cells per SIMD -> 8.7 TCUPS at 2.4 GHz: the
-# `peak` below.  The same microbenchmark shows that in a MIXED stream every instruction costs
-# ~4.2-4.4 cycles whatever the order ("order ..." and "cellmix" lines): this exact 6-op
-# recurrence, registers only, no memory, sustains 25.0 cycles per 64 cells = 6.3 TCUPS per
-# GPU -- reported as `mix_ceiling`.
-VALU_OPS_PER_CELL = 6
-VALU_ISSUE_CYCLES_PER_CELL_WAVE = 18
-VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9     # 8.74e12 cells/s
-VALU_MIX_CEILING_CUPS = 6.30e12       # cellmix microbenchmark, 4 waves per SIMD
+# VALU issue roofline of the fill kernel.  The benchmarked path is the packed-16 pair kernel
+# (nw_fill_tiles_pk): 8 VALU instructions per 2 cells -- v_perm_b32, v_pk_add_i16 x2,
+# v_pk_max_i16 x2, v_lshl_add_u32 (half rate: 4 issue cycles per wave64 instruction per SIMD
+# when measured one kind at a time) and v_and_b32 x2 (full rate: 2) -- tools/valu_microbench.hip,
+# profiles/r01_valu_microbench.txt.  Priced one by one that is 6*4 + 2*2 = 28 issue cycles per
+# 128 cells per SIMD -> 11.2 TCUPS at 2.4 GHz: `peak`.  The same microbenchmark runs this exact
+# recurrence in registers only (no memory, no tile hand-off): 12.4 TCUPS at 4 waves per SIMD,
+# 11.7 at 2 -- reported as `mix_ceiling` (the kernel is capped at 3 waves per SIMD by its 138
+# VGPRs).  The 32-bit kernel (N > 2, CSADP_PK16=0): 6 instructions per cell, 8.7 / 6.3 TCUPS.
+PK16 = os.environ.get("CSADP_PK16", "1") != "0"
+VALU_OPS_PER_CELL = 4 if PK16 else 6
+VALU_ISSUE_CYCLES_PER_CELL_WAVE = 14 if PK16 else 18
+VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9
+VALU_MIX_CEILING_CUPS = 12.36e12 if PK16 else 6.30e12       # cellmix16 / cellmix microbenchmark, 4 waves per SIMD
+FILL_KERNEL = "nw_fill_tiles_pk" if PK16 else "nw_fill_tiles"
 
 
 def pmc_traffic_per_launch():
@@ -44,7 +46,7 @@ def pmc_traffic_per_launch():
     FETCH_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md), or None."""
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            k = json.load(f)["nw_fill_tiles"]
+            k = json.load(f)[FILL_KERNEL]
         return int(k["hbm_write_bytes_per_launch"] + k["hbm_read_bytes_per_launch_x2_corrected"])
     except Exception:
         return None
@@ -176,7 +178,7 @@ def main():
             "host_boundary_ms": {"create_pack_upload": round(create_s * 1e3, 2), "fetch_download_strings": round(fetch_s * 1e3, 2),
                                  "pcie_inclusive_gcups": round(rank_cells / (create_s + fetch_s + tm["total_ms"] / 1e3) / 1e9, 1),
                                  "note": "not part of value: one batch from host buffers to host strings, unpipelined"},
-            "roofline": {"bound": "hbm", "kernel": "nw_fill_tiles",
+            "roofline": {"bound": "hbm", "kernel": FILL_KERNEL,
                          "achieved": round(eff_bytes_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(eff_bytes_s / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic_per_launch(),
@@ -194,8 +196,8 @@ def main():
                               "unit": "GCUPS", "frac": round(eff_cups / VALU_PEAK_CUPS, 4),
                               "mix_ceiling": round(VALU_MIX_CEILING_CUPS / 1e9, 1),
                               "frac_of_mix_ceiling": round(eff_cups / VALU_MIX_CEILING_CUPS, 4),
-                              "note": "peak = 1024 SIMDs x 64 cells / 18 issue cycles x 2.4 GHz with per-op issue rates "
-                                      "measured one kind at a time; mix_ceiling = the same 6-op recurrence in registers "
+                              "note": "peak = 1024 SIMDs x 64 cells / issue cycles x 2.4 GHz with per-op issue rates "
+                                      "measured one kind at a time; mix_ceiling = the same recurrence in registers "
                                       "only, as measured on this chip (profiles/r01_valu_microbench.txt)"},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:

@@ -134,7 +134,9 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	int rc = fb.layout();
 	if (rc != CSADP_OK) return rc;
 	parallel_for((int)active.size(), [&](int j) {
-		tasks[active[(size_t)j]].write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
+		Progressive &p = tasks[active[(size_t)j]];
+		if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.pk_leftc(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
+		else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 	});
 	if ((rc = fb.upload()) != CSADP_OK) return rc;
 	if ((rc = fb.run()) != CSADP_OK) return rc;
@@ -219,8 +221,10 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
 		parallel_for((int)b->active.size(), [&](int j) {
-			bp->tasks[(size_t)bp->active[(size_t)j]].write_tables(bp->fb.coltab(j), bp->fb.leftc(j), bp->fb.ncols_pad(j),
-			                                                    bp->fb.rowshift(j), bp->fb.top(j), bp->fb.wide());
+			Progressive &p = bp->tasks[(size_t)bp->active[(size_t)j]];
+			FillBatch &fb = bp->fb;
+			if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.pk_leftc(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
+			else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 		});
 		if ((rc = b->fb.upload()) != CSADP_OK) return rc;
 		if ((rc = b->fb.sync()) != CSADP_OK) return rc;

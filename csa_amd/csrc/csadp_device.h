@@ -58,6 +58,37 @@ struct TileRef {
 	int32_t first;            /* 1 = first tile of this strip: start from the top border */
 };
 
+/*
+ * Packed-16 pair job: TWO pairwise fills (i = 1, fresh borders) share every register, the
+ * low half word carrying matrix A and the high half word matrix B (v_pk_add_i16 /
+ * v_pk_max_i16 process both at once: 8 VALU instructions per 2 cells).  Values are kept
+ * relative to a per-strip, per-matrix 32-bit base that is re-centred at every tile start;
+ * the Lipschitz bound of the recurrence (|dX| <= 8 per column, <= 12 per row for i = 1)
+ * keeps a wave's live values within +-11 k of it.  Geometry (strips, steps) is that of the
+ * larger of the two matrices; the smaller one computes unread cells beyond its edge.
+ */
+struct PairJob {
+	uint64_t tab[2];          /* u32 [ncols_pad] per matrix: bytes 8*sv[c]+2 (narrow table format)          */
+	uint64_t leftc;           /* u32 [ncols_pad] packed i16 pair: left gain 4*(sv[4]-i)+1 of A | B << 16     */
+	uint64_t rowsel;          /* u32 [padl + R*steps_pad + R*64] v_perm selector of row r at index padl+(r-1): */
+	                          /*     byte0 = letter of A, byte2 = 4 + letter of B, 0x0c (-> 0) elsewhere       */
+	uint64_t top[2];          /* i32 [ncols_pad + 1] X of border row 0 per matrix                             */
+	uint64_t handoff;         /* i32 [nstrips][hpitch][R][2] ABSOLUTE right-edge X after step T: index T+1    */
+	uint64_t state;           /* u32 [nstrips][C+1+R+2][64] packed lane registers + the two bases             */
+	uint64_t dirs;            /* u32 [nstrips][steps_pad][R][64][2]: word g of a lane = columns 8g..8g+7,      */
+	                          /*     8 codes of A in the low half, 8 codes of B in the high half, first column  */
+	                          /*     in the top bits of each half                                              */
+	uint64_t ops[2];          /* u8 traceback ops per matrix                                                   */
+	uint64_t summary[2];      /* i32 [4] per matrix                                                            */
+	int32_t nrows[2], ncols[2];
+	int32_t nrows_max, ncols_max;
+	int32_t nstrips;
+	int32_t steps_pad;
+	int32_t hpitch;
+	int32_t padl;             /* in rows: R*(64*nstrips + 64)                                                  */
+	int32_t leftmul[2];       /* X of border column 0 is leftmul * r (0 on fresh borders)                     */
+};
+
 }  // namespace csadp
 
 #endif

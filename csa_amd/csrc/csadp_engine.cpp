@@ -135,6 +135,11 @@ void FillBatch::clear()
 	extra_.clear();
 	tiles_.clear();
 	diag_off_.clear();
+	pjobs_.clear();
+	pextra_.clear();
+	pair_of_.clear();
+	half_of_.clear();
+	pk_ = false;
 	laid_out_ = false;
 	ran_ = false;
 }
@@ -161,6 +166,13 @@ int FillBatch::layout()
 	extra_.assign(nj, Extra());
 	cells_ = dir_bytes_ = border_bytes_ = 0;
 	wide_ = false;
+	pk_ = false;
+	if (nj >= 2 && C == 16 && env_int("CSADP_PK16", 1) != 0) {
+		pk_ = true;
+		for (const FillJob &J : jobs_)
+			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) pk_ = false;
+	}
+	if (pk_) return layout_pk();
 
 	/* geometry + tile schedule */
 	int ndiag = 0;
@@ -308,7 +320,208 @@ uint32_t *FillBatch::coltab(int j) { return reinterpret_cast<uint32_t *>(h_in_ +
 int32_t *FillBatch::leftc(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_leftc); }
 uint8_t *FillBatch::rowshift(int j) { return h_in_ + extra_[j].in_rowshift + jobs_[j].padl; }
 int32_t *FillBatch::top(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_top); }
-int FillBatch::ncols_pad(int j) const { return extra_[j].ncols_pad; }
+int FillBatch::ncols_pad(int j) const { return pk_ ? pextra_[(size_t)pair_of_[(size_t)j]].ncols_pad : extra_[j].ncols_pad; }
+
+/* Packed-16 pair mode: jobs sorted by size are paired (A = low half word, B = high half word);
+ * the pair uses the geometry of the larger matrix.  Same arena structure as layout(). */
+int FillBatch::layout_pk()
+{
+	Engine &E = Engine::get();
+	const int C = 16, R = E.R(), TR = E.TR();
+	const int nj = (int)jobs_.size();
+	std::vector<int> order((size_t)nj);
+	for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
+	std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+		if (jobs_[(size_t)a].ncols != jobs_[(size_t)b].ncols) return jobs_[(size_t)a].ncols > jobs_[(size_t)b].ncols;
+		return jobs_[(size_t)a].nrows > jobs_[(size_t)b].nrows;
+	});
+	const int np = (nj + 1) / 2;
+	pjobs_.assign((size_t)np, PairJob());
+	pextra_.assign((size_t)np, PairExtra());
+	pair_of_.assign((size_t)nj, 0);
+	half_of_.assign((size_t)nj, 0);
+	int ndiag = 0;
+	std::vector<int> diag_count;
+	for (int p = 0; p < np; ++p) {
+		PairJob &P = pjobs_[(size_t)p];
+		memset(&P, 0, sizeof(P));
+		PairExtra &X = pextra_[(size_t)p];
+		for (int h = 0; h < 2; ++h) {
+			const int idx = 2 * p + h;
+			X.job[h] = idx < nj ? order[(size_t)idx] : -1;
+			if (X.job[h] >= 0) {
+				const FillJob &J = jobs_[(size_t)X.job[h]];
+				if (4LL * (2LL * J.nrows + J.ncols) + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
+				P.nrows[h] = J.nrows;
+				P.ncols[h] = J.ncols;
+				P.leftmul[h] = J.leftmul;
+				pair_of_[(size_t)X.job[h]] = p;
+				half_of_[(size_t)X.job[h]] = h;
+				cells_ += (long long)J.nrows * J.ncols;
+				dir_bytes_ += (long long)J.nrows * (long long)((J.ncols + C - 1) / C) * 4;
+			}
+		}
+		P.nrows_max = std::max(P.nrows[0], P.nrows[1]);
+		P.ncols_max = std::max(P.ncols[0], P.ncols[1]);
+		const int lanes = (P.ncols_max + C - 1) / C;
+		P.nstrips = (lanes + kLanes - 1) / kLanes;
+		X.ncols_pad = P.nstrips * kLanes * C;
+		const int rsteps = (P.nrows_max + R - 1) / R;
+		P.steps_pad = (int)align_up((size_t)rsteps + (size_t)kLanes * P.nstrips, TR);
+		P.hpitch = P.steps_pad + 64;
+		P.padl = R * (kLanes * P.nstrips + 64);
+		for (int s = 0; s < P.nstrips; ++s) {
+			const int a0 = (kLanes * s) / TR;
+			const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
+			ndiag = std::max(ndiag, a1 + s + 1);
+			if ((int)diag_count.size() < a1 + s + 1) diag_count.resize((size_t)(a1 + s + 1), 0);
+			for (int a = a0; a <= a1; ++a) diag_count[(size_t)(a + s)]++;
+			border_bytes_ += 2LL * 8 * (a1 - a0 + 1) * TR * R + 2LL * 4 * (a1 - a0 + 1) * (C + 3 + R) * kLanes;
+		}
+	}
+	diag_off_.assign((size_t)ndiag + 1, 0);
+	for (int d = 0; d < ndiag; ++d) diag_off_[(size_t)d + 1] = diag_off_[(size_t)d] + (size_t)diag_count[(size_t)d];
+	tiles_.assign(diag_off_[(size_t)ndiag], TileRef());
+	{
+		std::vector<size_t> cur(diag_off_.begin(), diag_off_.end() - 1);
+		for (int p = 0; p < np; ++p) {
+			const PairJob &P = pjobs_[(size_t)p];
+			const int rsteps = (P.nrows_max + R - 1) / R;
+			for (int s = 0; s < P.nstrips; ++s) {
+				const int a0 = (kLanes * s) / TR;
+				const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
+				for (int a = a0; a <= a1; ++a) {
+					TileRef t;
+					t.job = p;
+					t.a = a;
+					t.s = s;
+					t.first = (a == a0);
+					tiles_[cur[(size_t)(a + s)]++] = t;
+				}
+			}
+		}
+	}
+
+	nslots_ = pipelined_ ? E.slots() : 1;
+	next_slot_ = 0;
+	size_t off = 0;
+	for (int sl = 0; sl < nslots_; ++sl) {
+		jobs_off_[sl] = off;
+		off = align_up(off + (size_t)np * sizeof(PairJob), 256);
+	}
+	tiles_off_ = off;
+	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
+	for (int p = 0; p < np; ++p) {
+		PairJob &P = pjobs_[(size_t)p];
+		PairExtra &X = pextra_[(size_t)p];
+		for (int h = 0; h < 2; ++h) {
+			X.in_tab[h] = P.tab[h] = off;
+			off = align_up(off + (size_t)X.ncols_pad * 4, 256);
+		}
+		X.in_leftc = P.leftc = off;
+		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
+		X.in_rowsel = P.rowsel = off;
+		off = align_up(off + ((size_t)P.padl + (size_t)R * P.steps_pad + (size_t)R * 64 + 64) * 4, 256);
+		for (int h = 0; h < 2; ++h) {
+			X.in_top[h] = P.top[h] = off;
+			off = align_up(off + ((size_t)X.ncols_pad + 1) * 4, 256);
+		}
+	}
+	in_bytes_ = off;
+	std::vector<std::vector<PairJob>> slot_jobs((size_t)nslots_, pjobs_);
+	for (int sl = 0; sl < nslots_; ++sl) {
+		res_off_[sl] = off;
+		for (int j = 0; j < nj; ++j) {
+			const FillJob &J = jobs_[(size_t)j];
+			Extra &X = extra_[(size_t)j];
+			PairJob &P = slot_jobs[(size_t)sl][(size_t)pair_of_[(size_t)j]];
+			const int h = half_of_[(size_t)j];
+			P.summary[h] = off;
+			X.res_summary = off - res_off_[sl];
+			off += 64;
+			P.ops[h] = off;
+			X.res_ops = off - res_off_[sl];
+			off = align_up(off + (size_t)J.nrows + J.ncols + 64, 256);
+		}
+		const size_t dummy = off;                 /* unpaired high half: nothing to trace, summary goes here */
+		off += 256;
+		res_bytes_ = off - res_off_[sl];
+		for (int p = 0; p < np; ++p) {
+			PairJob &P = slot_jobs[(size_t)sl][(size_t)p];
+			if (pextra_[(size_t)p].job[1] < 0) { P.summary[1] = dummy; P.ops[1] = dummy + 64; }
+			P.state = off;
+			off = align_up(off + (size_t)P.nstrips * (C + 3 + R) * kLanes * 4, 256);
+			P.handoff = off;
+			off = align_up(off + (size_t)P.nstrips * P.hpitch * R * 8, 256);
+			P.dirs = off;
+			off = align_up(off + (size_t)P.nstrips * P.steps_pad * R * 2 * kLanes * 4, 256);
+		}
+	}
+	total_bytes_ = off;
+
+	if (total_bytes_ > arena_cap_) {
+		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
+		arena_ = E.take_arena(total_bytes_, &arena_cap_);
+	}
+	if (total_bytes_ > arena_cap_) {
+		E.drop_arena_cache();
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		if (total_bytes_ + (256u << 20) > free_b) {
+			fprintf(stderr, "csadp: batch needs %.1f GiB of HBM, %.1f GiB free\n",
+			        total_bytes_ / 1073741824.0, free_b / 1073741824.0);
+			return CSADP_ERR_RANGE;
+		}
+		HIP_TRY(hipMalloc((void **)&arena_, total_bytes_));
+		arena_cap_ = total_bytes_;
+	}
+	if (in_bytes_ > h_in_cap_) {
+		if (h_in_) (void)hipHostFree(h_in_);
+		h_in_ = nullptr;
+		HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
+		h_in_cap_ = in_bytes_;
+	}
+	if (res_bytes_ > h_res_cap_) {
+		if (h_res_) (void)hipHostFree(h_res_);
+		h_res_ = nullptr;
+		HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
+		h_res_cap_ = res_bytes_;
+	}
+	for (int sl = 0; sl < nslots_; ++sl)
+		for (auto &e : ev_[sl])
+			if (!e) HIP_TRY(hipEventCreate(&e));
+	memset(h_in_, 0, in_bytes_);
+	for (int p = 0; p < np; ++p) {                /* selector bytes default to 0x0c = constant zero byte */
+		const PairJob &P = pjobs_[(size_t)p];
+		memset(h_in_ + pextra_[(size_t)p].in_rowsel, 0x0c, ((size_t)P.padl + (size_t)R * P.steps_pad + (size_t)R * 64 + 64) * 4);
+	}
+	for (int sl = 0; sl < nslots_; ++sl)
+		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)np * sizeof(PairJob));
+	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
+	pjobs_ = slot_jobs[0];
+	laid_out_ = true;
+	ran_ = false;
+	return CSADP_OK;
+}
+
+uint32_t *FillBatch::pk_tab(int j)
+{
+	return reinterpret_cast<uint32_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_tab[half_of_[(size_t)j]]);
+}
+uint16_t *FillBatch::pk_leftc(int j)
+{
+	return reinterpret_cast<uint16_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_leftc) + half_of_[(size_t)j];
+}
+uint8_t *FillBatch::pk_rowsel(int j)
+{
+	const int p = pair_of_[(size_t)j];
+	return h_in_ + pextra_[(size_t)p].in_rowsel + (size_t)pjobs_[(size_t)p].padl * 4 + (half_of_[(size_t)j] ? 2 : 0);
+}
+int FillBatch::pk_selbase(int j) const { return half_of_[(size_t)j] ? 4 : 0; }
+int32_t *FillBatch::pk_top(int j)
+{
+	return reinterpret_cast<int32_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_top[half_of_[(size_t)j]]);
+}
 
 int FillBatch::upload()
 {
@@ -330,15 +543,18 @@ int FillBatch::run()
 	hipStream_t st = E.stream(sl);
 	hipEvent_t *ev = ev_[sl];
 	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]);
+	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]);
 	const TileRef *dtiles = reinterpret_cast<const TileRef *>(arena_ + tiles_off_);
 	HIP_TRY(hipEventRecord(ev[0], st));
 	const int ndiag = (int)diag_off_.size() - 1;
 	for (int d = 0; d < ndiag; ++d) {
 		const int cnt = (int)(diag_off_[d + 1] - diag_off_[d]);
-		HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, dtiles + diag_off_[d], cnt, st));
+		if (pk_) HIP_TRY(launch_fill_pk(E.R(), E.TR(), arena_, dpairs, dtiles + diag_off_[d], cnt, st));
+		else HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, dtiles + diag_off_[d], cnt, st));
 	}
 	HIP_TRY(hipEventRecord(ev[1], st));
-	HIP_TRY(launch_traceback(E.C(), E.R(), arena_, djobs, (int)jobs_.size(), st));
+	if (pk_) HIP_TRY(launch_traceback_pk(E.R(), arena_, dpairs, (int)pjobs_.size(), st));
+	else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, djobs, (int)jobs_.size(), st));
 	HIP_TRY(hipEventRecord(ev[2], st));
 	ran_ = true;
 	return CSADP_OK;

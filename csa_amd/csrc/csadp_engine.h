@@ -82,6 +82,14 @@ public:
 	uint32_t *coltab(int j);
 	int32_t *leftc(int j);
 	bool wide() const { return wide_; }   /* table format of this batch (csadp_device.h) */
+	/* packed-16 pair mode (PairJob): every job is pairwise (i = 1, fresh borders) and two jobs
+	 * share a register set.  Host tables then go through the *_pk accessors. */
+	bool packed() const { return pk_; }
+	uint32_t *pk_tab(int j);
+	uint16_t *pk_leftc(int j);         /* element stride 2 */
+	uint8_t *pk_rowsel(int j);         /* byte of row 1, element stride 4 */
+	int pk_selbase(int j) const;       /* 0 for the low half, 4 for the high half */
+	int32_t *pk_top(int j);
 	uint8_t *rowshift(int j);        /* points at row 1 (index padl) */
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
@@ -95,6 +103,12 @@ public:
 
 private:
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
+	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_leftc, in_rowsel, in_top[2]; };
+	int layout_pk();
+	std::vector<PairJob> pjobs_;
+	std::vector<PairExtra> pextra_;
+	std::vector<int> pair_of_, half_of_;
+	bool pk_ = false;
 	std::vector<FillJob> jobs_;
 	std::vector<Extra> extra_;
 	std::vector<TileRef> tiles_;

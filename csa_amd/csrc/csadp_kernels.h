@@ -17,6 +17,11 @@ hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const Fi
 /* Launch the direction walk: one wave per job. */
 hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st);
 
+/* Packed-16 pair mode (PairJob): C is fixed to 16 columns per lane. */
+hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles,
+                          hipStream_t st);
+hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int npairs, hipStream_t st);
+
 /* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;
  * chars = nseq x length bytes, sequence-major; out must be zeroed. */
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st);

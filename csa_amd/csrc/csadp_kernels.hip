@@ -343,6 +343,334 @@ __global__ __launch_bounds__(64) void nw_traceback(uint8_t *__restrict__ arena,
 	}
 }
 
+/* =========================================================================================
+ * Packed-16 pair mode (PairJob, csadp_device.h): the same skewed wavefront, two pairwise
+ * matrices per register.  Per 2 cells: v_perm_b32 (both diag gains in one byte permute),
+ * v_pk_add_i16 x2, v_pk_max_i16 x2, v_and (tags), v_lshl_add (pack 2 bits of both
+ * matrices), v_and (clear tags) = 8 VALU instructions.
+ * ========================================================================================= */
+
+typedef short pk16 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, (pk16)(__builtin_bit_cast(pk16, a) + __builtin_bit_cast(pk16, b)));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, (pk16)(__builtin_bit_cast(pk16, a) - __builtin_bit_cast(pk16, b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
+{
+	return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk16, a), __builtin_bit_cast(pk16, b)));
+}
+__device__ __forceinline__ uint32_t pk_pack(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int pk_lo(uint32_t v) { return (int)(short)(v & 0xffffu); }
+__device__ __forceinline__ int pk_hi(uint32_t v) { return (int)v >> 16; }
+
+constexpr int CP = 16;                 /* columns per lane in packed mode */
+
+template <int R, int TR, bool RAMP>
+__device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const uint32_t (&tabB)[CP],
+                                              const uint32_t (&leftc)[CP], uint32_t (&hup)[CP], uint32_t &diag_in,
+                                              uint32_t (&last)[R], const uint32_t *feed, const uint32_t *mysel,
+                                              uint32_t *edge, uint32_t *dirs, int r0s, int lane)
+{
+	uint32_t fnext[R], snext[R];
+	/* the tag mask is made opaque so that the compiler keeps "(acc << 2) + tags" as ONE
+	 * v_lshl_add_u32 instead of proving the operands disjoint and splitting it into shift + or */
+	uint32_t tagmask = 0x00030003u;
+	asm volatile("" : "+v"(tagmask));
+#pragma unroll
+	for (int q = 0; q < R; ++q) {
+		fnext[q] = feed[q];
+		snext[q] = mysel[q];
+	}
+#pragma unroll 2
+	for (int t = 0; t < TR; ++t) {
+		uint32_t inl[R], sel[R];
+		if (t > 0 && lane == kLanes - 1) {
+#pragma unroll
+			for (int q = 0; q < R; ++q) edge[(t - 1) * R + q] = last[q];
+		}
+#pragma unroll
+		for (int q = 0; q < R; ++q) {
+			sel[q] = snext[q];
+			inl[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)fnext[q], (int)last[q], DPP_WAVE_SHR1, 0xf, 0xf, false);
+		}
+#pragma unroll
+		for (int q = 0; q < R; ++q) {
+			fnext[q] = feed[(t + 1) * R + q];
+			snext[q] = mysel[(t + 1) * R + q];
+		}
+		uint32_t acc[R][2];
+#pragma unroll
+		for (int q = 0; q < R; ++q) acc[q][0] = acc[q][1] = 0;
+		if (!RAMP || r0s + t >= 0) {
+			uint32_t cd[R], cl[R];
+			cd[0] = diag_in;
+#pragma unroll
+			for (int q = 1; q < R; ++q) cd[q] = inl[q - 1];
+#pragma unroll
+			for (int q = 0; q < R; ++q) cl[q] = inl[q];
+#pragma unroll
+			for (int i = 0; i < CP + R - 1; ++i) {
+#pragma unroll
+				for (int q = 0; q < R; ++q) {
+					const int c = i - q;
+					if (c < 0 || c >= CP) continue;
+					const uint32_t g = __builtin_amdgcn_perm(tabB[c], tabA[c], sel[q]);   /* gain of A | gain of B << 16 */
+					const uint32_t dg = pk_add(cd[q], g);
+					const uint32_t lf = pk_add(cl[q], leftc[c]);
+					uint32_t h = pk_max(pk_max(dg, hup[c]), lf);
+					acc[q][c / 8] = (acc[q][c / 8] << 2) + (h & tagmask);       /* v_lshl_add_u32 */
+					cd[q] = hup[c];
+					h &= 0xfffcfffcu;
+					hup[c] = h;
+					cl[q] = h;
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < R; ++q) last[q] = cl[q];
+		}
+		diag_in = inl[R - 1];
+#pragma unroll
+		for (int q = 0; q < R; ++q)
+			*reinterpret_cast<uint2 *>(dirs + ((size_t)t * R + q) * (2 * kLanes)) = make_uint2(acc[q][0], acc[q][1]);
+	}
+	if (lane == kLanes - 1) {
+#pragma unroll
+		for (int q = 0; q < R; ++q) edge[(TR - 1) * R + q] = last[q];
+	}
+}
+
+template <int R, int TR>
+__global__ __launch_bounds__(64, 3) void nw_fill_tiles_pk(uint8_t *__restrict__ arena,
+                                                       const PairJob *__restrict__ jobs,
+                                                       const TileRef *__restrict__ tiles)
+{
+	constexpr int NST = CP + 1 + R + 2;                                        /* state words per lane */
+	__shared__ __attribute__((aligned(16))) uint32_t feed[R * (TR + 1) + 4];   /* lane-0 inputs (packed) */
+	__shared__ __attribute__((aligned(16))) uint32_t edge[R * TR];             /* lane-63 outputs        */
+	__shared__ __attribute__((aligned(16))) uint32_t selb[R * (TR + 64) + 16]; /* row selectors          */
+
+	const TileRef tr = tiles[blockIdx.x];
+	const PairJob &J = jobs[tr.job];
+	const int lane = threadIdx.x;
+	const int s = tr.s;
+	const int T0 = tr.a * TR;
+	const int L = s * kLanes + lane;
+
+	{
+		const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowsel) + (J.padl + R * (T0 - s * kLanes - 64));
+		for (int j = lane; j < R * (TR + 64); j += kLanes) selb[j] = src[j];
+	}
+
+	uint32_t tabA[CP], tabB[CP], leftc[CP], hup[CP];
+	uint32_t diag_in, last[R];
+	int32_t baseA, baseB;
+	{
+		const uint32_t *ta = reinterpret_cast<const uint32_t *>(arena + J.tab[0]) + (size_t)L * CP;
+		const uint32_t *tb = reinterpret_cast<const uint32_t *>(arena + J.tab[1]) + (size_t)L * CP;
+		const uint32_t *lc = reinterpret_cast<const uint32_t *>(arena + J.leftc) + (size_t)L * CP;
+#pragma unroll
+		for (int c = 0; c < CP; ++c) {
+			tabA[c] = ta[c];
+			tabB[c] = tb[c];
+			leftc[c] = lc[c];
+		}
+	}
+	uint32_t *st = reinterpret_cast<uint32_t *>(arena + J.state) + (size_t)s * NST * kLanes + lane;
+	if (tr.first) {
+		const int32_t *tpa = reinterpret_cast<const int32_t *>(arena + J.top[0]) + (size_t)L * CP;
+		const int32_t *tpb = reinterpret_cast<const int32_t *>(arena + J.top[1]) + (size_t)L * CP;
+		/* base of the strip = border value left of its first column (wave-uniform) */
+		baseA = reinterpret_cast<const int32_t *>(arena + J.top[0])[(size_t)s * kLanes * CP];
+		baseB = reinterpret_cast<const int32_t *>(arena + J.top[1])[(size_t)s * kLanes * CP];
+		diag_in = pk_pack(tpa[0] - baseA, tpb[0] - baseB);
+#pragma unroll
+		for (int c = 0; c < CP; ++c) hup[c] = pk_pack(tpa[c + 1] - baseA, tpb[c + 1] - baseB);
+#pragma unroll
+		for (int q = 0; q < R; ++q) last[q] = hup[CP - 1];
+	} else {
+#pragma unroll
+		for (int c = 0; c < CP; ++c) hup[c] = st[c * kLanes];
+		diag_in = st[CP * kLanes];
+#pragma unroll
+		for (int q = 0; q < R; ++q) last[q] = st[(CP + 1 + q) * kLanes];
+		baseA = (int32_t)st[(CP + 1 + R) * kLanes];
+		baseB = (int32_t)st[(CP + 2 + R) * kLanes];
+		/* re-centre: move both bases to the value held by the middle lane */
+		const uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)hup[CP / 2], kLanes / 2);
+		const int dA = pk_lo(rep) & ~3, dB = pk_hi(rep) & ~3;
+		const uint32_t delta = pk_pack(dA, dB);
+		baseA += dA;
+		baseB += dB;
+#pragma unroll
+		for (int c = 0; c < CP; ++c) hup[c] = pk_sub(hup[c], delta);
+		diag_in = pk_sub(diag_in, delta);
+#pragma unroll
+		for (int q = 0; q < R; ++q) last[q] = pk_sub(last[q], delta);
+	}
+	/* lane-0 inputs of this tile, converted from absolute X to this tile's bases */
+	if (s == 0) {
+		const int la = J.leftmul[0], lb = J.leftmul[1];
+		for (int e = lane; e < R * TR; e += kLanes) {
+			const int r = R * T0 + e + 1;
+			feed[e] = pk_pack(la * r - baseA, lb * r - baseB);
+		}
+	} else {
+		const int2 *h = reinterpret_cast<const int2 *>(arena + J.handoff) + ((size_t)(s - 1) * J.hpitch + T0) * R;
+		for (int e = lane; e < R * TR; e += kLanes) {
+			const int2 v = h[e];
+			feed[e] = pk_pack(v.x - baseA, v.y - baseB);
+		}
+	}
+	__syncthreads();
+
+	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (R * 2 * kLanes) + lane * 2;
+	const uint32_t *mysel = selb + R * (64 - lane);
+	const int r0s = T0 - L;
+
+	if (tr.first)
+		fill_steps_pk<R, TR, true>(tabA, tabB, leftc, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
+	else
+		fill_steps_pk<R, TR, false>(tabA, tabB, leftc, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
+
+#pragma unroll
+	for (int c = 0; c < CP; ++c) st[c * kLanes] = hup[c];
+	st[CP * kLanes] = diag_in;
+#pragma unroll
+	for (int q = 0; q < R; ++q) st[(CP + 1 + q) * kLanes] = last[q];
+	st[(CP + 1 + R) * kLanes] = (uint32_t)baseA;
+	st[(CP + 2 + R) * kLanes] = (uint32_t)baseB;
+	__syncthreads();
+	{
+		int2 *hand = reinterpret_cast<int2 *>(arena + J.handoff) + ((size_t)s * J.hpitch + T0 + 1) * R;
+		for (int e = lane; e < R * TR; e += kLanes) {
+			const uint32_t v = edge[e];
+			hand[e] = make_int2(pk_lo(v) + baseA, pk_hi(v) + baseB);
+		}
+	}
+}
+
+/* Traceback of one matrix of a pair job: blockIdx = 2*pair + half.  Same run-batched walk as
+ * nw_traceback; a word column covers 8 matrix columns, the window is 32 word columns wide. */
+template <int R>
+__global__ __launch_bounds__(64) void nw_traceback_pk(uint8_t *__restrict__ arena,
+                                                      const PairJob *__restrict__ jobs)
+{
+	constexpr int WQ = 32;
+	constexpr int RW = R * WQ;
+	constexpr int WT = 16384 / RW;
+	__shared__ __attribute__((aligned(16))) uint32_t win[WT * RW];
+
+	const PairJob &J = jobs[blockIdx.x >> 1];
+	const int half = blockIdx.x & 1;
+	uint8_t *ops = arena + J.ops[half];
+	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary[half]);
+	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
+	const int lane = threadIdx.x;
+	const size_t strip_words = (size_t)J.steps_pad * (R * 2 * kLanes);
+	const int qmax = J.nstrips * 2 * kLanes;
+	const int hshift = 16 * half;
+	int r = J.nrows[half], k = J.ncols[half];
+	int n = 0;
+
+	while (r > 0 && k > 0) {
+		const int q0 = (k - 1) >> 3;
+		const int Ttop = (r - 1) / R + (q0 >> 1);
+		const int qbase = (q0 & ~3) - 16;
+		constexpr int UNITS = WT * RW / 4;
+		constexpr int BATCH = 16;
+		for (int b0 = 0; b0 < UNITS / kLanes; b0 += BATCH) {
+			uint4 v[BATCH];
+#pragma unroll
+			for (int b = 0; b < BATCH; ++b) {
+				const int u = (b0 + b) * kLanes + lane;
+				const int i = u / (8 * R);
+				const int row = (u / 8) % R;
+				const int T = Ttop - i;
+				const int q = qbase - (((i * 2 * R) / (16 + R)) & ~3) + 4 * (u % 8);
+				v[b] = make_uint4(0, 0, 0, 0);
+				if (T >= 0 && q >= 0 && q < qmax)
+					v[b] = *reinterpret_cast<const uint4 *>(dirs + (size_t)(q >> 7) * strip_words +
+					                                        ((size_t)T * R + row) * (2 * kLanes) + (q & 127));
+			}
+#pragma unroll
+			for (int b = 0; b < BATCH; ++b)
+				reinterpret_cast<uint4 *>(win)[(b0 + b) * kLanes + lane] = v[b];
+		}
+		__syncthreads();
+		for (;;) {
+			const int ri = r - lane, ki = k - lane;
+			uint32_t code = 3;
+			if (ri > 0 && ki > 0) {
+				const int kc = ki - 1;
+				const int q = kc >> 3;
+				const int i = Ttop - ((ri - 1) / R + (q >> 1));
+				if (i >= 0 && i < WT) {
+					const int j = q - (qbase - (((i * 2 * R) / (16 + R)) & ~3));
+					if (j >= 0 && j < WQ) {
+						const uint32_t word = win[(i * R + (ri - 1) % R) * WQ + j];
+						code = (word >> (hshift + 2 * (7 - (kc & 7)))) & 3u;
+					}
+				}
+			}
+			const unsigned long long stop = __ballot(code != DIR_D);
+			const int run = stop ? __builtin_ctzll(stop) : kLanes;
+			if (run > 0) {
+				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+				n += run;
+				r -= run;
+				k -= run;
+				continue;
+			}
+			const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
+			if (c0 == 3) break;
+			if (lane == 0) ops[n] = (uint8_t)c0;
+			++n;
+			if (c0 == DIR_L) --k; else --r;
+		}
+		__syncthreads();
+	}
+	if (lane == 0) {
+		summary[0] = n;
+		summary[1] = r;
+		summary[2] = k;
+		summary[3] = 0;
+	}
+}
+
+template <int R>
+static hipError_t launch_fill_pk_r(int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+{
+	if (TR == 64) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 64>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	else if (TR == 128) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 128>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	else if (TR == 256) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 256>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
+hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+{
+	if (ntiles <= 0) return hipSuccess;
+	if (R == 1) return launch_fill_pk_r<1>(TR, arena, jobs, tiles, ntiles, st);
+	if (R == 2) return launch_fill_pk_r<2>(TR, arena, jobs, tiles, ntiles, st);
+	if (R == 4) return launch_fill_pk_r<4>(TR, arena, jobs, tiles, ntiles, st);
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int npairs, hipStream_t st)
+{
+	if (npairs <= 0) return hipSuccess;
+	if (R == 1) hipLaunchKernelGGL((nw_traceback_pk<1>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
+	else if (R == 2) hipLaunchKernelGGL((nw_traceback_pk<2>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
+	else if (R == 4) hipLaunchKernelGGL((nw_traceback_pk<4>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
+}
+
 /*
  * K3.  Column statistics of a finished alignment, tools.c:259-281 (CalculateSumOfPairsScore):
  * per column the number of gaps, whether all sequences carry the same character, and the

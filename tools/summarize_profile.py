@@ -28,7 +28,8 @@ def main():
         dur = collections.defaultdict(dict)
         for r in csv.DictReader(open(fn)):
             name = r["Kernel_Name"]
-            key = "nw_fill_tiles" if "nw_fill_tiles" in name else ("nw_traceback" if "nw_traceback" in name else "other")
+            key = ("nw_fill_tiles_pk" if "nw_fill_tiles_pk" in name else "nw_fill_tiles" if "nw_fill_tiles" in name else
+                   "nw_traceback_pk" if "nw_traceback_pk" in name else "nw_traceback" if "nw_traceback" in name else "other")
             agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[key].add(r["Dispatch_Id"])
             dur[key][r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])

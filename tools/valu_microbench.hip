@@ -182,6 +182,45 @@ ORDER_KERNEL(pair, H2("%0") H1("%2") F1("%1") F1("%3") H3("%4") H2("%6") F2("%5"
 ORDER_KERNEL(allf, F1("%0") F1("%1") F2("%2") F1("%3") F1("%4") F2("%5") F1("%6") F1("%7") F2("%8") F1("%9") F1("%10") F2("%11"))
 ORDER_KERNEL(allh, H2("%0") H1("%1") H3("%2") H2("%3") H1("%4") H3("%5") H2("%6") H1("%7") H3("%8") H2("%9") H1("%10") H3("%11"))
 
+// packed-16 variant of the cell recurrence: two independent matrices in the lo/hi halves of
+// every register (v_perm_b32 gain lookup, v_pk_add_i16 x2, v_pk_max_i16 x2, tag and/accumulate,
+// clean) = 8 ops per 2 cells; 2 chains (rows) per wave as in the real kernel
+__global__ void k_cellmix16(int *out, const unsigned *in, int iters) {
+	unsigned tabA[16], tabB[16], hup[16]; unsigned leftc = 0xfffdfffd;
+	for (int c = 0; c < 16; ++c) { tabA[c] = in[threadIdx.x * 16 + c]; tabB[c] = in[threadIdx.x * 16 + c + 7]; hup[c] = c * 4; }
+	unsigned last0 = 0, last1 = 4, diag_in = 0, acc0 = 0, acc1 = 0;
+	unsigned sel0 = 0x0c020c00u | (in[3] & 1), sel1 = 0x0c030c01u ^ (in[5] & 1);
+	for (int t = 0; t < iters; ++t) {
+		unsigned cd0 = diag_in, cd1 = last0, cl0 = last0 + t, cl1 = last1 + t;
+		diag_in = cl1;
+#pragma unroll
+		for (int i = 0; i < 17; ++i) {
+#pragma unroll
+			for (int q = 0; q < 2; ++q) {
+				const int c = i - q;
+				if (c < 0 || c >= 16) continue;
+				unsigned &cd = q ? cd1 : cd0; unsigned &cl = q ? cl1 : cl0; unsigned &acc = q ? acc1 : acc0;
+				unsigned g, dg, lf, m, h, tg;
+				asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(g) : "v"(tabA[c]), "v"(tabB[c]), "v"(q ? sel1 : sel0));
+				asm volatile("v_pk_add_i16 %0, %1, %2" : "=v"(dg) : "v"(cd), "v"(g));
+				asm volatile("v_pk_add_i16 %0, %1, %2" : "=v"(lf) : "v"(cl), "v"(leftc));
+				asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(m) : "v"(dg), "v"(hup[c]));
+				asm volatile("v_pk_max_i16 %0, %1, %2" : "=v"(h) : "v"(m), "v"(lf));
+				tg = h & 0x00030003u;
+				acc = (acc << 2) + tg;
+				cd = hup[c];
+				h &= 0xfffcfffcu;
+				hup[c] = h; cl = h;
+			}
+		}
+		last0 = cl0; last1 = cl1;
+		sel0 ^= (acc0 & 1); sel1 ^= (acc1 & 1);
+	}
+	unsigned sum = last0 + last1 + acc0 + acc1;
+	for (int c = 0; c < 16; ++c) sum += hup[c];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = (int)sum;
+}
+
 typedef void (*kern_t)(int *, int, int);
 
 static void run(const char *name, kern_t k, int ncu, double ghz_hint)
@@ -246,6 +285,21 @@ int main()
 			printf("cellmix (6 ops/cell, 2 chains) %d waves/SIMD: %.2f ns per 64 cells per SIMD = %.1f cyc@2.4GHz -> chip %.2f TCUPS\n",
 			       wps, ms * 1e6 / cellwaves_per_simd, ms * 1e6 / cellwaves_per_simd * 2.4,
 			       (double)iters * 32 * 64 * wps * 4 * ncu / (ms * 1e-3) / 1e12);
+		}
+		CHECK(hipFuncSetAttribute((const void *)k_cellmix16, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+		for (int wps = 1; wps <= 4; wps *= 2) {
+			const int iters = 20000;
+			const int tpb = 64 * 4 * wps;
+			hipLaunchKernelGGL(k_cellmix16, dim3(ncu), dim3(tpb), 100 * 1024, 0, o, inp, iters);
+			CHECK(hipDeviceSynchronize());
+			CHECK(hipEventRecord(e0));
+			hipLaunchKernelGGL(k_cellmix16, dim3(ncu), dim3(tpb), 100 * 1024, 0, o, inp, iters);
+			CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+			float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+			const double cellwaves_per_simd = (double)iters * 64 * wps;    // 2 matrices x 32 cells per step per wave
+			printf("cellmix16 (packed, 8 ops / 2 cells) %d waves/SIMD: %.2f ns per 64 cells per SIMD = %.1f cyc@2.4GHz -> chip %.2f TCUPS\n",
+			       wps, ms * 1e6 / cellwaves_per_simd, ms * 1e6 / cellwaves_per_simd * 2.4,
+			       (double)iters * 64 * 64 * wps * 4 * ncu / (ms * 1e-3) / 1e12);
 		}
 		CHECK(hipFree(o)); CHECK(hipFree(inp));
 	}
