@@ -91,8 +91,8 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
     ap.add_argument("--len", type=int, default=16384, dest="length")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -158,7 +158,8 @@ def main():
             "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, fill + traceback, whole job",
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int16" if PK16 else "int32",
             "data": "synthetic", "verified": bool(ok),
             "per_gpu_gcups": round(value / args.gpus, 3),
             "config": {"workload": "config 4 share: %d synthetic circular %d bp pairs per GPU "
@@ -183,13 +184,17 @@ def main():
                          "frac": round(eff_bytes_s / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic_per_launch(),
                          "bytes_per_launch": round(alg_bytes / launches),
-                         "avg_launch_us": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
-                         "avg_launch_us_alone": round(tm["fill_ms"] * 1e3 / launches, 2),
+                         "avg_launch_us": round(tm["fill_ms"] * 1e3 / launches, 2),
+                         "per_launch_achieved": round(alg_bytes / (tm["fill_ms"] * 1e-3) / 1e9, 1),
+                         "stream_us_per_launch_pipelined": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
                          "concurrent_streams": slots,
-                         "note": "algorithmic bytes = 0.25 B/cell directions + tile borders (SURVEY 8d). achieved = "
-                                 "algorithmic bytes of all timed passes / timed wall time (launches of consecutive "
-                                 "passes overlap on separate streams, so bytes_per_launch / avg_launch_us understates "
-                                 "it by the overlap). The binding roofline is integer VALU issue: roofline_valu"},
+                         "note": "algorithmic bytes = 0.25 B/cell directions + tile borders (SURVEY 8d). avg_launch_us = "
+                                 "HIP events around the 160 launches of one pass run alone on its stream (agrees with "
+                                 "rocprofv3 --stats AverageNs, profiles/r01_kernel_stats*.csv); per_launch_achieved = "
+                                 "bytes_per_launch / avg_launch_us. achieved = algorithmic bytes of all timed passes / "
+                                 "timed wall time: launches of consecutive passes overlap on `concurrent_streams` streams. "
+                                 "dtype: 16-bit lanes relative to exact int32 bases (results bit-exact). The binding "
+                                 "roofline is integer VALU issue: roofline_valu"},
             "roofline_valu": {"bound": "valu-issue", "ops_per_cell": VALU_OPS_PER_CELL,
                               "issue_cycles_per_64_cells": VALU_ISSUE_CYCLES_PER_CELL_WAVE,
                               "achieved": round(eff_cups / 1e9, 1), "peak": round(VALU_PEAK_CUPS / 1e9, 1),
