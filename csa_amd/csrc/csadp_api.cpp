@@ -135,7 +135,7 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	if (rc != CSADP_OK) return rc;
 	parallel_for((int)active.size(), [&](int j) {
 		Progressive &p = tasks[active[(size_t)j]];
-		if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.pk_leftc(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
+		if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 		else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 	});
 	if ((rc = fb.upload()) != CSADP_OK) return rc;
@@ -223,7 +223,7 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 		parallel_for((int)b->active.size(), [&](int j) {
 			Progressive &p = bp->tasks[(size_t)bp->active[(size_t)j]];
 			FillBatch &fb = bp->fb;
-			if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.pk_leftc(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
+			if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 			else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 		});
 		if ((rc = b->fb.upload()) != CSADP_OK) return rc;

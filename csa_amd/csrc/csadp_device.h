@@ -59,7 +59,8 @@ struct TileRef {
 };
 
 /*
- * Packed-16 pair job: TWO pairwise fills (i = 1, fresh borders) share every register, the
+ * Packed-16 pair job: TWO pairwise fills (i = 1, fresh borders, hence left gain -3 in every
+ * column) share every register, the
  * low half word carrying matrix A and the high half word matrix B (v_pk_add_i16 /
  * v_pk_max_i16 process both at once: 8 VALU instructions per 2 cells).  Values are kept
  * relative to a per-strip, per-matrix 32-bit base that is re-centred at every tile start;
@@ -69,7 +70,6 @@ struct TileRef {
  */
 struct PairJob {
 	uint64_t tab[2];          /* u32 [ncols_pad] per matrix: bytes 8*sv[c]+2 (narrow table format)          */
-	uint64_t leftc;           /* u32 [ncols_pad] packed i16 pair: left gain 4*(sv[4]-i)+1 of A | B << 16     */
 	uint64_t rowsel;          /* u32 [padl + R*steps_pad + R*64] v_perm selector of row r at index padl+(r-1): */
 	                          /*     byte0 = letter of A, byte2 = 4 + letter of B, 0x0c (-> 0) elsewhere       */
 	uint64_t top[2];          /* i32 [ncols_pad + 1] X of border row 0 per matrix                             */

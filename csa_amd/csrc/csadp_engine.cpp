@@ -167,7 +167,7 @@ int FillBatch::layout()
 	cells_ = dir_bytes_ = border_bytes_ = 0;
 	wide_ = false;
 	pk_ = false;
-	if (nj >= 2 && C == 16 && env_int("CSADP_PK16", 1) != 0) {
+	if (nj >= 2 && C == 16 && R <= 2 && env_int("CSADP_PK16", 1) != 0) {
 		pk_ = true;
 		for (const FillJob &J : jobs_)
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) pk_ = false;
@@ -418,8 +418,6 @@ int FillBatch::layout_pk()
 			X.in_tab[h] = P.tab[h] = off;
 			off = align_up(off + (size_t)X.ncols_pad * 4, 256);
 		}
-		X.in_leftc = P.leftc = off;
-		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
 		X.in_rowsel = P.rowsel = off;
 		off = align_up(off + ((size_t)P.padl + (size_t)R * P.steps_pad + (size_t)R * 64 + 64) * 4, 256);
 		for (int h = 0; h < 2; ++h) {
@@ -507,10 +505,6 @@ int FillBatch::layout_pk()
 uint32_t *FillBatch::pk_tab(int j)
 {
 	return reinterpret_cast<uint32_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_tab[half_of_[(size_t)j]]);
-}
-uint16_t *FillBatch::pk_leftc(int j)
-{
-	return reinterpret_cast<uint16_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_leftc) + half_of_[(size_t)j];
 }
 uint8_t *FillBatch::pk_rowsel(int j)
 {

@@ -86,7 +86,6 @@ public:
 	 * share a register set.  Host tables then go through the *_pk accessors. */
 	bool packed() const { return pk_; }
 	uint32_t *pk_tab(int j);
-	uint16_t *pk_leftc(int j);         /* element stride 2 */
 	uint8_t *pk_rowsel(int j);         /* byte of row 1, element stride 4 */
 	int pk_selbase(int j) const;       /* 0 for the low half, 4 for the high half */
 	int32_t *pk_top(int j);
@@ -103,7 +102,7 @@ public:
 
 private:
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
-	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_leftc, in_rowsel, in_top[2]; };
+	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
 	int layout_pk();
 	std::vector<PairJob> pjobs_;
 	std::vector<PairExtra> pextra_;

@@ -370,9 +370,13 @@ __device__ __forceinline__ int pk_hi(uint32_t v) { return (int)v >> 16; }
 
 constexpr int CP = 16;                 /* columns per lane in packed mode */
 
+/* left gain of a pairwise fill: the seed sequence carries no gaps, so 4*(sv[4]-i)+1 = -3 in
+ * every column of both matrices */
+constexpr uint32_t kLeftGainPk = 0xfffdfffdu;
+
 template <int R, int TR, bool RAMP>
 __device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const uint32_t (&tabB)[CP],
-                                              const uint32_t (&leftc)[CP], uint32_t (&hup)[CP], uint32_t &diag_in,
+                                              uint32_t (&hup)[CP], uint32_t &diag_in,
                                               uint32_t (&last)[R], const uint32_t *feed, const uint32_t *mysel,
                                               uint32_t *edge, uint32_t *dirs, int r0s, int lane)
 {
@@ -381,6 +385,7 @@ __device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const 
 	 * v_lshl_add_u32 instead of proving the operands disjoint and splitting it into shift + or */
 	uint32_t tagmask = 0x00030003u;
 	asm volatile("" : "+v"(tagmask));
+	const uint32_t leftgain = kLeftGainPk;
 #pragma unroll
 	for (int q = 0; q < R; ++q) {
 		fnext[q] = feed[q];
@@ -421,7 +426,7 @@ __device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const 
 					if (c < 0 || c >= CP) continue;
 					const uint32_t g = __builtin_amdgcn_perm(tabB[c], tabA[c], sel[q]);   /* gain of A | gain of B << 16 */
 					const uint32_t dg = pk_add(cd[q], g);
-					const uint32_t lf = pk_add(cl[q], leftc[c]);
+					const uint32_t lf = pk_add(cl[q], leftgain);
 					uint32_t h = pk_max(pk_max(dg, hup[c]), lf);
 					acc[q][c / 8] = (acc[q][c / 8] << 2) + (h & tagmask);       /* v_lshl_add_u32 */
 					cd[q] = hup[c];
@@ -445,7 +450,7 @@ __device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const 
 }
 
 template <int R, int TR>
-__global__ __launch_bounds__(64, 3) void nw_fill_tiles_pk(uint8_t *__restrict__ arena,
+__global__ __launch_bounds__(64, 4) void nw_fill_tiles_pk(uint8_t *__restrict__ arena,
                                                        const PairJob *__restrict__ jobs,
                                                        const TileRef *__restrict__ tiles)
 {
@@ -466,18 +471,16 @@ __global__ __launch_bounds__(64, 3) void nw_fill_tiles_pk(uint8_t *__restrict__ 
 		for (int j = lane; j < R * (TR + 64); j += kLanes) selb[j] = src[j];
 	}
 
-	uint32_t tabA[CP], tabB[CP], leftc[CP], hup[CP];
+	uint32_t tabA[CP], tabB[CP], hup[CP];
 	uint32_t diag_in, last[R];
 	int32_t baseA, baseB;
 	{
 		const uint32_t *ta = reinterpret_cast<const uint32_t *>(arena + J.tab[0]) + (size_t)L * CP;
 		const uint32_t *tb = reinterpret_cast<const uint32_t *>(arena + J.tab[1]) + (size_t)L * CP;
-		const uint32_t *lc = reinterpret_cast<const uint32_t *>(arena + J.leftc) + (size_t)L * CP;
 #pragma unroll
 		for (int c = 0; c < CP; ++c) {
 			tabA[c] = ta[c];
 			tabB[c] = tb[c];
-			leftc[c] = lc[c];
 		}
 	}
 	uint32_t *st = reinterpret_cast<uint32_t *>(arena + J.state) + (size_t)s * NST * kLanes + lane;
@@ -533,9 +536,9 @@ __global__ __launch_bounds__(64, 3) void nw_fill_tiles_pk(uint8_t *__restrict__ 
 	const int r0s = T0 - L;
 
 	if (tr.first)
-		fill_steps_pk<R, TR, true>(tabA, tabB, leftc, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
+		fill_steps_pk<R, TR, true>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
 	else
-		fill_steps_pk<R, TR, false>(tabA, tabB, leftc, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
+		fill_steps_pk<R, TR, false>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
 
 #pragma unroll
 	for (int c = 0; c < CP; ++c) st[c * kLanes] = hup[c];
@@ -657,7 +660,6 @@ hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, co
 	if (ntiles <= 0) return hipSuccess;
 	if (R == 1) return launch_fill_pk_r<1>(TR, arena, jobs, tiles, ntiles, st);
 	if (R == 2) return launch_fill_pk_r<2>(TR, arena, jobs, tiles, ntiles, st);
-	if (R == 4) return launch_fill_pk_r<4>(TR, arena, jobs, tiles, ntiles, st);
 	return hipErrorInvalidValue;
 }
 
@@ -666,7 +668,6 @@ hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int n
 	if (npairs <= 0) return hipSuccess;
 	if (R == 1) hipLaunchKernelGGL((nw_traceback_pk<1>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
 	else if (R == 2) hipLaunchKernelGGL((nw_traceback_pk<2>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
-	else if (R == 4) hipLaunchKernelGGL((nw_traceback_pk<4>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }

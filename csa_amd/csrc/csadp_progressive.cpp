@@ -161,17 +161,14 @@ void Progressive::write_tables(uint32_t *coltab, int32_t *leftc, int ncols_pad, 
 	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
 }
 
-void Progressive::write_tables_pk(uint32_t *tab, uint16_t *leftc, int ncols_pad, uint8_t *rowsel, int selbase,
-                                  int32_t *top) const
+void Progressive::write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel, int selbase, int32_t *top) const
 {
-	const int i = step_;
 	const int ncols = consensus_;
 	for (int k = 1; k <= ncols; ++k) {
 		const int *col = &sv_[(size_t)k * kSym];
 		uint32_t w = 0;
 		for (int c = 0; c < 4; ++c) w |= (uint32_t)((8 * col[c] + 2) & 255) << (8 * c);
 		tab[k - 1] = w;
-		leftc[2 * (size_t)(k - 1)] = (uint16_t)(int16_t)(4 * (col[kGap] - i) + 1);
 	}
 	const int n = order_[step_];
 	const int start = starts_[n];

@@ -40,9 +40,10 @@ public:
 	 *   top[0..ncols_pad]         X of border row 0 = 4*H[0][k]; beyond ncols: last value */
 	void write_tables(uint32_t *coltab, int32_t *leftc, int ncols_pad, uint8_t *rowshift, int32_t *top, bool wide) const;
 
-	/* Same inputs for the packed-16 pair mode (PairJob): narrow byte gains, i16 left gains at
-	 * element stride 2, one v_perm selector byte per row at stride 4 (selbase + letter). */
-	void write_tables_pk(uint32_t *tab, uint16_t *leftc, int ncols_pad, uint8_t *rowsel, int selbase, int32_t *top) const;
+	/* Same inputs for the packed-16 pair mode (PairJob; pairwise fills only, left gain is the
+	 * constant -3): narrow byte gains, one v_perm selector byte per row at stride 4
+	 * (selbase + letter). */
+	void write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel, int selbase, int32_t *top) const;
 
 	/* Apply the GPU traceback of the pending fill: ops in walk order (DIR_* codes, from cell
 	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border.
