@@ -78,6 +78,7 @@ struct PairJob {
 	uint64_t dirs;            /* u32 [nstrips][steps_pad][R][64][2]: word g of a lane = columns 8g..8g+7,      */
 	                          /*     8 codes of A in the low half, 8 codes of B in the high half, first column  */
 	                          /*     in the top bits of each half                                              */
+	uint64_t progress;        /* i32 [nstrips] persistent kernel: chunks (TR steps) each strip has published    */
 	uint64_t ops[2];          /* u8 traceback ops per matrix                                                   */
 	uint64_t summary[2];      /* i32 [4] per matrix                                                            */
 	int32_t nrows[2], ncols[2];

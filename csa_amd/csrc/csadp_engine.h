@@ -104,10 +104,17 @@ private:
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
 	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
 	int layout_pk();
+	int run_slot(int sl, bool persistent);
 	std::vector<PairJob> pjobs_;
 	std::vector<PairExtra> pextra_;
 	std::vector<int> pair_of_, half_of_;
 	bool pk_ = false;
+	/* persistent packed kernel: strip list (strip-major), per-slot flag region
+	 * [abort word | progress counters], zeroed by a memset node before every pass */
+	size_t strips_off_ = 0, nstrips_total_ = 0;
+	size_t flags_off_[Engine::kMaxSlots] = {}, flags_bytes_ = 0;
+	bool persist_ = false;
+	int *h_abort_ = nullptr;
 	std::vector<FillJob> jobs_;
 	std::vector<Extra> extra_;
 	std::vector<TileRef> tiles_;

@@ -20,6 +20,11 @@ hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, i
 /* Packed-16 pair mode (PairJob): C is fixed to 16 columns per lane. */
 hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles,
                           hipStream_t st);
+/* persistent variant: one launch per pass, one wave per (pair job, strip); strips must be sorted
+ * strip-major; *abort_word (zeroed before the launch) is set if a bounded spin ran out.
+ * Supported: R in {1,2}, TR in {64,128}. */
+hipError_t launch_fill_strips_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *strips, int nstrips,
+                                 int *abort_word, hipStream_t st);
 hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int npairs, hipStream_t st);
 
 /* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;

@@ -557,6 +557,137 @@ __global__ __launch_bounds__(64, 4) void nw_fill_tiles_pk(uint8_t *__restrict__ 
 	}
 }
 
+/*
+ * Persistent variant: ONE launch per pass, one single-wave workgroup per (pair job, strip),
+ * dispatched strip-major so that a strip's producer (the strip to its left) always has a
+ * lower block index.  A strip keeps its lane registers for the whole matrix and hands its
+ * right edge to the next strip chunk by chunk (TR steps): payload with agent-scope (sc1)
+ * stores, every lane drains (s_waitcnt vmcnt(0)), one lane publishes the chunk counter; the
+ * consumer polls that ONE word relaxed, issues ONE agent-scope acquire, then reads the payload
+ * with agent-scope loads (cdna_hip_programming.md, Guideline 16, R1).  Every spin is bounded:
+ * on a timeout (or when another wave raised it) the abort word is set, all waves drain, and the
+ * host repeats the pass with the launch-per-diagonal kernels -- the result never depends on
+ * dispatch order, only the speed does.
+ */
+#define CSADP_SPIN_LIMIT (1 << 22)
+
+template <int R, int TR>
+__global__ __launch_bounds__(64, 4) void nw_fill_strips_pk(uint8_t *__restrict__ arena,
+                                                           const PairJob *__restrict__ jobs,
+                                                           const TileRef *__restrict__ strips,
+                                                           int *__restrict__ abort_word)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t feed[R * (TR + 1) + 4];
+	__shared__ __attribute__((aligned(16))) uint32_t edge[R * TR];
+	__shared__ __attribute__((aligned(16))) uint32_t selb[R * (TR + 64) + 16];
+
+	const TileRef tr = strips[blockIdx.x];
+	const PairJob &J = jobs[tr.job];
+	const int lane = threadIdx.x;
+	const int s = tr.s;
+	const int L = s * kLanes + lane;
+	const int rsteps = (J.nrows_max + R - 1) / R;
+	const int a0 = (kLanes * s) / TR;
+	const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
+	const int pa1 = s > 0 ? (rsteps - 1 + kLanes * (s - 1) + 63) / TR : 0;     /* producer's last chunk */
+	int *progress = reinterpret_cast<int *>(arena + J.progress);
+	unsigned long long *hand_out = reinterpret_cast<unsigned long long *>(arena + J.handoff) + (size_t)s * J.hpitch * R;
+	const unsigned long long *hand_in =
+	    reinterpret_cast<const unsigned long long *>(arena + J.handoff) + (size_t)(s > 0 ? s - 1 : 0) * J.hpitch * R;
+
+	uint32_t tabA[CP], tabB[CP], hup[CP];
+	uint32_t diag_in, last[R];
+	int32_t baseA, baseB;
+	{
+		const uint32_t *ta = reinterpret_cast<const uint32_t *>(arena + J.tab[0]) + (size_t)L * CP;
+		const uint32_t *tb = reinterpret_cast<const uint32_t *>(arena + J.tab[1]) + (size_t)L * CP;
+		const int32_t *tpa = reinterpret_cast<const int32_t *>(arena + J.top[0]) + (size_t)L * CP;
+		const int32_t *tpb = reinterpret_cast<const int32_t *>(arena + J.top[1]) + (size_t)L * CP;
+		baseA = reinterpret_cast<const int32_t *>(arena + J.top[0])[(size_t)s * kLanes * CP];
+		baseB = reinterpret_cast<const int32_t *>(arena + J.top[1])[(size_t)s * kLanes * CP];
+#pragma unroll
+		for (int c = 0; c < CP; ++c) {
+			tabA[c] = ta[c];
+			tabB[c] = tb[c];
+			hup[c] = pk_pack(tpa[c + 1] - baseA, tpb[c + 1] - baseB);
+		}
+		diag_in = pk_pack(tpa[0] - baseA, tpb[0] - baseB);
+#pragma unroll
+		for (int q = 0; q < R; ++q) last[q] = hup[CP - 1];
+	}
+	const uint32_t *mysel = selb + R * (64 - lane);
+
+	for (int a = a0; a <= a1; ++a) {
+		const int T0 = a * TR;
+		if (a > a0) {       /* re-centre both bases on the middle lane */
+			const uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)hup[CP / 2], kLanes / 2);
+			const int dA = pk_lo(rep) & ~3, dB = pk_hi(rep) & ~3;
+			const uint32_t delta = pk_pack(dA, dB);
+			baseA += dA;
+			baseB += dB;
+#pragma unroll
+			for (int c = 0; c < CP; ++c) hup[c] = pk_sub(hup[c], delta);
+			diag_in = pk_sub(diag_in, delta);
+#pragma unroll
+			for (int q = 0; q < R; ++q) last[q] = pk_sub(last[q], delta);
+		}
+		{
+			const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowsel) + (J.padl + R * (T0 - s * kLanes - 64));
+			for (int j = lane; j < R * (TR + 64); j += kLanes) selb[j] = src[j];
+		}
+		if (s == 0) {
+			const int la = J.leftmul[0], lb = J.leftmul[1];
+			for (int e = lane; e < R * TR; e += kLanes) {
+				const int r = R * T0 + e + 1;
+				feed[e] = pk_pack(la * r - baseA, lb * r - baseB);
+			}
+		} else {
+			/* wait until the producer strip has published what this chunk reads */
+			const int need = (a + 1 < pa1 + 1) ? a + 1 : pa1 + 1;
+			int have = 0, spins = 0;
+			do {
+				have = __hip_atomic_load(progress + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (have >= need) break;
+				__builtin_amdgcn_s_sleep(4);
+				if ((++spins & 255) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) spins = CSADP_SPIN_LIMIT;
+			} while (spins < CSADP_SPIN_LIMIT);
+			if (have < need) {          /* wave-uniform: every lane polled the same word */
+				if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				return;
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			const unsigned long long *h = hand_in + (size_t)T0 * R;
+			for (int e = lane; e < R * TR; e += kLanes) {
+				const unsigned long long v = __hip_atomic_load(h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				feed[e] = pk_pack((int)(uint32_t)v - baseA, (int)(uint32_t)(v >> 32) - baseB);
+			}
+		}
+		__syncthreads();
+
+		uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (R * 2 * kLanes) + lane * 2;
+		const int r0s = T0 - L;
+		if (a == a0)
+			fill_steps_pk<R, TR, true>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
+		else
+			fill_steps_pk<R, TR, false>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
+		__syncthreads();
+
+		/* publish the right edge of this chunk (absolute X, A | B << 32), then the chunk counter */
+		{
+			unsigned long long *ho = hand_out + (size_t)(T0 + 1) * R;
+			for (int e = lane; e < R * TR; e += kLanes) {
+				const uint32_t v = edge[e];
+				const unsigned long long w = (unsigned long long)(uint32_t)(pk_lo(v) + baseA) |
+				                             ((unsigned long long)(uint32_t)(pk_hi(v) + baseB) << 32);
+				__hip_atomic_store(ho + e, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+			if (lane == 0) __hip_atomic_store(progress + s, a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__syncthreads();
+	}
+}
+
 /* Traceback of one matrix of a pair job: blockIdx = 2*pair + half.  Same run-batched walk as
  * nw_traceback; a word column covers 8 matrix columns, the window is 32 word columns wide. */
 template <int R>
@@ -661,6 +792,18 @@ hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, co
 	if (R == 1) return launch_fill_pk_r<1>(TR, arena, jobs, tiles, ntiles, st);
 	if (R == 2) return launch_fill_pk_r<2>(TR, arena, jobs, tiles, ntiles, st);
 	return hipErrorInvalidValue;
+}
+
+hipError_t launch_fill_strips_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *strips, int nstrips,
+                                 int *abort_word, hipStream_t st)
+{
+	if (nstrips <= 0) return hipSuccess;
+	if (R == 2 && TR == 64) hipLaunchKernelGGL((nw_fill_strips_pk<2, 64>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
+	else if (R == 2 && TR == 128) hipLaunchKernelGGL((nw_fill_strips_pk<2, 128>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
+	else if (R == 1 && TR == 64) hipLaunchKernelGGL((nw_fill_strips_pk<1, 64>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
+	else if (R == 1 && TR == 128) hipLaunchKernelGGL((nw_fill_strips_pk<1, 128>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
+	else return hipErrorInvalidValue;
+	return hipGetLastError();
 }
 
 hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int npairs, hipStream_t st)
