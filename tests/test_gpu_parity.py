@@ -246,3 +246,41 @@ def test_wide_profile_more_than_32_sequences(nseq):
         assert g["status"] == 0 and g["consensus"] == cons
         assert g["aligned"] == strs
         assert g["score"] == st.last_score and g["fills"] == st.fills
+
+
+def test_packed_mode_adversarial_pairs_vs_oracle():
+    """Inputs chosen to stress the packed-16 pair kernel (two matrices per register, 16-bit values
+    around re-centred int32 bases): homopolymers (steepest growth along the diagonal), all
+    mismatches, periodic sequences (many ties), and partners of very different sizes paired in
+    the same registers.  Everything is compared with the oracle string for string."""
+    r = rng(77)
+    n = 5000
+    rnd = bytes(r.choice(b"ACGT") for _ in range(n))
+    tasks = [
+        ([b"A" * n, b"A" * n], None, None, None),
+        ([b"A" * n, b"C" * (n - 7)], None, None, None),
+        ([b"ACGT" * (n // 4), b"CGTA" * (n // 4)], [3, 1], None, None),
+        ([b"AC" * (n // 2), b"CA" * (n // 2 - 3)], None, None, None),
+        ([rnd, rnd[:200]], [17, 5], None, None),
+        ([rnd[:300], rnd], [0, 4000], None, None),
+        ([rnd, bytes(reversed(rnd))], None, None, None),
+        ([b"A" * 2000 + b"C" * 3000, b"C" * 2500 + b"A" * 2500], None, None, None),
+        ([b"G", rnd], None, None, None),
+    ]
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["status"] == 0 and g["consensus"] == cons
+        assert g["aligned"] == strs
+        assert g["score"] == st.last_score
+
+
+def test_packed_mode_long_homopolymers():
+    """60 kbp of the same letter: X grows by 8 per row for 60 k rows (480 k in total), far
+    beyond 16 bits -- only the per-tile re-centring keeps the packed kernel exact."""
+    n = 60000
+    got = csa_amd.align_batch([([b"T" * n, b"T" * n], None, None, None),
+                               ([b"T" * n, b"T" * (n - 100)], None, None, None)])
+    assert got[0]["score"] == n and got[0]["aligned"] == [b"T" * n, b"T" * n]
+    assert got[1]["score"] == n - 200 and got[1]["consensus"] == n
+    assert got[1]["aligned"][1].count(b"-") == 100 and got[1]["aligned"][0] == b"T" * n
