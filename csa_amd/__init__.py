@@ -60,7 +60,7 @@ EXPORTS = [
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
     "csadp_partition_lpt", "csadp_load_fasta", "csadp_free_fasta",
-    "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations",
+    "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs",
     "csadp_debug_align_with_filler",
 ]
 
@@ -203,6 +203,17 @@ class PairBatch:
             self.close()
         except Exception:
             pass
+
+
+def score_pairs(tasks):
+    """csadp_score_pairs: DP scores of 2-sequence tasks without building strings."""
+    ta = TaskArray(tasks)
+    scores = (ctypes.c_int * ta.n)()
+    status = (ctypes.c_int * ta.n)()
+    L = lib()
+    L.csadp_score_pairs.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
+    _check(L.csadp_score_pairs(ta.arr, ta.n, scores, status), "csadp_score_pairs")
+    return list(scores), list(status)
 
 
 def partition_lpt(costs, nparts):

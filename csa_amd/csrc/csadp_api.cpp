@@ -280,6 +280,34 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 
 void csadp_pairs_destroy(csadp_pairbatch *b) { delete b; }
 
+int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *status)
+{
+	if (!tasks || !scores || ntasks <= 0) return CSADP_ERR_ARG;
+	csadp_pairbatch *b = nullptr;
+	int rc = csadp_pairs_create(tasks, ntasks, &b);
+	if (rc != CSADP_OK) return rc;
+	if ((rc = csadp_pairs_run(b)) == CSADP_OK && !b->active.empty()) rc = b->fb.download();
+	if (rc != CSADP_OK) { delete b; return rc; }
+	for (int t = 0; t < ntasks; ++t) scores[t] = 0;
+	parallel_for((int)b->active.size(), [&](int j) {
+		const int32_t *sm = b->fb.summary(j);
+		const size_t t = (size_t)b->active[(size_t)j];
+		const int a = b->tasks[t].score_from_trace(b->fb.ops(j), sm[0], sm[1], sm[2], &scores[t]);
+		if (a != CSADP_OK) b->status[t] = a;
+	});
+	/* tasks without a matrix (an empty region): the score is the border cell the host already knows */
+	for (int t = 0; t < ntasks; ++t) {
+		if (b->status[(size_t)t] == CSADP_OK && !b->tasks[(size_t)t].next_fill()) {
+			csadp_result r;
+			memset(&r, 0, sizeof(r));
+			if (b->tasks[(size_t)t].finish(&r) == CSADP_OK) { scores[t] = r.score; csadp_free_result(&r, 2); }
+		}
+		if (status) status[t] = b->status[(size_t)t];
+	}
+	delete b;
+	return CSADP_OK;
+}
+
 int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out)
 {
 	if (!aligned || !out || nseq < 2 || !aligned[0]) return CSADP_ERR_ARG;

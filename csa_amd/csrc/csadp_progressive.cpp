@@ -183,6 +183,39 @@ void Progressive::debug_rowcodes(signed char *out) const
 	for (int j = 0; j < nrows_; ++j) out[j] = (signed char)code_of(char_at(starts_[n] + j, n));
 }
 
+int Progressive::score_from_trace(const uint8_t *ops, int nops, int remj, int remk, int *score) const
+{
+	if (!pending_ || !score) return CSADP_ERR_STATE;
+	const int i = step_;
+	const int n = order_[i];
+	int j = nrows_, k = consensus_;
+	int pos = ends_[n] - 1;
+	long long sc = 0;
+	for (int t = 0; t < nops; ++t) {
+		const int op = ops[t];
+		if (j <= 0 || k <= 0) return CSADP_ERR_HIP;
+		if (op == DIR_D) {
+			const int c = code_of(char_at(pos, n));
+			const int *col = &sv_[(size_t)k * kSym];
+			sc += kMatch * col[c] + kIndel * col[kGap] + kMismatch * (i - (col[c] + col[kGap]));
+			--pos; --j; --k;
+		} else if (op == DIR_L) {
+			const int g = sv_[(size_t)k * kSym + kGap];
+			sc += kDoubleGap * g + kIndel * (i - g);
+			--k;
+		} else if (op == DIR_U) {
+			sc += kIndel * i;
+			--pos; --j;
+		} else {
+			return CSADP_ERR_HIP;
+		}
+	}
+	if (j != remj || k != remk) return CSADP_ERR_HIP;
+	sc += (j > 0) ? -(long long)border_i_ * j : (long long)border_top_[(size_t)k];
+	*score = (int)sc;
+	return CSADP_OK;
+}
+
 /* Traceback application, :1033-1155, driven by the op list instead of dpdirs. */
 int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score)
 {

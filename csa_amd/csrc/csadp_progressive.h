@@ -51,6 +51,10 @@ public:
 	 * scores along the path; if expect_score is given it must agree (test seam). */
 	int apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score = nullptr);
 
+	/* DP score H[nrows][ncols] of the pending fill from its traced path (border value + sum of
+	 * move scores, as apply_trace derives it) without touching the strings or the profile. */
+	int score_from_trace(const uint8_t *ops, int nops, int remj, int remk, int *score) const;
+
 	/* Publish the result (malloc'd strings, original index order). */
 	int finish(csadp_result *res);
 

@@ -118,6 +118,12 @@ CSADP_API int csadp_pairs_sync(csadp_pairbatch *b);
 CSADP_API int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results);
 CSADP_API void csadp_pairs_destroy(csadp_pairbatch *b);
 
+/* Score-only path for 2-sequence tasks (all-vs-all distance matrices, guide trees): fill and
+ * traceback run on the device exactly as for csadp_pairs_*, the host derives
+ * scores[t] = dpmatrix[nrows][ncols] from the traced path and skips building the aligned
+ * strings.  status[t] (may be NULL) receives per-task errors. */
+CSADP_API int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *status);
+
 typedef struct csadp_timing {
 	long long cells;        /* DP cells of one run()                                      */
 	int fill_launches;      /* fill-kernel launches of the last run()                     */

@@ -63,3 +63,19 @@ def test_sp_score_kernel_matches_tools_rule():
     assert st["sp_score"] == sp_score(fam)
     with pytest.raises(csa_amd.CsadpError):
         csa_amd.sp_score([b"ACGT", b"ACG"])
+
+
+def test_score_pairs_matches_alignment_scores():
+    """csadp_score_pairs == score of csadp_align_batch == SP of the strings, incl. empty regions."""
+    csa_amd.init(device=0)
+    cases = load_golden("tiny_pairs.json")
+    tasks = [([t.encode() for t in c["texts"]], c["rots"], c["starts"], c["ends"]) for c in cases]
+    scores, status = csa_amd.score_pairs(tasks)
+    full = csa_amd.align_batch(tasks)
+    assert status == [0] * len(tasks)
+    assert scores == [g["score"] for g in full]
+    from csa_amd.synth import synth_pair
+    big = [synth_pair(p, length=4000) for p in range(5)]
+    tasks = [([a, b], [ra, rb], None, None) for a, b, ra, rb in big]
+    scores, status = csa_amd.score_pairs(tasks)
+    assert scores == [sp_score(g["aligned"]) for g in csa_amd.align_batch(tasks)]
