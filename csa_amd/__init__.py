@@ -46,6 +46,11 @@ class SpStats(ctypes.Structure):
                 ("conserved_columns", ctypes.c_int), ("sp_score", ctypes.c_longlong)]
 
 
+class RotationInfo(ctypes.Structure):
+    _fields_ = [("blocks", ctypes.c_int), ("chain_size", ctypes.c_int), ("chain_span", ctypes.c_int),
+                ("first_block_depth", ctypes.c_int)]
+
+
 class Timing(ctypes.Structure):
     _fields_ = [("cells", ctypes.c_longlong), ("fill_launches", ctypes.c_int),
                 ("fill_tiles", ctypes.c_longlong), ("fill_ms", ctypes.c_float),
@@ -60,7 +65,7 @@ EXPORTS = [
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
     "csadp_partition_lpt", "csadp_load_fasta", "csadp_free_fasta",
-    "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs",
+    "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
     "csadp_debug_align_with_filler",
 ]
 
@@ -214,6 +219,22 @@ def score_pairs(tasks):
     L.csadp_score_pairs.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
     _check(L.csadp_score_pairs(ta.arr, ta.n, scores, status), "csadp_score_pairs")
     return list(scores), list(status)
+
+
+def find_rotations(texts):
+    """csadp_find_rotations: rotation offsets as the reference's tree analysis picks them.
+    Returns (status, rotations, info)."""
+    n = len(texts)
+    bts = [t if isinstance(t, bytes) else t.encode() for t in texts]
+    arr = (ctypes.c_char_p * n)(*bts)
+    sz = (ctypes.c_int * n)(*[len(b) for b in bts])
+    rot = (ctypes.c_int * n)()
+    info = RotationInfo()
+    L = lib()
+    L.csadp_find_rotations.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int),
+                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(RotationInfo)]
+    rc = L.csadp_find_rotations(n, arr, sz, rot, ctypes.byref(info))
+    return rc, list(rot), {k: getattr(info, k) for k, _ in RotationInfo._fields_}
 
 
 def partition_lpt(costs, nparts):

@@ -6,7 +6,7 @@
  * alignment.c:173-178) on the GPU.  Prints, per pair: alignment length, sum-of-pairs score
  * (tools.c:274-280) and the FNV-1a digest of the two aligned strings.
  *
- *   csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated <base>-Rotated.fasta]
+ *   csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated <base>-Rotated.fasta] [--find-rotations]
  *             [--pair a,b] [--write-rotated out.fasta]
  */
 #include <stdio.h>
@@ -54,6 +54,7 @@ int main(int argc, char **argv)
 	int *sizes, *rot;
 	int nseq = 0, i, a, b, rc, only_a = -1, only_b = -1, npairs = 0, p;
 	const char *rotated = NULL, *rotlist = NULL, *write_rot = NULL;
+	int find_rot = 0;
 	csadp_task *tasks;
 	csadp_result *res;
 	csadp_pairbatch *batch;
@@ -63,13 +64,14 @@ int main(int argc, char **argv)
 	long long cells = 0;
 
 	if (argc < 2) {
-		fprintf(stderr, "usage: csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated file] [--pair a,b] [--write-rotated out]\n");
+		fprintf(stderr, "usage: csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated file] [--find-rotations] [--pair a,b] [--write-rotated out]\n");
 		return 1;
 	}
 	for (i = 2; i < argc; i++) {
 		if (!strcmp(argv[i], "--rot") && i + 1 < argc) rotlist = argv[++i];
 		else if (!strcmp(argv[i], "--rotated") && i + 1 < argc) rotated = argv[++i];
 		else if (!strcmp(argv[i], "--write-rotated") && i + 1 < argc) write_rot = argv[++i];
+		else if (!strcmp(argv[i], "--find-rotations")) find_rot = 1;
 		else if (!strcmp(argv[i], "--pair") && i + 1 < argc) { if (sscanf(argv[++i], "%d,%d", &only_a, &only_b) != 2) return 1; }
 		else { fprintf(stderr, "csa_pairs: unknown argument %s\n", argv[i]); return 1; }
 	}
@@ -78,6 +80,12 @@ int main(int argc, char **argv)
 	if (rotated) {
 		int nread = 0;
 		if ((rc = csadp_read_rotations(rotated, rot, nseq, &nread)) != CSADP_OK || nread != nseq) die("read_rotations", rc ? rc : CSADP_ERR_ARG);
+	} else if (find_rot) {       /* the reference's mode R, computed natively (csadp_find_rotations) */
+		csadp_rotation_info ri;
+		double tr0 = now_s();
+		if ((rc = csadp_find_rotations(nseq, (const char *const *)texts, sizes, rot, &ri)) != CSADP_OK) die("find_rotations", rc);
+		printf("> rotation finder: %d blocks, heaviest chain %d (span %d), %.1f ms\n", ri.blocks, ri.chain_size, ri.chain_span,
+		       (now_s() - tr0) * 1e3);
 	} else if (rotlist) {
 		const char *q = rotlist;
 		for (i = 0; i < nseq && *q; i++) {

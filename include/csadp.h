@@ -149,6 +149,25 @@ typedef struct csadp_sp_stats {
 /* aligned[0..nseq) are NUL-terminated strings of equal length (else CSADP_ERR_ARG). */
 CSADP_API int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out);
 
+/* ---- rotation finder (csamsa.c:69-308 analyzeTree / getRotations) ----------------------- */
+
+typedef struct csadp_rotation_info {
+	int blocks;               /* unique maximal common blocks found (the reference's "nodes left")   */
+	int chain_size;           /* summed block length of the winning chain                            */
+	int chain_span;           /* its length including the intervals between blocks                   */
+	int first_block_depth;    /* length of the block whose positions are the rotations               */
+} csadp_rotation_info;
+
+/*
+ * rotations[s] = position in texts[s] of the first block of the heaviest chain of blocks common
+ * to all sequences, as the reference computes it from its generalized cyclic suffix tree.  Host
+ * computation (the reference spends < 3 % of its time here).  CSADP_ERR_RANGE: no unique common
+ * block exists, or the reference's own chain bookkeeping would not terminate on this input.
+ * Blocks as long as the shortest sequence are not considered.
+ */
+CSADP_API int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, int *rotations,
+                                   csadp_rotation_info *info);
+
 /* ---- host helpers ------------------------------------------------------------------ */
 
 /* Longest-processing-time partition of n task costs over nparts devices.

@@ -116,3 +116,62 @@ int csa_ref_progressive_dp(int nseq, const char **txts, const int *sizes, const 
 }
 
 void csa_ref_free(void *p) { free(p); }
+
+/* ---- rotation finder (csamsa.c:analyzeTree) ------------------------------------------- */
+
+#include "gencycsuffixtrees.h"   /* treenode, buildGeneralizedTree */
+#include "nodeslinkedlists.h"    /* linkedblock */
+
+extern struct _linkedblock *blockslist;      /* csamsa.c:36 */
+extern int maxinterval, minblocksize, maxblocksize;
+void analyzeTree(void);                      /* csamsa.c:271 */
+
+/*
+ * Build the reference's generalized cyclic suffix tree over the given sequences and run its
+ * analysis (csamsa.c:271-308).  rot[s] receives rotations[s] (csamsa.c:260-267).  dump (may
+ * be NULL, capacity dumpcap ints) receives the analysed block list in list order, per block:
+ *   depth, size, totalsize, index of nextblock in this list (-1), positions[0..nseq)
+ * *nblocks receives the number of blocks.  The texts are copied (the tree code frees the
+ * text of a discarded identical rotation).  NOTE: the reference calls exit() when no common
+ * unique block exists; callers must feed related sequences.
+ */
+int csa_ref_rotations(int nseq, const char **txts, const int *sizes, int *rot, int *dump, int dumpcap, int *nblocks)
+{
+	int s, saved, n = 0, used = 0;
+	struct _linkedblock *b, *c;
+
+	numberofseqs = nseq;
+	texts = (char **)calloc(64, sizeof(char *));
+	descs = (char **)calloc(64, sizeof(char *));
+	textsizes = (int *)calloc(64, sizeof(int));
+	for (s = 0; s < nseq; s++) {
+		texts[s] = strdup(txts[s]);
+		descs[s] = strdup("seq");
+		textsizes[s] = sizes[s];
+	}
+	minblocksize = 10;
+	maxblocksize = 0x7fffffff;
+	maxinterval = 0x7fffffff;
+	rotations = NULL;
+	saved = quiet_begin();
+	buildGeneralizedTree();
+	analyzeTree();
+	quiet_end(saved);
+	if (numberofseqs != nseq || rotations == NULL) return -1;     /* a sequence was discarded */
+	for (s = 0; s < nseq; s++) rot[s] = rotations[s];
+	for (b = blockslist; b != NULL; b = b->next) {
+		if (dump != NULL && used + 4 + nseq <= dumpcap) {
+			int idx = -1, j = 0;
+			for (c = blockslist; c != NULL; c = c->next, j++)
+				if (c == b->nextblock) { idx = j; break; }
+			dump[used++] = b->item->depth;
+			dump[used++] = b->size;
+			dump[used++] = b->totalsize;
+			dump[used++] = idx;
+			for (s = 0; s < nseq; s++) dump[used++] = b->positions ? b->positions[s] : -1;
+		}
+		n++;
+	}
+	if (nblocks) *nblocks = n;
+	return 0;
+}

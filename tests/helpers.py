@@ -240,3 +240,56 @@ def golden_task(case):
 
 def golden_aligned(case):
     return [a.encode() if a is not None else None for a in case["aligned"]]
+
+
+# ---- rotation finder checkers -------------------------------------------------------------
+
+def ref_rotations(seqs, timeout=20):
+    """Reference tree analysis (oracle/_ref, ref_shim.c:csa_ref_rotations) in a forked child: the
+    reference calls exit()/getchar() when it finds no block and can loop forever on some inputs.
+    Returns (rc, rotations, blocks); rc -9 = killed (non-terminating), -8 = exited."""
+    import pickle
+    import signal
+    lib = ref_lib()
+    n = len(seqs)
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(rd)
+        signal.alarm(timeout)
+        devnull = os.open(os.devnull, os.O_RDONLY)
+        os.dup2(devnull, 0)
+        txt = (ctypes.c_char_p * n)(*seqs)
+        sz = (ctypes.c_int * n)(*[len(s) for s in seqs])
+        rot = (ctypes.c_int * n)()
+        cap = 1 << 20
+        dump = (ctypes.c_int * cap)()
+        nb = ctypes.c_int()
+        rc = lib.csa_ref_rotations(n, txt, sz, rot, dump, cap, ctypes.byref(nb))
+        w = 4 + n
+        blocks = [tuple(dump[i * w:i * w + 3]) + (list(dump[i * w + 4:(i + 1) * w]),) for i in range(min(nb.value, cap // w))]
+        os.write(wr, pickle.dumps((rc, list(rot), blocks)))
+        os._exit(0)
+    os.close(wr)
+    data = b""
+    while True:
+        chunk = os.read(rd, 1 << 16)
+        if not chunk:
+            break
+        data += chunk
+    os.close(rd)
+    _, st = os.waitpid(pid, 0)
+    if not data:
+        return (-9 if os.WIFSIGNALED(st) else -8), [], []
+    return pickle.loads(data)
+
+
+def rotated_family(r, nseq, length, mut=0.05, indel=0.02):
+    """Related circular sequences, each cut at a random point (inputs of the rotation finder)."""
+    out = []
+    for f in random_family(r, nseq, length, mut=mut, indel=indel):
+        if len(f) < 12:
+            f = f + b"ACGTTGCAAGCT"
+        k = r.randrange(len(f))
+        out.append(f[k:] + f[:k])
+    return out

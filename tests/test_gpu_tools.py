@@ -79,3 +79,18 @@ def test_score_pairs_matches_alignment_scores():
     tasks = [([a, b], [ra, rb], None, None) for a, b, ra, rb in big]
     scores, status = csa_amd.score_pairs(tasks)
     assert scores == [sp_score(g["aligned"]) for g in csa_amd.align_batch(tasks)]
+
+
+def test_csa_pairs_native_rotations_end_to_end(tmp_path):
+    """Config 1 without any fixture: FASTA -> native rotation finder -> GPU DP; the harness also
+    writes the -Rotated.fasta the reference's mode R would write (md5 in pipeline.json)."""
+    import hashlib
+    import json
+    out = str(tmp_path / "Primates-Rotated.fasta")
+    log = _run([os.path.join(GOLDEN, "data", "Primates.txt"), "--find-rotations", "--pair", "0,1", "--write-rotated", out])
+    assert "rotations: 1947 1949 1950 2530" in log
+    assert "pair 0 1 len 16589 SP 15197 score 15197 fnv1a 7ee50a99" in log
+    with open(os.path.join(GOLDEN, "pipeline.json")) as f:
+        gold = json.load(f)["Primates"]
+    with open(out, "rb") as f:
+        assert hashlib.md5(f.read()).hexdigest() == gold["rotated_md5"]
