@@ -58,6 +58,21 @@ struct TileRef {
 	int32_t first;            /* 1 = first tile of this strip: start from the top border */
 };
 
+/* One launch may carry tiles of several passes that are in flight at different anti-diagonals
+ * (csadp_engine.cpp: FillBatch::flush): each segment is a tile list plus the index of its
+ * pass' first job in the job table. */
+struct TileSeg {
+	uint64_t tiles;           /* byte offset of a TileRef array in the arena */
+	int32_t count;
+	int32_t job_base;
+};
+constexpr int kMaxSegs = 8;
+struct SegList {
+	TileSeg seg[kMaxSegs];
+	int32_t n;
+	int32_t pad;
+};
+
 /*
  * Packed-16 pair job: TWO pairwise fills (i = 1, fresh borders, hence left gain -3 in every
  * column) share every register, the

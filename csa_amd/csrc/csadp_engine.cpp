@@ -66,7 +66,7 @@ int Engine::init(const csadp_config *cfg)
 	cus_ = prop.multiProcessorCount;
 	slots_ = env_int("CSADP_SLOTS", 4);
 	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
-	for (int i = 0; i < slots_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+	for (int i = 0; i < std::max(slots_, 2); ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
 	C_ = env_int("CSADP_COLS_PER_LANE", 16);
 	R_ = env_int("CSADP_ROWS_PER_STEP", 2);
 	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 64);
@@ -109,7 +109,7 @@ void Engine::shutdown()
 {
 	if (!ready_) return;
 	drop_arena_cache();
-	for (int i = 0; i < slots_; ++i) {
+	for (int i = 0; i < std::max(slots_, 2); ++i) {
 		(void)hipStreamSynchronize(streams_[i]);
 		(void)hipStreamDestroy(streams_[i]);
 		streams_[i] = nullptr;
@@ -231,10 +231,11 @@ int FillBatch::layout()
 	nslots_ = pipelined_ ? E.slots() : 1;
 	next_slot_ = 0;
 	size_t off = 0;
-	for (int sl = 0; sl < nslots_; ++sl) {
+	for (int sl = 0; sl < nslots_; ++sl) {          /* one contiguous job table: slot sl starts at sl * nj */
 		jobs_off_[sl] = off;
-		off = align_up(off + (size_t)nj * sizeof(FillJob), 256);
+		off += (size_t)nj * sizeof(FillJob);
 	}
+	off = align_up(off, 256);
 	tiles_off_ = off;
 	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
 	for (int j = 0; j < nj; ++j) {
@@ -314,6 +315,8 @@ int FillBatch::layout()
 	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
 	laid_out_ = true;
 	ran_ = false;
+	pending_ = 0;
+	memset(slot_used_, 0, sizeof(slot_used_));
 	return CSADP_OK;
 }
 
@@ -428,10 +431,11 @@ int FillBatch::layout_pk()
 	nslots_ = pipelined_ ? E.slots() : 1;
 	next_slot_ = 0;
 	size_t off = 0;
-	for (int sl = 0; sl < nslots_; ++sl) {
+	for (int sl = 0; sl < nslots_; ++sl) {          /* one contiguous job table: slot sl starts at sl * np */
 		jobs_off_[sl] = off;
-		off = align_up(off + (size_t)np * sizeof(PairJob), 256);
+		off += (size_t)np * sizeof(PairJob);
 	}
+	off = align_up(off, 256);
 	tiles_off_ = off;
 	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
 	strips_off_ = off;
@@ -534,6 +538,8 @@ int FillBatch::layout_pk()
 	pjobs_ = slot_jobs[0];
 	laid_out_ = true;
 	ran_ = false;
+	pending_ = 0;
+	memset(slot_used_, 0, sizeof(slot_used_));
 	return CSADP_OK;
 }
 
@@ -565,52 +571,142 @@ int FillBatch::upload()
 int FillBatch::run()
 {
 	if (!laid_out_) return CSADP_ERR_STATE;
-	const int sl = next_slot_;
-	next_slot_ = (next_slot_ + 1) % nslots_;
-	last_slot_ = sl;
+	++pending_;
 	ran_ = true;
-	return run_slot(sl, pk_ && persist_);
+	return CSADP_OK;
 }
 
-/* Enqueue one pass (fill + traceback) on the stream of slot sl. */
+int FillBatch::flush()
+{
+	if (pending_ == 0) return CSADP_OK;
+	const int k = pending_;
+	pending_ = 0;
+	/* Default: pass i goes to slot i % slots on that slot's own stream; kernels of different
+	 * streams overlap.  CSADP_MERGE=1 selects the single-stream merged schedule instead --
+	 * measured SLOWER on the bench batch (5.3 vs 4.2 ms per pass: every merged launch is a
+	 * barrier over ~3300 single-wave workgroups), kept for experiments. */
+	if (k == 1 || nslots_ < 3 || env_int("CSADP_MERGE", 0) == 0) {
+		for (int i = 0; i < k; ++i) {
+			const int sl = next_slot_;
+			next_slot_ = (next_slot_ + 1) % nslots_;
+			last_slot_ = sl;
+			const int rc = run_slot(sl, pk_ && persist_);
+			if (rc != CSADP_OK) return rc;
+		}
+		return CSADP_OK;
+	}
+	return run_merged(k);
+}
+
+/* Enqueue ONE pass (fill + traceback) of slot sl on stream sl. */
 int FillBatch::run_slot(int sl, bool persistent)
 {
 	Engine &E = Engine::get();
 	hipStream_t st = E.stream(sl);
 	hipEvent_t *ev = ev_[sl];
-	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]);
-	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]);
-	const TileRef *dtiles = reinterpret_cast<const TileRef *>(arena_ + tiles_off_);
+	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);
+	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[0]);
+	const int per_slot = pk_ ? (int)pjobs_.size() : (int)jobs_.size();
+	if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));     /* a merged schedule may still own it */
 	HIP_TRY(hipEventRecord(ev[0], st));
 	if (persistent) {
 		/* one launch: a wave per (pair job, strip), strips synchronise through progress counters */
 		HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
-		HIP_TRY(launch_fill_strips_pk(E.R(), E.TR(), arena_, dpairs, reinterpret_cast<const TileRef *>(arena_ + strips_off_),
-		                              (int)nstrips_total_, reinterpret_cast<int *>(arena_ + flags_off_[sl]), st));
+		HIP_TRY(launch_fill_strips_pk(E.R(), E.TR(), arena_, reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]),
+		                              reinterpret_cast<const TileRef *>(arena_ + strips_off_), (int)nstrips_total_,
+		                              reinterpret_cast<int *>(arena_ + flags_off_[sl]), st));
 	} else {
 		const int ndiag = (int)diag_off_.size() - 1;
 		for (int d = 0; d < ndiag; ++d) {
-			const int cnt = (int)(diag_off_[d + 1] - diag_off_[d]);
-			if (pk_) HIP_TRY(launch_fill_pk(E.R(), E.TR(), arena_, dpairs, dtiles + diag_off_[d], cnt, st));
-			else HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, dtiles + diag_off_[d], cnt, st));
+			SegList segs;
+			memset(&segs, 0, sizeof(segs));
+			segs.n = 1;
+			segs.seg[0].tiles = tiles_off_ + diag_off_[(size_t)d] * sizeof(TileRef);
+			segs.seg[0].count = (int)(diag_off_[(size_t)d + 1] - diag_off_[(size_t)d]);
+			segs.seg[0].job_base = sl * per_slot;
+			if (pk_) HIP_TRY(launch_fill_pk(E.R(), E.TR(), arena_, dpairs, segs, st));
+			else HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, segs, st));
 		}
 	}
 	HIP_TRY(hipEventRecord(ev[1], st));
-	if (pk_) HIP_TRY(launch_traceback_pk(E.R(), arena_, dpairs, (int)pjobs_.size(), st));
-	else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, djobs, (int)jobs_.size(), st));
+	if (pk_) HIP_TRY(launch_traceback_pk(E.R(), arena_, reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]), (int)pjobs_.size(), st));
+	else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]), (int)jobs_.size(), st));
 	HIP_TRY(hipEventRecord(ev[2], st));
+	slot_used_[sl] = true;
+	return CSADP_OK;
+}
+
+/*
+ * Enqueue npasses passes as ONE sequence of launches on stream 0.  With S = slots-1 passes in
+ * flight, pass j starts `stagger` = ceil(ndiag/S) launches after pass j-1; launch L carries
+ * anti-diagonal L - j*stagger of every pass j that is in flight, so head, middle and tail
+ * diagonals of different passes share a launch and its size stays near S/2 full diagonals.
+ * Tracebacks run on stream 1; a slot is handed to pass j+slots only after the traceback of
+ * pass j (one spare slot gives it `stagger` launches of slack).
+ */
+int FillBatch::run_merged(int npasses)
+{
+	Engine &E = Engine::get();
+	hipStream_t fs = E.stream(0), ts = E.stream(1);
+	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);
+	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[0]);
+	const int per_slot = pk_ ? (int)pjobs_.size() : (int)jobs_.size();
+	const int ndiag = (int)diag_off_.size() - 1;
+	const int inflight = std::min(nslots_ - 1, (int)kMaxSegs);
+	const int stagger = (ndiag + inflight - 1) / inflight;
+	const int total = (npasses - 1) * stagger + ndiag;
+	const int first_slot = next_slot_;
+	for (int L = 0; L < total; ++L) {
+		SegList segs;
+		memset(&segs, 0, sizeof(segs));
+		const int jlo = std::max(0, (L - ndiag + stagger) / stagger);          /* first pass still running */
+		const int jhi = std::min(npasses - 1, L / stagger);
+		for (int j = jlo; j <= jhi; ++j) {
+			const int d = L - j * stagger;
+			if (d < 0 || d >= ndiag) continue;
+			const int sl = (first_slot + j) % nslots_;
+			if (d == 0) {
+				if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(fs, ev_[sl][2], 0));
+				HIP_TRY(hipEventRecord(ev_[sl][0], fs));
+			}
+			TileSeg &g = segs.seg[segs.n++];
+			g.tiles = tiles_off_ + diag_off_[(size_t)d] * sizeof(TileRef);
+			g.count = (int)(diag_off_[(size_t)d + 1] - diag_off_[(size_t)d]);
+			g.job_base = sl * per_slot;
+		}
+		if (pk_) HIP_TRY(launch_fill_pk(E.R(), E.TR(), arena_, dpairs, segs, fs));
+		else HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, segs, fs));
+		for (int j = jlo; j <= jhi; ++j) {
+			if (L - j * stagger != ndiag - 1) continue;                          /* pass j just finished its fill */
+			const int sl = (first_slot + j) % nslots_;
+			HIP_TRY(hipEventRecord(ev_[sl][1], fs));
+			HIP_TRY(hipStreamWaitEvent(ts, ev_[sl][1], 0));
+			if (pk_) HIP_TRY(launch_traceback_pk(E.R(), arena_, reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]), (int)pjobs_.size(), ts));
+			else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]), (int)jobs_.size(), ts));
+			HIP_TRY(hipEventRecord(ev_[sl][2], ts));
+			slot_used_[sl] = true;
+			last_slot_ = sl;
+		}
+	}
+	next_slot_ = (first_slot + npasses) % nslots_;
 	return CSADP_OK;
 }
 
 int FillBatch::sync()
 {
-	for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipStreamSynchronize(Engine::get().stream(sl)));
+	const int rc = flush();
+	if (rc != CSADP_OK) return rc;
+	for (int sl = 0; sl < std::max(nslots_, 2); ++sl) HIP_TRY(hipStreamSynchronize(Engine::get().stream(sl)));
 	return CSADP_OK;
 }
 
 int FillBatch::download()
 {
 	if (!ran_) return CSADP_ERR_STATE;
+	{
+		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
+		if (rc != CSADP_OK) return rc;
+	}
 	hipStream_t st = Engine::get().stream(last_slot_);
 	if (pk_ && persist_) {
 		/* did a bounded spin of the persistent kernel run out?  Then its directions are
@@ -635,6 +731,10 @@ const int32_t *FillBatch::summary(int j) const { return reinterpret_cast<const i
 int FillBatch::timing(csadp_timing *t)
 {
 	if (!ran_) return CSADP_ERR_STATE;
+	{
+		const int rc = flush();
+		if (rc != CSADP_OK) return rc;
+	}
 	memset(t, 0, sizeof(*t));
 	hipEvent_t *ev = ev_[last_slot_];
 	HIP_TRY(hipEventSynchronize(ev[2]));

@@ -93,8 +93,13 @@ public:
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
 	int upload();                    /* inputs -> HBM (async on the engine stream) */
-	int run();                       /* enqueue all fill launches + the traceback on the next slot */
-	int sync();                      /* wait for every slot */
+	/* Request one more pass.  Passes are enqueued at the next sync()/timing()/download(): pass i
+	 * on slot i % slots and that slot's stream (default), or -- CSADP_MERGE=1, experimental --
+	 * all together on one stream, staggered, every launch carrying the current anti-diagonal of
+	 * every pass in flight (one TileSeg each) with the tracebacks on a second stream. */
+	int run();
+	int flush();                     /* enqueue what run() requested */
+	int sync();                      /* flush, then wait for all streams */
 	int download();                  /* results of the LAST run() -> host (blocking) */
 	const uint8_t *ops(int j) const;
 	const int32_t *summary(int j) const;   /* nops, remj, remk, 0 */
@@ -105,6 +110,7 @@ private:
 	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
 	int layout_pk();
 	int run_slot(int sl, bool persistent);
+	int run_merged(int npasses);
 	std::vector<PairJob> pjobs_;
 	std::vector<PairExtra> pextra_;
 	std::vector<int> pair_of_, half_of_;
@@ -122,7 +128,8 @@ private:
 	size_t in_bytes_ = 0, res_bytes_ = 0, total_bytes_ = 0;
 	size_t jobs_off_[Engine::kMaxSlots] = {}, res_off_[Engine::kMaxSlots] = {};
 	size_t tiles_off_ = 0;
-	int nslots_ = 1, next_slot_ = 0, last_slot_ = 0;
+	int nslots_ = 1, next_slot_ = 0, last_slot_ = 0, pending_ = 0;
+	bool slot_used_[Engine::kMaxSlots] = {};
 	uint8_t *arena_ = nullptr;
 	size_t arena_cap_ = 0;
 	uint8_t *h_in_ = nullptr;        /* pinned mirror of the input region */

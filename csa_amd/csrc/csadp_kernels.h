@@ -8,18 +8,17 @@
 
 namespace csadp {
 
-/* Launch one tile anti-diagonal: ntiles single-wave workgroups.  C = columns per lane
- * (16 or 32), R = rows per lane-step (1, 2 or 4), TR = steps per tile (64, 128 or 256). */
-/* wide = 6-bit count fields (needed when some job has i >= 32), else pre-scaled bytes */
-hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles,
-                       int ntiles, hipStream_t st);
+/* Launch the tiles of one or more tile anti-diagonals (one segment per pass in flight) as
+ * single-wave workgroups.  C = columns per lane (16 or 32), R = rows per lane-step (1, 2 or 4),
+ * TR = steps per tile (64, 128 or 256); wide = 6-bit count fields (needed when some job has
+ * i >= 32), else pre-scaled bytes. */
+hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, hipStream_t st);
 
 /* Launch the direction walk: one wave per job. */
 hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st);
 
 /* Packed-16 pair mode (PairJob): C is fixed to 16 columns per lane. */
-hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles,
-                          hipStream_t st);
+hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const SegList &segs, hipStream_t st);
 /* persistent variant: one launch per pass, one wave per (pair job, strip); strips must be sorted
  * strip-major; *abort_word (zeroed before the launch) is set if a bounded spin ran out.
  * Supported: R in {1,2}, TR in {64,128}. */

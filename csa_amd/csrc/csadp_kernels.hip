@@ -36,6 +36,25 @@ namespace csadp {
 
 #define DPP_WAVE_SHR1 0x138
 
+/* block index -> (tile, first job of its pass): a launch carries up to kMaxSegs tile lists */
+__device__ __forceinline__ TileRef resolve_tile(const uint8_t *arena, const SegList &segs, int *job_base)
+{
+	int b = blockIdx.x, i = 0;
+	while (i + 1 < segs.n && b >= segs.seg[i].count) {
+		b -= segs.seg[i].count;
+		++i;
+	}
+	*job_base = segs.seg[i].job_base;
+	return reinterpret_cast<const TileRef *>(arena + segs.seg[i].tiles)[b];
+}
+
+static int seg_tiles(const SegList &segs)     /* host: grid size of a launch */
+{
+	int n = 0;
+	for (int i = 0; i < segs.n; ++i) n += segs.seg[i].count;
+	return n;
+}
+
 /*
  * TR steps of one strip.  One step = R consecutive rows x C columns per lane.  The R rows
  * form R dependency chains that run one column apart (row rho works on column j while row
@@ -136,8 +155,7 @@ __device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32
 
 template <int C, int R, int TR, bool WIDE>
 __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
-                                                    const FillJob *__restrict__ jobs,
-                                                    const TileRef *__restrict__ tiles)
+                                                    const FillJob *__restrict__ jobs, const SegList segs)
 {
 	static_assert(C % 16 == 0, "a lane-step must fill whole direction words");
 	static_assert(TR % 64 == 0, "tile inputs are staged 64 lanes at a time");
@@ -148,8 +166,9 @@ __global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
 	__shared__ __attribute__((aligned(16))) int32_t edge[R * TR];              /* lane-63 outputs      */
 	__shared__ __attribute__((aligned(16))) uint8_t rsh[R * (TR + 64) + 16];   /* 6*code of tile rows  */
 
-	const TileRef tr = tiles[blockIdx.x];
-	const FillJob &J = jobs[tr.job];
+	int job_base;
+	const TileRef tr = resolve_tile(arena, segs, &job_base);
+	const FillJob &J = jobs[job_base + tr.job];
 	const int lane = threadIdx.x;
 	const int s = tr.s;
 	const int T0 = tr.a * TR;
@@ -451,16 +470,16 @@ __device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const 
 
 template <int R, int TR>
 __global__ __launch_bounds__(64, 4) void nw_fill_tiles_pk(uint8_t *__restrict__ arena,
-                                                       const PairJob *__restrict__ jobs,
-                                                       const TileRef *__restrict__ tiles)
+                                                       const PairJob *__restrict__ jobs, const SegList segs)
 {
 	constexpr int NST = CP + 1 + R + 2;                                        /* state words per lane */
 	__shared__ __attribute__((aligned(16))) uint32_t feed[R * (TR + 1) + 4];   /* lane-0 inputs (packed) */
 	__shared__ __attribute__((aligned(16))) uint32_t edge[R * TR];             /* lane-63 outputs        */
 	__shared__ __attribute__((aligned(16))) uint32_t selb[R * (TR + 64) + 16]; /* row selectors          */
 
-	const TileRef tr = tiles[blockIdx.x];
-	const PairJob &J = jobs[tr.job];
+	int job_base;
+	const TileRef tr = resolve_tile(arena, segs, &job_base);
+	const PairJob &J = jobs[job_base + tr.job];
 	const int lane = threadIdx.x;
 	const int s = tr.s;
 	const int T0 = tr.a * TR;
@@ -777,20 +796,21 @@ __global__ __launch_bounds__(64) void nw_traceback_pk(uint8_t *__restrict__ aren
 }
 
 template <int R>
-static hipError_t launch_fill_pk_r(int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+static hipError_t launch_fill_pk_r(int TR, uint8_t *arena, const PairJob *jobs, const SegList &segs, int ntiles, hipStream_t st)
 {
-	if (TR == 64) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 64>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
-	else if (TR == 128) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 128>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
-	else if (TR == 256) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 256>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	if (TR == 64) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 64>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
+	else if (TR == 128) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 128>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
+	else if (TR == 256) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 256>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
 	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 
-hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const SegList &segs, hipStream_t st)
 {
+	const int ntiles = seg_tiles(segs);
 	if (ntiles <= 0) return hipSuccess;
-	if (R == 1) return launch_fill_pk_r<1>(TR, arena, jobs, tiles, ntiles, st);
-	if (R == 2) return launch_fill_pk_r<2>(TR, arena, jobs, tiles, ntiles, st);
+	if (R == 1) return launch_fill_pk_r<1>(TR, arena, jobs, segs, ntiles, st);
+	if (R == 2) return launch_fill_pk_r<2>(TR, arena, jobs, segs, ntiles, st);
 	return hipErrorInvalidValue;
 }
 
@@ -860,31 +880,31 @@ hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long lo
 /* ---- launch wrappers (host) ----------------------------------------------------------- */
 
 template <int C, int R, int TR>
-static hipError_t launch_fill_t(bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+static hipError_t launch_fill_t(bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, int ntiles, hipStream_t st)
 {
-	if (wide) hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, true>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
-	else hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, false>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, tiles);
+	if (wide) hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, true>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
+	else hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, false>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
 	return hipGetLastError();
 }
 
 template <int C, int R>
-static hipError_t launch_fill_r(int TR, bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles, int ntiles, hipStream_t st)
+static hipError_t launch_fill_r(int TR, bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, int ntiles, hipStream_t st)
 {
-	if (TR == 64) return launch_fill_t<C, R, 64>(wide, arena, jobs, tiles, ntiles, st);
-	if (TR == 128) return launch_fill_t<C, R, 128>(wide, arena, jobs, tiles, ntiles, st);
-	if (TR == 256) return launch_fill_t<C, R, 256>(wide, arena, jobs, tiles, ntiles, st);
+	if (TR == 64) return launch_fill_t<C, R, 64>(wide, arena, jobs, segs, ntiles, st);
+	if (TR == 128) return launch_fill_t<C, R, 128>(wide, arena, jobs, segs, ntiles, st);
+	if (TR == 256) return launch_fill_t<C, R, 256>(wide, arena, jobs, segs, ntiles, st);
 	return hipErrorInvalidValue;
 }
 
-hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const TileRef *tiles,
-                       int ntiles, hipStream_t st)
+hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, hipStream_t st)
 {
+	const int ntiles = seg_tiles(segs);
 	if (ntiles <= 0) return hipSuccess;
-	if (C == 16 && R == 1) return launch_fill_r<16, 1>(TR, wide, arena, jobs, tiles, ntiles, st);
-	if (C == 16 && R == 2) return launch_fill_r<16, 2>(TR, wide, arena, jobs, tiles, ntiles, st);
-	if (C == 16 && R == 4) return launch_fill_r<16, 4>(TR, wide, arena, jobs, tiles, ntiles, st);
-	if (C == 32 && R == 1) return launch_fill_r<32, 1>(TR, wide, arena, jobs, tiles, ntiles, st);
-	if (C == 32 && R == 2) return launch_fill_r<32, 2>(TR, wide, arena, jobs, tiles, ntiles, st);
+	if (C == 16 && R == 1) return launch_fill_r<16, 1>(TR, wide, arena, jobs, segs, ntiles, st);
+	if (C == 16 && R == 2) return launch_fill_r<16, 2>(TR, wide, arena, jobs, segs, ntiles, st);
+	if (C == 16 && R == 4) return launch_fill_r<16, 4>(TR, wide, arena, jobs, segs, ntiles, st);
+	if (C == 32 && R == 1) return launch_fill_r<32, 1>(TR, wide, arena, jobs, segs, ntiles, st);
+	if (C == 32 && R == 2) return launch_fill_r<32, 2>(TR, wide, arena, jobs, segs, ntiles, st);
 	return hipErrorInvalidValue;
 }
 

@@ -106,9 +106,11 @@ CSADP_API void csadp_free_result(csadp_result *r, int nseq);
 
 /*
  * A batch of 2-sequence tasks whose inputs live in HBM: create() validates, packs and
- * uploads; run() enqueues fill + traceback for the whole batch on the library stream and
- * returns immediately; sync() waits; fetch() downloads the traceback and builds the
- * aligned strings.  run() may be called repeatedly (benchmark steps).
+ * uploads; run() requests one pass (fill + traceback of the whole batch) and returns
+ * immediately; sync() enqueues every requested pass and waits; fetch() downloads the traceback
+ * of the LAST pass and builds the aligned strings.  run() may be called repeatedly before a
+ * sync() (benchmark steps, streaming use): consecutive passes rotate over independent
+ * result/scratch slots on separate HIP streams so that they overlap on the device.
  */
 typedef struct csadp_pairbatch csadp_pairbatch;
 
