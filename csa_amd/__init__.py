@@ -51,6 +51,19 @@ class RotationInfo(ctypes.Structure):
                 ("first_block_depth", ctypes.c_int)]
 
 
+class AnchorMap(ctypes.Structure):
+    _fields_ = [("nseq", ctypes.c_int), ("nsegs", ctypes.c_int), ("border_nodes", ctypes.c_int),
+                ("size", ctypes.POINTER(ctypes.c_int)), ("dp", ctypes.POINTER(ctypes.c_int)),
+                ("positions", ctypes.POINTER(ctypes.c_int))]
+
+
+class MsaStats(ctypes.Structure):
+    _fields_ = [("nseq", ctypes.c_int), ("border_nodes", ctypes.c_int), ("segments", ctypes.c_int),
+                ("dp_gaps", ctypes.c_int), ("fills", ctypes.c_int), ("alignment_length", ctypes.c_int),
+                ("cells", ctypes.c_longlong), ("rotations_ms", ctypes.c_double), ("anchors_ms", ctypes.c_double),
+                ("dp_ms", ctypes.c_double), ("rows_ms", ctypes.c_double)]
+
+
 class Timing(ctypes.Structure):
     _fields_ = [("cells", ctypes.c_longlong), ("fill_launches", ctypes.c_int),
                 ("fill_tiles", ctypes.c_longlong), ("fill_ms", ctypes.c_float),
@@ -66,6 +79,7 @@ EXPORTS = [
     "csadp_pairs_destroy", "csadp_pairs_timing",
     "csadp_partition_lpt", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
+    "csadp_build_anchor_map", "csadp_free_anchor_map", "csadp_msa", "csadp_free_rows", "csadp_write_aligned_fasta",
     "csadp_debug_align_with_filler",
 ]
 
@@ -235,6 +249,66 @@ def find_rotations(texts):
                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(RotationInfo)]
     rc = L.csadp_find_rotations(n, arr, sz, rot, ctypes.byref(info))
     return rc, list(rot), {k: getattr(info, k) for k, _ in RotationInfo._fields_}
+
+
+def build_anchor_map(texts, rotations):
+    """csadp_build_anchor_map: the reference's alignment map for the given rotations.
+    Returns (status, segments, border_nodes); segments = [(size, dp, [positions])]."""
+    n = len(texts)
+    bts = [t if isinstance(t, bytes) else t.encode() for t in texts]
+    arr = (ctypes.c_char_p * n)(*bts)
+    sz = (ctypes.c_int * n)(*[len(b) for b in bts])
+    rot = (ctypes.c_int * n)(*rotations)
+    m = AnchorMap()
+    L = lib()
+    L.csadp_build_anchor_map.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int),
+                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(AnchorMap)]
+    rc = L.csadp_build_anchor_map(n, arr, sz, rot, ctypes.byref(m))
+    segs = []
+    if rc == 0:
+        for k in range(m.nsegs):
+            segs.append((m.size[k], m.dp[k], [m.positions[k * n + s] for s in range(n)]))
+    nodes = m.border_nodes
+    L.csadp_free_anchor_map.argtypes = [ctypes.POINTER(AnchorMap)]
+    L.csadp_free_anchor_map.restype = None
+    L.csadp_free_anchor_map(ctypes.byref(m))
+    return rc, segs, nodes
+
+
+def msa(texts, rotations=None):
+    """csadp_msa: the reference's alignment stage (mode N when rotations is None, else the given
+    rotations).  Returns (status, rotations, rows, stats)."""
+    n = len(texts)
+    bts = [t if isinstance(t, bytes) else t.encode() for t in texts]
+    arr = (ctypes.c_char_p * n)(*bts)
+    sz = (ctypes.c_int * n)(*[len(b) for b in bts])
+    rin = (ctypes.c_int * n)(*rotations) if rotations is not None else None
+    rout = (ctypes.c_int * n)()
+    rows = ctypes.POINTER(ctypes.c_char_p)()
+    st = MsaStats()
+    L = lib()
+    L.csadp_msa.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int),
+                            ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                            ctypes.POINTER(ctypes.POINTER(ctypes.c_char_p)), ctypes.POINTER(MsaStats)]
+    rc = L.csadp_msa(n, arr, sz, rin, rout, ctypes.byref(rows), ctypes.byref(st))
+    out = []
+    if rc == 0:
+        out = [rows[s] for s in range(n)]
+        L.csadp_free_rows.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+        L.csadp_free_rows.restype = None
+        L.csadp_free_rows(rows, n)
+    return rc, list(rout), out, {k: getattr(st, k) for k, _ in MsaStats._fields_}
+
+
+def write_aligned_fasta(path, descs, rotations, rows):
+    n = len(rows)
+    d = (ctypes.c_char_p * n)(*[x if isinstance(x, bytes) else x.encode() for x in descs])
+    r = (ctypes.c_char_p * n)(*[x if isinstance(x, bytes) else x.encode() for x in rows])
+    rot = (ctypes.c_int * n)(*rotations) if rotations is not None else None
+    L = lib()
+    L.csadp_write_aligned_fasta.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int),
+                                            ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+    _check(L.csadp_write_aligned_fasta(path.encode(), d, rot, r, n), "csadp_write_aligned_fasta")
 
 
 def partition_lpt(costs, nparts):

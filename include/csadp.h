@@ -170,6 +170,62 @@ typedef struct csadp_rotation_info {
 CSADP_API int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, int *rotations,
                                    csadp_rotation_info *info);
 
+/* ---- anchor stage (alignment.c:69-86 PrepareTreeForAlignment, :163-214 RunAlignment) ------ */
+
+/*
+ * The alignment map the reference builds before and around its ProgressiveDP calls: a list of
+ * segments from the fake first one (size 1 at position -1, alignment.c:57-64) to the fake last
+ * one (size 0 at the sequence ends).  Segment k fixes size[k] letters of every sequence s starting
+ * at rotated position positions[k*nseq+s] as an anchor column block; dp[k] = 1 marks the gap
+ * between segment k and k+1 as one ProgressiveDP task (starts = positions+size, ends = the next
+ * segment's positions).  A gap with dp[k] = 0 is one the reference skips because some sequence has
+ * nothing in it (alignment.c:180-183) -- its letters are then absent from the output, as there.
+ */
+typedef struct csadp_anchor_map {
+	int nseq;
+	int nsegs;
+	int border_nodes;     /* border nodes found before the loop (the reference's list length) */
+	int *size;            /* [nsegs]       */
+	int *dp;              /* [nsegs]       */
+	int *positions;       /* [nsegs*nseq]  */
+} csadp_anchor_map;
+
+/*
+ * Host computation.  texts are the un-rotated circular sequences; letters other than A,C,G,T
+ * compare equal to each other (gencycsuffixtrees.c:320).  CSADP_ERR_RANGE: a proper suffix of one
+ * rotated sequence is a whole rotation of another one -- the reference's walk then leaves the
+ * sequence (morenodeslinkedlists.c:590-617) and has no defined result.
+ */
+CSADP_API int csadp_build_anchor_map(int nseq, const char *const *texts, const int *sizes, const int *rotations,
+                                     csadp_anchor_map *out);
+CSADP_API void csadp_free_anchor_map(csadp_anchor_map *m);
+
+/* ---- the whole alignment stage (csamsa.c:606-623, mode N / mode A) ------------------------- */
+
+typedef struct csadp_msa_stats {
+	int nseq;
+	int border_nodes;
+	int segments;             /* alignment map segments including the two fake ones ("alignment segments") */
+	int dp_gaps;              /* gaps aligned by DP = ProgressiveDP calls of the reference                */
+	int fills;                /* DP matrix fills over all gaps                                             */
+	int alignment_length;     /* length of row 0 ("Alignment size")                                        */
+	long long cells;
+	double rotations_ms, anchors_ms, dp_ms, rows_ms;
+} csadp_msa_stats;
+
+/*
+ * rotations_in NULL: the rotations are found as in mode N (csadp_find_rotations); otherwise they
+ * are used as given (all zero = the reference's mode A).  rows_out receives nseq malloc'd rows in
+ * input order, exactly the sequence lines of the reference's "-Aligned.fasta"; free with
+ * csadp_free_rows.  All gaps are aligned in one device batch.
+ */
+CSADP_API int csadp_msa(int nseq, const char *const *texts, const int *sizes, const int *rotations_in, int *rotations_out,
+                        char ***rows_out, csadp_msa_stats *stats);
+CSADP_API void csadp_free_rows(char **rows, int nseq);
+/* SaveAlignment's file format (alignment.c:97-105): ">desc @ rot" (">desc" when rotations is NULL), the row. */
+CSADP_API int csadp_write_aligned_fasta(const char *path, const char *const *descs, const int *rotations,
+                                        const char *const *rows, int nseq);
+
 /* ---- host helpers ------------------------------------------------------------------ */
 
 /* Longest-processing-time partition of n task costs over nparts devices.

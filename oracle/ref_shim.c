@@ -175,3 +175,90 @@ int csa_ref_rotations(int nseq, const char **txts, const int *sizes, int *rot, i
 	if (nblocks) *nblocks = n;
 	return 0;
 }
+
+/* ---- anchor map (alignment.c:RunAlignment) -------------------------------------------- */
+
+#include "morenodeslinkedlists.h"  /* bordernode, linkedpos, firstbordernode */
+
+void PrepareTreeForAlignment(void);          /* alignment.c:69 */
+void RunAlignment(void);                     /* alignment.c:163 */
+void SaveAlignment(char *outputfilename);    /* alignment.c:88 */
+
+/*
+ * Run the reference's N-mode alignment stage on the given sequences: build the cyclic tree, take
+ * the rotations from analyzeTree (given_rot == NULL) or use the given ones, prepare the border
+ * nodes (alignment.c:69-86), run the anchor loop (alignment.c:163-214, including the reference's
+ * own ProgressiveDP for the gaps) and report
+ *   border (capacity bcap ints): the border-node list right after PrepareTreeForAlignment, per
+ *          node: size, then for every sequence: count, positions...
+ *   segs   (capacity scap ints): the final alignment map from firstsegment to lastsegment, per
+ *          segment: size, 1 if the gap after it was filled by DP else 0, positions[0..nseq)
+ * savepath (may be NULL): SaveAlignment output file.
+ */
+int csa_ref_alignment_map(int nseq, const char **txts, const int *sizes, const int *given_rot, int *rot_out,
+                          int *border, int bcap, int *nborder, int *segs, int scap, int *nsegs, const char *savepath)
+{
+	int s, saved, used, n;
+	bordernode *b;
+	linkedpos *p;
+	alignmapsegment *g;
+
+	if (orderedseqs) { free(orderedseqs); orderedseqs = NULL; }
+	if (seqlengths) { free(seqlengths); seqlengths = NULL; }
+	numberofseqs = nseq;
+	texts = (char **)calloc(64, sizeof(char *));
+	descs = (char **)calloc(64, sizeof(char *));
+	textsizes = (int *)calloc(64, sizeof(int));
+	for (s = 0; s < nseq; s++) {
+		char name[32];
+		snprintf(name, sizeof(name), "seq%d", s);
+		texts[s] = strdup(txts[s]);
+		descs[s] = strdup(name);
+		textsizes[s] = sizes[s];
+	}
+	minblocksize = 10;
+	maxblocksize = 0x7fffffff;
+	maxinterval = 0x7fffffff;
+	rotations = NULL;
+	saved = quiet_begin();
+	buildGeneralizedTree();
+	if (numberofseqs != nseq) { quiet_end(saved); return -1; }
+	if (given_rot == NULL) {
+		analyzeTree();
+	} else {
+		rotations = (int *)calloc((size_t)nseq, sizeof(int));
+		for (s = 0; s < nseq; s++) rotations[s] = given_rot[s];
+	}
+	if (rotations == NULL) { quiet_end(saved); return -1; }
+	for (s = 0; s < nseq; s++) rot_out[s] = rotations[s];
+	PrepareTreeForAlignment();
+	used = 0; n = 0;
+	for (b = firstbordernode->next; b != NULL; b = b->next) {
+		int need = 1 + nseq;
+		for (s = 0; s < nseq; s++) for (p = b->positions[s]; p != NULL; p = p->next) need++;
+		if (border != NULL && used + need <= bcap) {
+			border[used++] = b->size;
+			for (s = 0; s < nseq; s++) {
+				int at = used++, c = 0;
+				for (p = b->positions[s]; p != NULL; p = p->next) { border[used++] = p->k; c++; }
+				border[at] = c;
+			}
+		}
+		n++;
+	}
+	if (nborder) *nborder = n;
+	RunAlignment();
+	used = 0; n = 0;
+	for (g = firstsegment; g != NULL; g = g->next) {
+		if (segs != NULL && used + 2 + nseq <= scap) {
+			segs[used++] = g->size;
+			segs[used++] = (g->alignedstrings != NULL) ? 1 : 0;
+			for (s = 0; s < nseq; s++) segs[used++] = g->positions[s];
+		}
+		n++;
+	}
+	if (nsegs) *nsegs = n;
+	if (savepath != NULL) SaveAlignment((char *)savepath);
+	quiet_end(saved);
+	return 0;
+}

@@ -13,6 +13,11 @@ Outputs (all data, no reference source text):
   pipeline.json        (--pipeline) md5 of <set>-Aligned.fasta / -Rotated.fasta written by the
                        unmodified reference program in mode N (oracle/_ref/CSA_ref)
 
+  anchors.json         (--anchors) the anchor stage of the compiled reference (ref_shim.c:
+                       csa_ref_alignment_map): small families with their rotations, border-node
+                       count, final alignment map and the rows SaveAlignment wrote; and the
+                       alignment maps of the two example sets
+
 usage: python tests/golden/make_golden.py [--all-pairs]
 """
 import json
@@ -21,8 +26,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from helpers import (fnv1a, random_family, read_fasta, ref_progressive, rng,  # noqa: E402
-                     sp_score)
+from helpers import (fnv1a, random_family, read_fasta, ref_alignment_map, ref_progressive, rng,  # noqa: E402
+                     rotated_family, sp_score)
 
 REF_MANUAL = "/root/reference/Manual"
 # rotations printed by the reference's mode R for each example set
@@ -142,6 +147,42 @@ def pipeline():
     return out
 
 
+def anchors():
+    import tempfile
+    out = {"families": [], "sets": {}}
+    seed = 0
+    while len(out["families"]) < 60:
+        seed += 1
+        r = rng(7000 + seed)
+        n = r.choice([2, 3, 4, 5, 8])
+        length = r.choice([60, 150, 300])
+        mut, indel = r.choice([0.03, 0.08, 0.15]), r.choice([0.0, 0.02, 0.05])
+        found = seed % 2 == 0                      # rotations from the reference's own finder, or given
+        if found:
+            fam = rotated_family(r, n, length, mut=mut, indel=indel)
+            given = None
+        else:
+            fam = random_family(r, n, length, mut=mut, indel=indel, alphabet=r.choice([b"ACGT", b"ACG"]))
+            if r.random() < 0.4:
+                fam = [f + f[:len(f) // 3] for f in fam]
+            fam = [f if len(f) >= 12 else f + b"ACGTTGCAAGCT" for f in fam]
+            given = [r.randrange(len(f)) if r.random() < 0.7 else 0 for f in fam]
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "a.fasta")
+            rc, rot, border, segs = ref_alignment_map(fam, given_rot=given, savepath=path, timeout=30)
+            if rc != 0:
+                continue                            # the reference exits / does not terminate on this input
+            rows = [ln.rstrip(b"\n").decode() for ln in open(path, "rb") if not ln.startswith(b">")]
+        out["families"].append({"seqs": [f.decode() for f in fam], "given": given is not None, "rotations": rot,
+                                "border_nodes": len(border), "segments": segs, "rows": rows})
+    for name in ("Primates", "Mammals"):
+        _, seqs = read_fasta(os.path.join(HERE, "data", name + ".txt"))
+        rc, rot, border, segs = ref_alignment_map(seqs, timeout=900)
+        assert rc == 0 and rot == ROT[name], (name, rc, rot)
+        out["sets"][name] = {"rotations": rot, "border_nodes": len(border), "segments": segs}
+    return out
+
+
 def copy_data():
     os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
     for name in ("Primates", "Mammals"):
@@ -157,6 +198,10 @@ def main():
     if "--pipeline" in sys.argv:
         with open(os.path.join(HERE, "pipeline.json"), "w") as f:
             json.dump(pipeline(), f, indent=1)
+        return
+    if "--anchors" in sys.argv:
+        with open(os.path.join(HERE, "anchors.json"), "w") as f:
+            json.dump(anchors(), f, indent=0)
         return
     if "--only-real" not in sys.argv:
         with open(os.path.join(HERE, "tiny_pairs.json"), "w") as f:

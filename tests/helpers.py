@@ -293,3 +293,59 @@ def rotated_family(r, nseq, length, mut=0.05, indel=0.02):
         k = r.randrange(len(f))
         out.append(f[k:] + f[:k])
     return out
+
+
+# ---- anchor map checkers -------------------------------------------------------------------
+
+def ref_alignment_map(seqs, given_rot=None, savepath=None, timeout=60):
+    """Reference N-mode alignment stage (oracle/_ref, ref_shim.c:csa_ref_alignment_map) in a forked
+    child (the reference may exit() or not terminate).  Returns (rc, rotations, border, segments):
+    border = [(size, [positions per sequence])], segments = [(size, has_dp, [positions])]."""
+    import pickle
+    import signal
+    lib = ref_lib()
+    n = len(seqs)
+    rd, wr = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        os.close(rd)
+        signal.alarm(timeout)
+        devnull = os.open(os.devnull, os.O_RDONLY)
+        os.dup2(devnull, 0)
+        txt = (ctypes.c_char_p * n)(*seqs)
+        sz = (ctypes.c_int * n)(*[len(s) for s in seqs])
+        rot = (ctypes.c_int * n)()
+        grot = (ctypes.c_int * n)(*given_rot) if given_rot is not None else None
+        bcap = scap = 1 << 22
+        bd = (ctypes.c_int * bcap)()
+        sd = (ctypes.c_int * scap)()
+        nb = ctypes.c_int()
+        ns = ctypes.c_int()
+        rc = lib.csa_ref_alignment_map(n, txt, sz, grot, rot, bd, bcap, ctypes.byref(nb), sd, scap, ctypes.byref(ns),
+                                       savepath.encode() if savepath else None)
+        border, at = [], 0
+        for _ in range(nb.value if rc == 0 else 0):
+            size = bd[at]
+            at += 1
+            pos = []
+            for _s in range(n):
+                c = bd[at]
+                pos.append(list(bd[at + 1:at + 1 + c]))
+                at += 1 + c
+            border.append((size, pos))
+        w = 2 + n
+        segs = [(sd[i * w], sd[i * w + 1], list(sd[i * w + 2:(i + 1) * w])) for i in range(ns.value if rc == 0 else 0)]
+        os.write(wr, pickle.dumps((rc, list(rot), border, segs)))
+        os._exit(0)
+    os.close(wr)
+    data = b""
+    while True:
+        chunk = os.read(rd, 1 << 16)
+        if not chunk:
+            break
+        data += chunk
+    os.close(rd)
+    _, st = os.waitpid(pid, 0)
+    if not data:
+        return (-9 if os.WIFSIGNALED(st) else -8), [], [], []
+    return pickle.loads(data)
