@@ -24,21 +24,29 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# VALU issue roofline of the fill kernel.  The benchmarked path is the packed-16 pair kernel
-# (nw_fill_tiles_pk): 8 VALU instructions per 2 cells -- v_perm_b32, v_pk_add_i16 x2,
-# v_pk_max_i16 x2, v_lshl_add_u32 (half rate: 4 issue cycles per wave64 instruction per SIMD
-# when measured one kind at a time) and v_and_b32 x2 (full rate: 2) -- tools/valu_microbench.hip,
-# profiles/r01_valu_microbench.txt.  Priced one by one that is 6*4 + 2*2 = 28 issue cycles per
-# 128 cells per SIMD -> 11.2 TCUPS at 2.4 GHz: `peak`.  The same microbenchmark runs this exact
-# recurrence in registers only (no memory, no tile hand-off): 12.4 TCUPS at 4 waves per SIMD,
-# 11.7 at 2 -- reported as `mix_ceiling` (the kernel is capped at 3 waves per SIMD by its 138
-# VGPRs).  The 32-bit kernel (N > 2, CSADP_PK16=0): 6 instructions per cell, 8.7 / 6.3 TCUPS.
+# The benchmarked path is the bit-parallel pair kernel nw_fill_bits (csadp_bits.hip): a lane
+# advances one row of 32 columns per step on three bit planes.  Its only HBM stream is the
+# direction output, 2 bit per cell = 0.25 B/cell, written exactly once -> bound "hbm".
+# Second roofline, VALU issue: the steady-state step is 59 VALU instructions per 32 cells per lane
+# (ISA count of the compiled kernel: 45 three-operand / DPP instructions, which issue in 4 cycles
+# per wave64 and SIMD when measured one kind at a time, and 14 two-operand ones at 2 cycles --
+# tools/valu_microbench.hip, profiles/r01_valu_microbench.txt) = 208 issue cycles per 2048 cells
+# per SIMD -> 24.2 TCUPS at 2.4 GHz: `peak` of roofline_valu.
+# CSADP_BITS=0 falls back to the packed-16 kernel (nw_fill_tiles_pk, 4 VALU per cell, 11.2 TCUPS
+# issue peak) and CSADP_BITS=0 CSADP_PK16=0 to the 32-bit kernel (6 per cell, 8.7 TCUPS).
+BITS = os.environ.get("CSADP_BITS", "1") != "0"
 PK16 = os.environ.get("CSADP_PK16", "1") != "0"
-VALU_OPS_PER_CELL = 4 if PK16 else 6
-VALU_ISSUE_CYCLES_PER_CELL_WAVE = 14 if PK16 else 18
+if BITS:
+    VALU_OPS_PER_CELL = round(59 / 32, 3)
+    VALU_ISSUE_CYCLES_PER_CELL_WAVE = round((45 * 4 + 14 * 2) / 32, 3)
+    FILL_KERNEL = "nw_fill_bits"
+    DTYPE = "u32 bit planes"
+else:
+    VALU_OPS_PER_CELL = 4 if PK16 else 6
+    VALU_ISSUE_CYCLES_PER_CELL_WAVE = 14 if PK16 else 18
+    FILL_KERNEL = "nw_fill_tiles_pk" if PK16 else "nw_fill_tiles"
+    DTYPE = "int16" if PK16 else "int32"
 VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9
-VALU_MIX_CEILING_CUPS = 12.36e12 if PK16 else 6.30e12       # cellmix16 / cellmix microbenchmark, 4 waves per SIMD
-FILL_KERNEL = "nw_fill_tiles_pk" if PK16 else "nw_fill_tiles"
 
 
 def pmc_traffic_per_launch():
@@ -126,9 +134,11 @@ def main():
         torch.cuda.synchronize()
 
     elapsed = cdist.timed_steps(group, batch.run, sync, args.steps, args.warmup)
-    tm_pipe = batch.timing()                     # HIP events of the LAST timed pass, on its own stream
-    # the same pass once more, alone (no neighbouring pass in flight)
-    batch.run()
+    tm_pipe = batch.timing()                     # HIP events of the launch that held the LAST timed pass
+    # one launch alone (nothing else in flight): the bit-parallel path merges `launch_passes`
+    # consecutive passes into a launch, so request that many
+    for _ in range(max(tm_pipe["launch_passes"], 1)):
+        batch.run()
     sync()
     tm = batch.timing()
     cells_step = group.sum(tm["cells"])
@@ -146,64 +156,60 @@ def main():
             ok = ok and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
             ok = ok and sp_score(r["aligned"]) == r["score"]
         launches = max(tm["fill_launches"], 1)
-        alg_bytes = tm["dir_bytes"] + tm["border_bytes"]       # 0.25 B/cell directions + tile borders, per pass
-        # the fill kernel is in flight during the whole timed region (passes overlap on
-        # `slots` streams, the traceback of a pass hides under the next pass' fill), so its
-        # sustained rate is: work of all timed passes / wall time of the timed region
+        lp = max(tm["launch_passes"], 1)                        # passes per launch (1 unless bit-parallel)
+        alg_bytes = tm["dir_bytes"] + tm["border_bytes"]       # per pass: 0.25 B/cell directions (+ tile borders of the tiled kernels)
+        # the fill kernel is in flight during the whole timed region (launches alternate on two
+        # streams, the traceback of one hides under the next fill), so its sustained rate is:
+        # work of all timed passes / wall time of the timed region
         rank_cells = tm["cells"]
         eff_bytes_s = alg_bytes * args.steps / elapsed
         eff_cups = rank_cells * args.steps / elapsed
-        slots = int(os.environ.get("CSADP_SLOTS", "4"))
         line = {
             "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, fill + traceback, whole job",
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int16" if PK16 else "int32",
+            "dtype": DTYPE,
             "data": "synthetic", "verified": bool(ok),
             "per_gpu_gcups": round(value / args.gpus, 3),
             "config": {"workload": "config 4 share: %d synthetic circular %d bp pairs per GPU "
                                    "(global pairs rank*%d..), linear-gap NW fill + traceback, "
                                    "bit-exact vs reference" % (args.pairs, args.length, args.pairs),
                        "pairs_per_gpu": args.pairs, "seq_len": args.length,
-                       "cols_per_lane": int(os.environ.get("CSADP_COLS_PER_LANE", "16")),
-                       "rows_per_step": int(os.environ.get("CSADP_ROWS_PER_STEP", "2")),
-                       "tile_steps": int(os.environ.get("CSADP_TILE_ROWS", "64")),
-                       "pipelined_passes": slots,
+                       "kernel": FILL_KERNEL,
+                       "passes_per_launch": lp,
                        "parallelism": "tasks sharded over %d GPU(s), no collective" % args.gpus},
-            "kernel_ms": {"fill_pipelined": round(tm_pipe["fill_ms"], 3),
-                          "traceback_pipelined": round(tm_pipe["traceback_ms"], 3),
-                          "fill_alone": round(tm["fill_ms"], 3), "traceback_alone": round(tm["traceback_ms"], 3),
-                          "fill_launches": tm["fill_launches"], "fill_tiles": tm["fill_tiles"],
-                          "fill_alone_gcups": round(tm["cells"] / tm["fill_ms"] / 1e6, 2)},
+            "kernel_ms": {"fill_launch_pipelined": round(tm_pipe["fill_ms"], 3),
+                          "traceback_launch_pipelined": round(tm_pipe["traceback_ms"], 3),
+                          "fill_launch_alone": round(tm["fill_ms"], 3), "traceback_launch_alone": round(tm["traceback_ms"], 3),
+                          "passes_per_launch": lp,
+                          "fill_launches_per_pass": tm["fill_launches"] / lp, "fill_tiles": tm["fill_tiles"],
+                          "fill_alone_gcups": round(lp * tm["cells"] / tm["fill_ms"] / 1e6, 2)},
             "host_boundary_ms": {"create_pack_upload": round(create_s * 1e3, 2), "fetch_download_strings": round(fetch_s * 1e3, 2),
-                                 "pcie_inclusive_gcups": round(rank_cells / (create_s + fetch_s + tm["total_ms"] / 1e3) / 1e9, 1),
+                                 "pcie_inclusive_gcups": round(rank_cells / (create_s + fetch_s + tm["total_ms"] / lp / 1e3) / 1e9, 1),
                                  "note": "not part of value: one batch from host buffers to host strings, unpipelined"},
             "roofline": {"bound": "hbm", "kernel": FILL_KERNEL,
                          "achieved": round(eff_bytes_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(eff_bytes_s / 1e9 / HBM_PEAK_GBS, 6),
                          "traffic": pmc_traffic_per_launch(),
-                         "bytes_per_launch": round(alg_bytes / launches),
+                         "bytes_per_launch": round(lp * alg_bytes / launches),
                          "avg_launch_us": round(tm["fill_ms"] * 1e3 / launches, 2),
-                         "per_launch_achieved": round(alg_bytes / (tm["fill_ms"] * 1e-3) / 1e9, 1),
-                         "stream_us_per_launch_pipelined": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
-                         "concurrent_streams": slots,
-                         "note": "algorithmic bytes = 0.25 B/cell directions + tile borders (SURVEY 8d). avg_launch_us = "
-                                 "HIP events around the 160 launches of one pass run alone on its stream (agrees with "
-                                 "rocprofv3 --stats AverageNs, profiles/r01_kernel_stats*.csv); per_launch_achieved = "
-                                 "bytes_per_launch / avg_launch_us. achieved = algorithmic bytes of all timed passes / "
-                                 "timed wall time: launches of consecutive passes overlap on `concurrent_streams` streams. "
-                                 "dtype: 16-bit lanes relative to exact int32 bases (results bit-exact). The binding "
-                                 "roofline is integer VALU issue: roofline_valu"},
+                         "per_launch_achieved": round(lp * alg_bytes / (tm["fill_ms"] * 1e-3) / 1e9, 1),
+                         "launch_us_pipelined": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
+                         "note": "algorithmic bytes = 0.25 B/cell of direction output (SURVEY 8d) x cells of the "
+                                 "`passes_per_launch` passes one launch carries. avg_launch_us = HIP events around ONE "
+                                 "such launch run alone on its stream (agrees with rocprofv3 --stats AverageNs, "
+                                 "profiles/); per_launch_achieved = bytes_per_launch / avg_launch_us. achieved = "
+                                 "algorithmic bytes of all timed passes / timed wall time (launches alternate on two "
+                                 "streams, so the next launch fills the tail of the previous one and hides its traceback). "
+                                 "roofline_valu prices the same kernel against VALU issue"},
             "roofline_valu": {"bound": "valu-issue", "ops_per_cell": VALU_OPS_PER_CELL,
                               "issue_cycles_per_64_cells": VALU_ISSUE_CYCLES_PER_CELL_WAVE,
                               "achieved": round(eff_cups / 1e9, 1), "peak": round(VALU_PEAK_CUPS / 1e9, 1),
                               "unit": "GCUPS", "frac": round(eff_cups / VALU_PEAK_CUPS, 4),
-                              "mix_ceiling": round(VALU_MIX_CEILING_CUPS / 1e9, 1),
-                              "frac_of_mix_ceiling": round(eff_cups / VALU_MIX_CEILING_CUPS, 4),
-                              "note": "peak = 1024 SIMDs x 64 cells / issue cycles x 2.4 GHz with per-op issue rates "
-                                      "measured one kind at a time; mix_ceiling = the same recurrence in registers "
-                                      "only, as measured on this chip (profiles/r01_valu_microbench.txt)"},
+                              "note": "peak = 1024 SIMDs x 64 cells / issue cycles x 2.4 GHz with the per-instruction "
+                                      "issue rates measured one kind at a time on this chip "
+                                      "(profiles/r01_valu_microbench.txt) and the instruction count of the compiled kernel"},
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)

@@ -68,7 +68,8 @@ class Timing(ctypes.Structure):
     _fields_ = [("cells", ctypes.c_longlong), ("fill_launches", ctypes.c_int),
                 ("fill_tiles", ctypes.c_longlong), ("fill_ms", ctypes.c_float),
                 ("traceback_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
-                ("dir_bytes", ctypes.c_longlong), ("border_bytes", ctypes.c_longlong)]
+                ("dir_bytes", ctypes.c_longlong), ("border_bytes", ctypes.c_longlong),
+                ("launch_passes", ctypes.c_int), ("bit_parallel", ctypes.c_int)]
 
 
 # symbols declared in include/csadp.h and include/csadp_debug.h

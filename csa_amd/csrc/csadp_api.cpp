@@ -130,12 +130,18 @@ bool advance(Progressive &p)
 int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, FillBatch &fb, std::vector<int> &status)
 {
 	fb.clear();
-	for (int t : active) fb.add(tasks[t].nrows(), tasks[t].ncols(), tasks[t].nprev(), tasks[t].border_i());
+	bool unit = true;
+	for (int t : active) {
+		fb.add(tasks[t].nrows(), tasks[t].ncols(), tasks[t].nprev(), tasks[t].border_i());
+		unit = unit && tasks[t].unit_borders();
+	}
+	fb.allow_bits(unit);
 	int rc = fb.layout();
 	if (rc != CSADP_OK) return rc;
 	parallel_for((int)active.size(), [&](int j) {
 		Progressive &p = tasks[active[(size_t)j]];
-		if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
+		if (fb.bits()) p.write_tables_bits(fb.bit_cols(j), fb.bit_nwords(j), fb.bit_rows(j), fb.bit_rowwords(j));
+		else if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 		else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 	});
 	if ((rc = fb.upload()) != CSADP_OK) return rc;
@@ -217,13 +223,19 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 		if (pending[(size_t)t]) b->active.push_back(t);
 	if (!b->active.empty()) {
 		b->fb.set_pipelined(true);
-		for (int t : b->active) b->fb.add(b->tasks[t].nrows(), b->tasks[t].ncols(), b->tasks[t].nprev(), b->tasks[t].border_i());
+		bool unit = true;
+		for (int t : b->active) {
+			b->fb.add(b->tasks[t].nrows(), b->tasks[t].ncols(), b->tasks[t].nprev(), b->tasks[t].border_i());
+			unit = unit && b->tasks[t].unit_borders();
+		}
+		b->fb.allow_bits(unit);
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
 		parallel_for((int)b->active.size(), [&](int j) {
 			Progressive &p = bp->tasks[(size_t)bp->active[(size_t)j]];
 			FillBatch &fb = bp->fb;
-			if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
+			if (fb.bits()) p.write_tables_bits(fb.bit_cols(j), fb.bit_nwords(j), fb.bit_rows(j), fb.bit_rowwords(j));
+			else if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 			else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 		});
 		if ((rc = b->fb.upload()) != CSADP_OK) return rc;

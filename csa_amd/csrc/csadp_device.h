@@ -105,6 +105,32 @@ struct PairJob {
 	int32_t leftmul[2];       /* X of border column 0 is leftmul * r (0 on fresh borders)                     */
 };
 
+/*
+ * Bit-parallel job: ONE first fill (i = 1, fresh borders H[0][k] = -k, H[r][0] = -r, scores
+ * +1 / -1 / -1).  Adjacent cells of such a matrix differ by -1..2, so a row is held as three
+ * thermometer bit planes of its horizontal differences and a lane advances 32 columns per step
+ * with word-wide logic and two carry-propagating additions (csadp_kernels.hip: nw_fill_bits).
+ * A wave owns a strip of 64 words = 2048 columns; the strips of a job are the waves of ONE
+ * workgroup, chained through LDS, so the whole matrix is a single launch.  Lane L of a strip
+ * computes row (l - L) at its local step l.
+ */
+constexpr int kBitMaxStrips = 16;    /* waves per workgroup: jobs up to 32768 columns */
+constexpr int kBitBlock = 32;        /* steps per hand-off block between strips */
+
+struct BitJob {
+	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */
+	uint64_t rowplanes;       /* u32 [2][rowwords]   same for the rows (0-based), zero padded                             */
+	uint64_t dirs;            /* u32 [nstrips][steps_pad][64][2]: word 0 = NOT-diagonal mask, word 1 = left mask of the   */
+	                          /*     32 columns of lane L in row (step - L)                                               */
+	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
+	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
+	int32_t nrows, ncols;
+	int32_t nstrips;
+	int32_t steps_pad;        /* local steps per strip, multiple of kBitBlock, >= nrows + 64                               */
+	int32_t nwords_pad;       /* 64 * nstrips                                                                              */
+	int32_t rowwords;         /* steps_pad / 32                                                                            */
+};
+
 }  // namespace csadp
 
 #endif

@@ -141,6 +141,9 @@ void FillBatch::clear()
 	pair_of_.clear();
 	half_of_.clear();
 	pk_ = false;
+	bits_ = false;
+	bjobs_.clear();
+	bextra_.clear();
 	laid_out_ = false;
 	ran_ = false;
 }
@@ -168,6 +171,13 @@ int FillBatch::layout()
 	cells_ = dir_bytes_ = border_bytes_ = 0;
 	wide_ = false;
 	pk_ = false;
+	bits_ = false;
+	if (bits_allowed_ && nj >= 1 && env_int("CSADP_BITS", 1) != 0) {
+		bits_ = true;
+		for (const FillJob &J : jobs_)
+			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0 || J.ncols > kBitMaxStrips * kLanes * 32) bits_ = false;
+	}
+	if (bits_) return layout_bits();
 	if (nj >= 2 && C == 16 && R <= 2 && env_int("CSADP_PK16", 1) != 0) {
 		pk_ = true;
 		for (const FillJob &J : jobs_)
@@ -558,6 +568,142 @@ int32_t *FillBatch::pk_top(int j)
 	return reinterpret_cast<int32_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_top[half_of_[(size_t)j]]);
 }
 
+/* Bit-parallel mode: one BitJob per fill, the whole matrix in one launch (csadp_bits.hip). */
+int FillBatch::layout_bits()
+{
+	Engine &E = Engine::get();
+	const int nj = (int)jobs_.size();
+	bjobs_.assign((size_t)nj, BitJob());
+	bextra_.assign((size_t)nj, BitExtra());
+	tiles_.clear();
+	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
+	bits_maxstrips_ = 1;
+	for (int j = 0; j < nj; ++j) {
+		const FillJob &J = jobs_[(size_t)j];
+		BitJob &B = bjobs_[(size_t)j];
+		memset(&B, 0, sizeof(B));
+		B.nrows = J.nrows;
+		B.ncols = J.ncols;
+		const int words = (J.ncols + 31) / 32;
+		B.nstrips = (words + kLanes - 1) / kLanes;
+		B.nwords_pad = B.nstrips * kLanes;
+		B.steps_pad = (int)align_up((size_t)J.nrows + 64, kBitBlock);
+		B.rowwords = B.steps_pad / 32;
+		bits_maxstrips_ = std::max(bits_maxstrips_, B.nstrips);
+		extra_[(size_t)j].ncols_pad = B.nwords_pad * 32;
+		cells_ += (long long)J.nrows * J.ncols;
+		dir_bytes_ += (long long)J.nrows * words * 8;
+	}
+	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
+	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
+	 * group * nj workgroups, aiming at two workgroups per compute unit, and two such groups are
+	 * kept in flight on two streams so that the tail and the traceback of one overlap the next. */
+	bits_group_ = 1;
+	nslots_ = 1;
+	if (pipelined_) {
+		const int want = 2 * std::max(E.compute_units(), 1);
+		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, Engine::kMaxSlots / 2));
+		bits_group_ = std::min(bits_group_, env_int("CSADP_BITS_GROUP", bits_group_));
+		bits_group_ = std::max(bits_group_, 1);
+		nslots_ = 2 * bits_group_;
+	}
+	next_slot_ = 0;
+	size_t off = 0;
+	for (int sl = 0; sl < nslots_; ++sl) {
+		jobs_off_[sl] = off;
+		off += (size_t)nj * sizeof(BitJob);
+	}
+	off = align_up(off, 256);
+	tiles_off_ = off;
+	for (int j = 0; j < nj; ++j) {
+		BitJob &B = bjobs_[(size_t)j];
+		bextra_[(size_t)j].in_cols = B.colplanes = off;
+		off = align_up(off + (size_t)2 * B.nwords_pad * 4, 256);
+		bextra_[(size_t)j].in_rows = B.rowplanes = off;
+		off = align_up(off + (size_t)2 * B.rowwords * 4, 256);
+	}
+	in_bytes_ = off;
+	std::vector<std::vector<BitJob>> slot_jobs((size_t)nslots_, bjobs_);
+	for (int sl = 0; sl < nslots_; ++sl) {
+		res_off_[sl] = off;
+		for (int j = 0; j < nj; ++j) {
+			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+			Extra &X = extra_[(size_t)j];
+			B.summary = off;
+			X.res_summary = off - res_off_[sl];
+			off += 64;
+			B.ops = off;
+			X.res_ops = off - res_off_[sl];
+			off = align_up(off + (size_t)B.nrows + B.ncols + 64, 256);
+		}
+		res_bytes_ = off - res_off_[sl];
+		flags_off_[sl] = off;                     /* abort word */
+		off += 256;
+		flags_bytes_ = 256;
+		for (int j = 0; j < nj; ++j) {
+			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+			B.dirs = off;
+			off = align_up(off + (size_t)B.nstrips * B.steps_pad * kLanes * 8, 256);
+		}
+	}
+	total_bytes_ = off;
+	const int rc = finish_layout();
+	if (rc != CSADP_OK) return rc;
+	for (int sl = 0; sl < nslots_; ++sl)
+		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(BitJob));
+	bjobs_ = slot_jobs[0];
+	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
+	return CSADP_OK;
+}
+
+/* HBM arena, pinned staging mirrors (zeroed inputs), events */
+int FillBatch::finish_layout()
+{
+	Engine &E = Engine::get();
+	if (total_bytes_ > arena_cap_) {
+		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
+		arena_ = E.take_arena(total_bytes_, &arena_cap_);
+	}
+	if (total_bytes_ > arena_cap_) {
+		E.drop_arena_cache();
+		size_t free_b = 0, total_b = 0;
+		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		if (total_bytes_ + (256u << 20) > free_b) {
+			fprintf(stderr, "csadp: batch needs %.1f GiB of HBM, %.1f GiB free\n",
+			        total_bytes_ / 1073741824.0, free_b / 1073741824.0);
+			return CSADP_ERR_RANGE;
+		}
+		HIP_TRY(hipMalloc((void **)&arena_, total_bytes_));
+		arena_cap_ = total_bytes_;
+	}
+	if (in_bytes_ > h_in_cap_) {
+		if (h_in_) (void)hipHostFree(h_in_);
+		h_in_ = nullptr;
+		HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
+		h_in_cap_ = in_bytes_;
+	}
+	if (res_bytes_ > h_res_cap_) {
+		if (h_res_) (void)hipHostFree(h_res_);
+		h_res_ = nullptr;
+		HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
+		h_res_cap_ = res_bytes_;
+	}
+	for (int sl = 0; sl < nslots_; ++sl)
+		for (auto &e : ev_[sl])
+			if (!e) HIP_TRY(hipEventCreate(&e));
+	memset(h_in_, 0, in_bytes_);
+	laid_out_ = true;
+	ran_ = false;
+	pending_ = 0;
+	memset(slot_used_, 0, sizeof(slot_used_));
+	return CSADP_OK;
+}
+
+uint32_t *FillBatch::bit_cols(int j) { return reinterpret_cast<uint32_t *>(h_in_ + bextra_[(size_t)j].in_cols); }
+int FillBatch::bit_nwords(int j) const { return bjobs_[(size_t)j].nwords_pad; }
+uint32_t *FillBatch::bit_rows(int j) { return reinterpret_cast<uint32_t *>(h_in_ + bextra_[(size_t)j].in_rows); }
+int FillBatch::bit_rowwords(int j) const { return bjobs_[(size_t)j].rowwords; }
+
 int FillBatch::upload()
 {
 	if (!laid_out_) return CSADP_ERR_STATE;
@@ -585,6 +731,7 @@ int FillBatch::flush()
 	 * streams overlap.  CSADP_MERGE=1 selects the single-stream merged schedule instead --
 	 * measured SLOWER on the bench batch (5.3 vs 4.2 ms per pass: every merged launch is a
 	 * barrier over ~3300 single-wave workgroups), kept for experiments. */
+	if (bits_) return flush_bits(k);
 	if (k == 1 || nslots_ < 3 || env_int("CSADP_MERGE", 0) == 0) {
 		for (int i = 0; i < k; ++i) {
 			const int sl = next_slot_;
@@ -596,6 +743,38 @@ int FillBatch::flush()
 		return CSADP_OK;
 	}
 	return run_merged(k);
+}
+
+/* Bit-parallel mode: enqueue k passes as merged launches of up to bits_group_ consecutive slots.
+ * Slots [0, group) always run on stream 0 and slots [group, 2*group) on stream 1, so a slot is
+ * reused in stream order. */
+int FillBatch::flush_bits(int k)
+{
+	Engine &E = Engine::get();
+	const int nj = (int)bjobs_.size();
+	while (k > 0) {
+		const int first = next_slot_;
+		const int half_end = (first / bits_group_ + 1) * bits_group_;          /* end of this stream's slot range */
+		const int g = std::min(k, std::min(half_end, nslots_) - first);
+		hipStream_t st = E.stream(nslots_ > 1 ? (first / bits_group_) % 2 : 0);
+		hipEvent_t *ev = ev_[first + g - 1];
+		const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
+		HIP_TRY(hipEventRecord(ev[0], st));
+		HIP_TRY(hipMemsetAsync(arena_ + flags_off_[first], 0, flags_bytes_, st));
+		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
+		HIP_TRY(hipEventRecord(ev[1], st));
+		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, st));
+		HIP_TRY(hipEventRecord(ev[2], st));
+		for (int sl = first; sl < first + g; ++sl) {
+			slot_used_[sl] = true;
+			flag_slot_[sl] = first;
+		}
+		last_slot_ = first + g - 1;
+		last_group_ = g;
+		next_slot_ = (first + g) % nslots_;
+		k -= g;
+	}
+	return CSADP_OK;
 }
 
 /* Enqueue ONE pass (fill + traceback) of slot sl on stream sl. */
@@ -696,7 +875,7 @@ int FillBatch::sync()
 {
 	const int rc = flush();
 	if (rc != CSADP_OK) return rc;
-	for (int sl = 0; sl < std::max(nslots_, 2); ++sl) HIP_TRY(hipStreamSynchronize(Engine::get().stream(sl)));
+	for (int sl = 0; sl < std::max(Engine::get().slots(), 2); ++sl) HIP_TRY(hipStreamSynchronize(Engine::get().stream(sl)));
 	return CSADP_OK;
 }
 
@@ -707,7 +886,15 @@ int FillBatch::download()
 		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
 		if (rc != CSADP_OK) return rc;
 	}
-	hipStream_t st = Engine::get().stream(last_slot_);
+	hipStream_t st = Engine::get().stream(bits_ ? (nslots_ > 1 ? (last_slot_ / bits_group_) % 2 : 0) : last_slot_);
+	if (bits_) {
+		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + flags_off_[flag_slot_[last_slot_]], 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (*h_abort_ != 0) {
+			fprintf(stderr, "csadp: a wait inside the bit-parallel fill kernel timed out\n");
+			return CSADP_ERR_HIP;
+		}
+	}
 	if (pk_ && persist_) {
 		/* did a bounded spin of the persistent kernel run out?  Then its directions are
 		 * incomplete: repeat the pass with the launch-per-diagonal kernels (no in-kernel waits) */
@@ -741,6 +928,8 @@ int FillBatch::timing(csadp_timing *t)
 	HIP_TRY(hipEventElapsedTime(&t->fill_ms, ev[0], ev[1]));
 	HIP_TRY(hipEventElapsedTime(&t->traceback_ms, ev[1], ev[2]));
 	HIP_TRY(hipEventElapsedTime(&t->total_ms, ev[0], ev[2]));
+	t->launch_passes = bits_ ? last_group_ : 1;
+	t->bit_parallel = bits_ ? 1 : 0;
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;
 	t->fill_tiles = (long long)tiles_.size();

@@ -89,6 +89,15 @@ public:
 	uint8_t *pk_rowsel(int j);         /* byte of row 1, element stride 4 */
 	int pk_selbase(int j) const;       /* 0 for the low half, 4 for the high half */
 	int32_t *pk_top(int j);
+	/* bit-parallel mode (BitJob): every job is a first fill with unit borders (the caller vouches
+	 * for the borders with allow_bits) and at most kBitMaxStrips*2048 columns wide.  Host tables:
+	 * two bit planes of the column letters and two of the row letters. */
+	void allow_bits(bool on) { bits_allowed_ = on; }
+	bool bits() const { return bits_; }
+	uint32_t *bit_cols(int j);         /* [2][bit_nwords(j)] */
+	int bit_nwords(int j) const;
+	uint32_t *bit_rows(int j);         /* [2][bit_rowwords(j)] */
+	int bit_rowwords(int j) const;
 	uint8_t *rowshift(int j);        /* points at row 1 (index padl) */
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
@@ -108,7 +117,17 @@ public:
 private:
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
 	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
+	struct BitExtra { size_t in_cols, in_rows; };
 	int layout_pk();
+	int layout_bits();
+	int flush_bits(int k);
+	int bits_group_ = 1, last_group_ = 1;
+	int flag_slot_[Engine::kMaxSlots] = {};
+	int finish_layout();             /* arena / staging allocation shared by the layouts */
+	std::vector<BitJob> bjobs_;
+	std::vector<BitExtra> bextra_;
+	bool bits_ = false, bits_allowed_ = false;
+	int bits_maxstrips_ = 1;
 	int run_slot(int sl, bool persistent);
 	int run_merged(int npasses);
 	std::vector<PairJob> pjobs_;

@@ -177,6 +177,26 @@ void Progressive::write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel,
 	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
 }
 
+void Progressive::write_tables_bits(uint32_t *cols, int nwords, uint32_t *rows, int rowwords) const
+{
+	const int ncols = consensus_;
+	for (int k = 1; k <= ncols; ++k) {
+		const int *col = &sv_[(size_t)k * kSym];
+		int c = 0;
+		while (c < 3 && col[c] == 0) ++c;                 /* the one letter of this column */
+		const int w = (k - 1) >> 5, b = (k - 1) & 31;
+		cols[w] |= (uint32_t)(c & 1) << b;
+		cols[nwords + w] |= (uint32_t)(c >> 1) << b;
+	}
+	const int n = order_[step_];
+	const int start = starts_[n];
+	for (int j = 0; j < nrows_; ++j) {
+		const int c = code_of(char_at(start + j, n));
+		rows[j >> 5] |= (uint32_t)(c & 1) << (j & 31);
+		rows[rowwords + (j >> 5)] |= (uint32_t)(c >> 1) << (j & 31);
+	}
+}
+
 void Progressive::debug_rowcodes(signed char *out) const
 {
 	const int n = order_[step_];

@@ -44,6 +44,11 @@ public:
 	 * constant -3): narrow byte gains, one v_perm selector byte per row at stride 4
 	 * (selbase + letter). */
 	void write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel, int selbase, int32_t *top) const;
+	/* first fill with fresh borders: H[0][k] = -k, H[r][0] = -r, every column one letter (the
+	 * conditions of the bit-parallel kernel, csadp_bits.hip) */
+	bool unit_borders() const { return step_ == 1 && border_i_ == 1 && !stale_; }
+	/* bit planes of the column letters (profile of one sequence) and of the row letters */
+	void write_tables_bits(uint32_t *cols, int nwords, uint32_t *rows, int rowwords) const;
 
 	/* Apply the GPU traceback of the pending fill: ops in walk order (DIR_* codes, from cell
 	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border.

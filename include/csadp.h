@@ -135,6 +135,10 @@ typedef struct csadp_timing {
 	float total_ms;         /* fill + traceback, HIP events on the library stream         */
 	long long dir_bytes;    /* direction bytes written to HBM by one run()                */
 	long long border_bytes; /* tile hand-off bytes written + read by one run()            */
+	int launch_passes;      /* passes carried by the launch that held the last run(): the   */
+	                        /* bit-parallel path merges consecutive run() calls into one     */
+	                        /* launch; fill_ms / traceback_ms / total_ms are that launch's    */
+	int bit_parallel;       /* 1 = the batch runs the bit-parallel kernels (nw_fill_bits)    */
 } csadp_timing;
 
 CSADP_API int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);

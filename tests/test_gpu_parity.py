@@ -19,6 +19,19 @@ def device():
     yield
 
 
+# First fills (every pairwise task, and step 1 of every progressive task) run the bit-parallel
+# kernels by default (csadp_bits.hip); CSADP_BITS=0 sends them to the packed-16 pair kernel and
+# CSADP_BITS=0 CSADP_PK16=0 to the 32-bit profile kernel.  The environment is read at every batch
+# layout, so the tests below that take `fill_mode` cover all three.
+@pytest.fixture(params=["bits", "packed16", "int32"])
+def fill_mode(request, monkeypatch):
+    if request.param != "bits":
+        monkeypatch.setenv("CSADP_BITS", "0")
+    if request.param == "int32":
+        monkeypatch.setenv("CSADP_PK16", "0")
+    return request.param
+
+
 def _check_case(case, got):
     exp = golden_aligned(case)
     assert got["status"] == 0
@@ -29,7 +42,7 @@ def _check_case(case, got):
         assert got["aligned"] == exp
 
 
-def test_tiny_pairs_golden():
+def test_tiny_pairs_golden(fill_mode):
     cases = load_golden("tiny_pairs.json")
     got = csa_amd.align_batch([golden_task(c) for c in cases])
     for c, g in zip(cases, got):
@@ -51,7 +64,7 @@ def test_tiny_one_by_one_matches_batch():
         _check_case(c, csa_amd.align_batch([golden_task(c)])[0])
 
 
-def test_score_equals_sp_for_pairs():
+def test_score_equals_sp_for_pairs(fill_mode):
     cases = [c for c in load_golden("tiny_pairs.json") if c["aligned"][0] is not None]
     got = csa_amd.align_batch([golden_task(c) for c in cases])
     for c, g in zip(cases, got):
@@ -79,7 +92,7 @@ def test_ragged_shapes_vs_oracle(shape):
     assert g["score"] == st.last_score
 
 
-def test_unrelated_pair_negative_scores():
+def test_unrelated_pair_negative_scores(fill_mode):
     a, b, ra, rb = synth_pair(3, length=3000, unrelated=True)
     g = csa_amd.align_batch([([a, b], [ra, rb], None, None)])[0]
     cons, strs, st = oracle_progressive([a, b], [ra, rb])
@@ -174,7 +187,7 @@ def test_full_size_synthetic_properties():
         assert g["aligned"] == h["aligned"] and g["score"] == h["score"]
 
 
-def test_full_size_pair_vs_oracle():
+def test_full_size_pair_vs_oracle(fill_mode):
     """One 16 kbp synthetic pair, full strings against the oracle."""
     a, b, ra, rb = synth_pair(1)
     g = csa_amd.align_batch([([a, b], [ra, rb], None, None)])[0]
@@ -182,7 +195,7 @@ def test_full_size_pair_vs_oracle():
     assert g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
 
 
-def test_mixed_length_batch():
+def test_mixed_length_batch(fill_mode):
     """Config 5 flavour at reduced scale: lengths spanning 100x in one batch."""
     r = rng(2026)
     tasks = []
@@ -248,7 +261,7 @@ def test_wide_profile_more_than_32_sequences(nseq):
         assert g["score"] == st.last_score and g["fills"] == st.fills
 
 
-def test_packed_mode_adversarial_pairs_vs_oracle():
+def test_packed_mode_adversarial_pairs_vs_oracle(fill_mode):
     """Inputs chosen to stress the packed-16 pair kernel (two matrices per register, 16-bit values
     around re-centred int32 bases): homopolymers (steepest growth along the diagonal), all
     mismatches, periodic sequences (many ties), and partners of very different sizes paired in
@@ -275,7 +288,7 @@ def test_packed_mode_adversarial_pairs_vs_oracle():
         assert g["score"] == st.last_score
 
 
-def test_packed_mode_long_homopolymers():
+def test_packed_mode_long_homopolymers(fill_mode):
     """60 kbp of the same letter: X grows by 8 per row for 60 k rows (480 k in total), far
     beyond 16 bits -- only the per-tile re-centring keeps the packed kernel exact."""
     n = 60000

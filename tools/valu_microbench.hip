@@ -106,6 +106,12 @@ DEF_KERNEL(mov, OP8(F_MOV), "v_mov_b32 %0, %1")
 DEF_KERNEL(addc, OP8(F_ADDC), "v_addc_co_u32 %0, vcc, %0, %1, vcc")
 DEF_KERNEL(lshlor, OP8(F_LSHLOR), "v_lshl_or_b32 %0, %0, 2, %1")
 DEF_KERNEL(med3, OP8(F_MED3), "v_med3_i32 %0, %0, %1, %2")
+#define F_BITOP3(r) "v_bitop3_b32 " r ", " r ", %8, %9 bitop3:0x96"
+#define F_OR3(r) "v_or3_b32 " r ", " r ", %8, %9"
+#define F_NOT(r) "v_not_b32 " r ", " r
+DEF_KERNEL(bitop3, OP8(F_BITOP3), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF_KERNEL(or3, OP8(F_OR3), "v_or3_b32 %0, %0, %1, %2")
+DEF_KERNEL(not, OP8(F_NOT), "v_not_b32 %0, %0")
 
 // in-kernel clock under an all-CU integer VALU load: shader cycles (s_memtime) per 100 MHz
 // reference tick (s_memrealtime), MI355X_MICROARCH.md 'DVFS give-back' item 6
@@ -350,6 +356,6 @@ int main()
 	RUN(pkadd16); RUN(pkmin16); RUN(dpp);
 	RUN(add_sdwa); RUN(add_sdwaw); RUN(cndmask64); RUN(cndmask32); RUN(perm); RUN(lshl); RUN(lshr); RUN(or); RUN(xor);
 	RUN(sub); RUN(minf); RUN(min3f); RUN(addf); RUN(cmp); RUN(andor); RUN(bfi); RUN(mad24); RUN(mul24); RUN(minu16);
-	RUN(mov); RUN(addc); RUN(lshlor); RUN(med3);
+	RUN(mov); RUN(addc); RUN(lshlor); RUN(med3); RUN(bitop3); RUN(or3); RUN(not);
 	return 0;
 }
