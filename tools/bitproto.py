@@ -69,3 +69,114 @@ for it in range(300):
             if d != D[i][j]:
                 print("MISMATCH", it, i, j, d, D[i][j]); sys.exit(1)
 print("all ok")
+
+
+# ---- word-level emulation of the kernel's step (32-bit words, packed hand-off word) ----------
+M32 = 0xffffffff
+A_, B_, C_ = 0xF0, 0xCC, 0xAA
+
+
+def lut(f):
+    return f(A_, B_, C_) & 0xff
+
+
+def bitop3(a, b, c, t):
+    r = 0
+    for idx in range(8):
+        if (t >> idx) & 1:
+            ma = a if idx & 4 else ~a
+            mb = b if idx & 2 else ~b
+            mc = c if idx & 1 else ~c
+            r |= ma & mb & mc
+    return r & M32
+
+
+def perm(s0, s1, sel):
+    src = [(s1 >> (8 * i)) & 0xff for i in range(4)] + [(s0 >> (8 * i)) & 0xff for i in range(4)]
+    out = 0
+    for i in range(4):
+        sb = (sel >> (8 * i)) & 0xff
+        out |= (src[sb] if sb < 8 else 0) << (8 * i)
+    return out
+
+
+def sbfe(x, off):
+    return M32 if (x >> off) & 1 else 0
+
+
+def kernel_words(a, b):
+    """rows of a against columns of b, 32 columns per word, returns per row (notdiag, left) bit masks"""
+    m, n = len(a), len(b)
+    code = {"A": 0, "C": 1, "G": 2, "T": 3}
+    nw = (n + 31) // 32
+    B0 = [0] * nw
+    B1 = [0] * nw
+    for j, ch in enumerate(b):
+        B0[j >> 5] |= (code[ch] & 1) << (j & 31)
+        B1[j >> 5] |= (code[ch] >> 1) << (j & 31)
+    nH0 = [M32] * nw
+    H1 = [0] * nw
+    H2 = [0] * nw
+    out = []
+    for i in range(m):
+        PP = code[a[i]]                                       # word entering lane 0: no carries, the row letter
+        nd_row = lf_row = 0
+        for w in range(nw):
+            PPin = PP
+            R0, R1 = sbfe(PPin, 0), sbfe(PPin, 1)
+            c2, c1 = (PPin >> 15) & 1, (PPin >> 23) & 1
+            x0 = B0[w] ^ R0
+            nE = bitop3(x0, B1[w], R1, lut(lambda a, b, c: a | (b ^ c)))
+            g2 = bitop3(nE, nH0[w], 0, lut(lambda a, b, c: ~a & b))
+            s2 = (nH0[w] + g2 + c2) & M32
+            G2 = bitop3(s2, nH0[w], g2, lut(lambda a, b, c: a ^ b ^ c))
+            O2 = bitop3(g2, nH0[w], G2, lut(lambda a, b, c: a | (b & c)))
+            t1 = bitop3(nE, nH0[w], G2, lut(lambda a, b, c: ~a | (~b & c)))
+            g1 = bitop3(t1, H1[w], 0, lut(lambda a, b, c: a & ~b))
+            A1 = bitop3(g1, nE, nH0[w], lut(lambda a, b, c: a | (b & c)))
+            s1 = (A1 + g1 + c1) & M32
+            G1 = bitop3(s1, A1, g1, lut(lambda a, b, c: a ^ b ^ c))
+            O1 = bitop3(g1, A1, G1, lut(lambda a, b, c: a | (b & c)))
+            v = bitop3(H1[w], G2, G1, lut(lambda a, b, c: (a & b) | (~a & c)))
+            ww = bitop3(nE, v, H2[w], lut(lambda a, b, c: ~c & (~a | b)))
+            O0 = bitop3(ww, nE, nH0[w], lut(lambda a, b, c: a | (b & c)))
+            G0 = ((O0 << 1) | (PPin >> 31)) & M32
+            C1 = bitop3(nE, G2, H2[w], lut(lambda a, b, c: ~a | b | c))
+            C0 = bitop3(nE, G1, H1[w], lut(lambda a, b, c: ~a | b | c))
+            T2 = bitop3(C1, G0, 0, lut(lambda a, b, c: a & ~b))
+            a1 = bitop3(C1, G1, 0, lut(lambda a, b, c: a & ~b))
+            T1 = bitop3(G0, a1, C0, lut(lambda a, b, c: (a & b) | (~a & c)))
+            b0 = bitop3(C0, G1, G0, lut(lambda a, b, c: c & (~a | b)))
+            nT0 = bitop3(b0, C1, G2, lut(lambda a, b, c: a & (~b | c)))
+            nd = C0 & nE
+            lf = nd & nT0
+            nd_row |= nd << (32 * w)
+            lf_row |= lf << (32 * w)
+            Tq = perm(O1, O2, 0x0c07030c)
+            Pq = perm(O0, Tq, 0x0702010c)
+            PP = bitop3(Pq, PPin, 0xff, lut(lambda a, b, c: a | (b & c)))
+            nH0[w], H1[w], H2[w] = nT0, T1, T2
+        out.append((nd_row, lf_row))
+    return out
+
+
+if __name__ == "__main__":
+    random.seed(2)
+    for it in range(200):
+        m = random.randint(1, 60)
+        n = random.randint(1, 200)
+        if it % 2:
+            b = "".join(random.choice("ACGT") for _ in range(n))
+            a = ("".join(c if random.random() > 0.15 else random.choice("ACGT") for c in b)[:m]) or "A"
+            m = len(a)
+        else:
+            a = "".join(random.choice("AC") for _ in range(m))
+            b = "".join(random.choice("AC") for _ in range(n))
+        H, D = plain(a, b)
+        out = kernel_words(a, b)
+        for i in range(1, m + 1):
+            nd, lf = out[i - 1]
+            for j in range(1, n + 1):
+                d = (1 if (lf >> (j - 1)) & 1 else 0) if (nd >> (j - 1)) & 1 else 2
+                assert d == D[i][j], ("word-level", it, i, j, d, D[i][j])
+    print("word-level emulation ok")
