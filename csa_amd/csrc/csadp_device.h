@@ -121,7 +121,10 @@ struct BitJob {
 	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */
 	uint64_t rowplanes;       /* u32 [2][rowwords]   same for the rows (0-based), zero padded                             */
 	uint64_t dirs;            /* u32 [nstrips][steps_pad][64][2]: word 0 = NOT-diagonal mask, word 1 = left mask of the   */
-	                          /*     32 columns of lane L in row (step - L)                                               */
+	                          /*     32 columns of lane L in row (step - L).  Unused (0 bytes) in checkpoint mode         */
+	uint64_t ckpt;            /* checkpoint mode: u32 [nstrips][steps_pad/32][64][4] lane state (nH0, H1, H2, hand-off     */
+	                          /*     word) after every block of 32 steps                                                  */
+	uint64_t hand;            /* checkpoint mode: u32 [nstrips][steps_pad] hand-off word leaving lane 63 after each step   */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;

@@ -594,18 +594,25 @@ int FillBatch::layout_bits()
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)J.nrows * words * 8;
 	}
+	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
 	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
 	 * group * nj workgroups, aiming at two workgroups per compute unit, and two such groups are
 	 * kept in flight on two streams so that the tail and the traceback of one overlap the next. */
+	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	bits_group_ = 1;
 	nslots_ = 1;
 	if (pipelined_) {
 		const int want = 2 * std::max(E.compute_units(), 1);
-		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, Engine::kMaxSlots / 2));
+		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
 		bits_group_ = std::min(bits_group_, env_int("CSADP_BITS_GROUP", bits_group_));
 		bits_group_ = std::max(bits_group_, 1);
-		nslots_ = 2 * bits_group_;
+		/* launches in flight: 2 with direction planes in HBM (8.6 GB per bench pass), 3 in
+		 * checkpoint mode (0.6 GB), where the long replay traceback of one launch should hide
+		 * under the fills of the next two */
+		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", bits_ckpt_ ? 3 : 2), std::max(E.slots(), 2)));
+		bits_streams_ = std::min(bits_streams_, Engine::kMaxSlots / bits_group_);
+		nslots_ = bits_streams_ * bits_group_;
 	}
 	next_slot_ = 0;
 	size_t off = 0;
@@ -643,7 +650,11 @@ int FillBatch::layout_bits()
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
 			B.dirs = off;
-			off = align_up(off + (size_t)B.nstrips * B.steps_pad * kLanes * 8, 256);
+			if (!bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * kLanes * 8, 256);
+			B.ckpt = off;
+			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16, 256);
+			B.hand = off;
+			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * 4, 256);
 		}
 	}
 	total_bytes_ = off;
@@ -756,14 +767,14 @@ int FillBatch::flush_bits(int k)
 		const int first = next_slot_;
 		const int half_end = (first / bits_group_ + 1) * bits_group_;          /* end of this stream's slot range */
 		const int g = std::min(k, std::min(half_end, nslots_) - first);
-		hipStream_t st = E.stream(nslots_ > 1 ? (first / bits_group_) % 2 : 0);
+		hipStream_t st = E.stream(nslots_ > 1 ? (first / bits_group_) % bits_streams_ : 0);
 		hipEvent_t *ev = ev_[first + g - 1];
 		const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
 		HIP_TRY(hipEventRecord(ev[0], st));
 		HIP_TRY(hipMemsetAsync(arena_ + flags_off_[first], 0, flags_bytes_, st));
-		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
+		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
 		HIP_TRY(hipEventRecord(ev[1], st));
-		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, st));
+		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, st));
 		HIP_TRY(hipEventRecord(ev[2], st));
 		for (int sl = first; sl < first + g; ++sl) {
 			slot_used_[sl] = true;
@@ -886,7 +897,7 @@ int FillBatch::download()
 		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
 		if (rc != CSADP_OK) return rc;
 	}
-	hipStream_t st = Engine::get().stream(bits_ ? (nslots_ > 1 ? (last_slot_ / bits_group_) % 2 : 0) : last_slot_);
+	hipStream_t st = Engine::get().stream(bits_ ? (nslots_ > 1 ? (last_slot_ / bits_group_) % bits_streams_ : 0) : last_slot_);
 	if (bits_) {
 		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + flags_off_[flag_slot_[last_slot_]], 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));

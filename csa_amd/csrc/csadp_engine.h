@@ -21,7 +21,7 @@ public:
 	int init(const csadp_config *cfg);
 	void shutdown();
 	bool ready() const { return ready_; }
-	static constexpr int kMaxSlots = 8;
+	static constexpr int kMaxSlots = 16;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
 	int slots() const { return slots_; }
 	int C() const { return C_; }
@@ -121,12 +121,12 @@ private:
 	int layout_pk();
 	int layout_bits();
 	int flush_bits(int k);
-	int bits_group_ = 1, last_group_ = 1;
+	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2;
 	int flag_slot_[Engine::kMaxSlots] = {};
 	int finish_layout();             /* arena / staging allocation shared by the layouts */
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
-	bool bits_ = false, bits_allowed_ = false;
+	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false;
 	int bits_maxstrips_ = 1;
 	int run_slot(int sl, bool persistent);
 	int run_merged(int npasses);
