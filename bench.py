@@ -24,21 +24,27 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALG_BYTES_PER_CELL = 0.25             # 2-bit direction per cell, the figure for roofline.achieved
 # The benchmarked path is the bit-parallel pair kernel nw_fill_bits (csadp_bits.hip): a lane
-# advances one row of 32 columns per step on three bit planes.  Its only HBM stream is the
-# direction output, 2 bit per cell = 0.25 B/cell, written exactly once -> bound "hbm".
-# Second roofline, VALU issue: the steady-state step is 59 VALU instructions per 32 cells per lane
-# (ISA count of the compiled kernel: 45 three-operand / DPP instructions, which issue in 4 cycles
-# per wave64 and SIMD when measured one kind at a time, and 14 two-operand ones at 2 cycles --
-# tools/valu_microbench.hip, profiles/r01_valu_microbench.txt) = 208 issue cycles per 2048 cells
-# per SIMD -> 24.2 TCUPS at 2.4 GHz: `peak` of roofline_valu.
-# CSADP_BITS=0 falls back to the packed-16 kernel (nw_fill_tiles_pk, 4 VALU per cell, 11.2 TCUPS
-# issue peak) and CSADP_BITS=0 CSADP_PK16=0 to the 32-bit kernel (6 per cell, 8.7 TCUPS).
+# advances one row of 32 columns per step on three bit planes.  Default = checkpoint mode
+# (CSADP_BITS_CKPT=1): the fill writes lane-state checkpoints (0.017 B/cell) instead of the
+# direction planes and the traceback (nw_traceback_replay) re-derives the directions of the blocks
+# on the path, so the implementation moves ~7 % of the algorithmic 0.25 B/cell and
+# roofline.achieved (algorithmic bytes / time, as SURVEY 8(d) defines it) can exceed what the HBM
+# could stream.  CSADP_BITS_CKPT=0 writes the direction planes (the kernel is then bound by HBM
+# writes: 5.2 of the 5.9 TB/s a plain store kernel reaches on this chip, tools/hbm_write_probe.hip).
+# Second roofline, VALU issue: ISA count of the compiled steady-state step = 20 v_bitop3 (2.6 issue
+# cycles per wave64 and SIMD when measured alone), 10 DPP / three-operand instructions (4.3) and 2
+# two-operand ones (2.1) per 32 cells -- tools/valu_microbench.hip, profiles/r01_valu_microbench.txt.
+# CSADP_BITS=0 falls back to the packed-16 kernel (nw_fill_tiles_pk, 4 VALU per cell) and
+# CSADP_BITS=0 CSADP_PK16=0 to the 32-bit kernel (6 per cell).
 BITS = os.environ.get("CSADP_BITS", "1") != "0"
+CKPT = os.environ.get("CSADP_BITS_CKPT", "1") != "0"
 PK16 = os.environ.get("CSADP_PK16", "1") != "0"
 if BITS:
-    VALU_OPS_PER_CELL = round(59 / 32, 3)
-    VALU_ISSUE_CYCLES_PER_CELL_WAVE = round((45 * 4 + 14 * 2) / 32, 3)
+    mix = {"v_bitop3": (20 if CKPT else 21, 2.6), "dpp_or_three_operand": (10, 4.3), "two_operand": (2 if CKPT else 3, 2.1)}
+    VALU_OPS_PER_CELL = round(sum(n for n, _ in mix.values()) / 32, 3)
+    VALU_ISSUE_CYCLES_PER_CELL_WAVE = round(sum(n * c for n, c in mix.values()) / 32, 3)
     FILL_KERNEL = "nw_fill_bits"
     DTYPE = "u32 bit planes"
 else:
@@ -157,7 +163,8 @@ def main():
             ok = ok and sp_score(r["aligned"]) == r["score"]
         launches = max(tm["fill_launches"], 1)
         lp = max(tm["launch_passes"], 1)                        # passes per launch (1 unless bit-parallel)
-        alg_bytes = tm["dir_bytes"] + tm["border_bytes"]       # per pass: 0.25 B/cell directions (+ tile borders of the tiled kernels)
+        impl_bytes = tm["dir_bytes"] + tm["border_bytes"]      # what the kernels write per pass (directions or checkpoints, + tile borders)
+        alg_bytes = ALG_BYTES_PER_CELL * tm["cells"] + (tm["border_bytes"] if not tm["bit_parallel"] else 0)
         # the fill kernel is in flight during the whole timed region (launches alternate on two
         # streams, the traceback of one hides under the next fill), so its sustained rate is:
         # work of all timed passes / wall time of the timed region
@@ -196,7 +203,11 @@ def main():
                          "avg_launch_us": round(tm["fill_ms"] * 1e3 / launches, 2),
                          "per_launch_achieved": round(lp * alg_bytes / (tm["fill_ms"] * 1e-3) / 1e9, 1),
                          "launch_us_pipelined": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
-                         "note": "algorithmic bytes = 0.25 B/cell of direction output (SURVEY 8d) x cells of the "
+                         "implementation_bytes_per_launch": round(lp * impl_bytes / launches),
+                         "mode": {0: "tiled", 1: "bit-parallel, direction planes in HBM", 2: "bit-parallel, checkpoints + replay traceback"}[tm["bit_parallel"]],
+                         "note": "checkpoint mode writes implementation_bytes_per_launch instead of the direction planes "
+                                 "(the traceback replays the path), so frac can exceed what HBM could stream; see DESIGN.md 5. "
+                                 "algorithmic bytes = 0.25 B/cell of direction output (SURVEY 8d) x cells of the "
                                  "`passes_per_launch` passes one launch carries. avg_launch_us = HIP events around ONE "
                                  "such launch run alone on its stream (agrees with rocprofv3 --stats AverageNs, "
                                  "profiles/); per_launch_achieved = bytes_per_launch / avg_launch_us. achieved = "

@@ -595,6 +595,11 @@ int FillBatch::layout_bits()
 		dir_bytes_ += (long long)J.nrows * words * 8;
 	}
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
+	if (bits_ckpt_) {                              /* no direction planes: lane state per block + hand-off words */
+		dir_bytes_ = 0;
+		for (const BitJob &B : bjobs_)
+			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 + (long long)(B.nstrips - 1) * B.steps_pad * 4;
+	}
 	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
 	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
 	 * group * nj workgroups, aiming at two workgroups per compute unit, and two such groups are
@@ -940,7 +945,7 @@ int FillBatch::timing(csadp_timing *t)
 	HIP_TRY(hipEventElapsedTime(&t->traceback_ms, ev[1], ev[2]));
 	HIP_TRY(hipEventElapsedTime(&t->total_ms, ev[0], ev[2]));
 	t->launch_passes = bits_ ? last_group_ : 1;
-	t->bit_parallel = bits_ ? 1 : 0;
+	t->bit_parallel = bits_ ? (bits_ckpt_ ? 2 : 1) : 0;
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;
 	t->fill_tiles = (long long)tiles_.size();

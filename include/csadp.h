@@ -133,12 +133,16 @@ typedef struct csadp_timing {
 	float fill_ms;          /* HIP-event time from first to last fill launch, last run()  */
 	float traceback_ms;     /* HIP-event time of the traceback kernel, last run()         */
 	float total_ms;         /* fill + traceback, HIP events on the library stream         */
-	long long dir_bytes;    /* direction bytes written to HBM by one run()                */
-	long long border_bytes; /* tile hand-off bytes written + read by one run()            */
+	long long dir_bytes;    /* direction bytes written to HBM by one run() (0 in          */
+	                        /* checkpoint mode, where the traceback replays the path)      */
+	long long border_bytes; /* tile hand-off bytes written + read by one run(); checkpoint */
+	                        /* mode: lane-state checkpoints + strip hand-off words written   */
 	int launch_passes;      /* passes carried by the launch that held the last run(): the   */
 	                        /* bit-parallel path merges consecutive run() calls into one     */
 	                        /* launch; fill_ms / traceback_ms / total_ms are that launch's    */
-	int bit_parallel;       /* 1 = the batch runs the bit-parallel kernels (nw_fill_bits)    */
+	int bit_parallel;       /* 0 = tiled kernels, 1 = bit-parallel kernels (nw_fill_bits) with  */
+	                        /* direction planes in HBM, 2 = bit-parallel with checkpoints and    */
+	                        /* replay traceback (default)                                        */
 } csadp_timing;
 
 CSADP_API int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);

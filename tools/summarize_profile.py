@@ -28,7 +28,7 @@ def main():
         dur = collections.defaultdict(dict)
         for r in csv.DictReader(open(fn)):
             name = r["Kernel_Name"]
-            key = ("nw_fill_tiles_pk" if "nw_fill_tiles_pk" in name else "nw_fill_tiles" if "nw_fill_tiles" in name else
+            key = ("nw_fill_bits" if "nw_fill_bits" in name else "nw_traceback_replay" if "nw_traceback_replay" in name else "nw_traceback_bits" if "nw_traceback_bits" in name else "nw_fill_tiles_pk" if "nw_fill_tiles_pk" in name else "nw_fill_tiles" if "nw_fill_tiles" in name else
                    "nw_traceback_pk" if "nw_traceback_pk" in name else "nw_traceback" if "nw_traceback" in name else "other")
             agg[key][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[key].add(r["Dispatch_Id"])
