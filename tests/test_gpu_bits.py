@@ -1,0 +1,151 @@
+"""GPU tests (-m gpu) aimed at the bit-parallel kernels (csadp_bits.hip): word / strip / block
+boundaries of the 32-column lanes, the LDS hand-off between the strips of a workgroup, the
+checkpoint + replay traceback and the direction-plane traceback.  Expected strings come from the
+oracle (oracle/csa_dp_oracle.c) on the same inputs."""
+import pytest
+
+import csa_amd
+from helpers import degap, oracle_progressive, random_family, rng, rotated, sp_score
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    csa_amd.init(device=0)
+    yield
+
+
+# checkpoint mode (default) replays blocks during the traceback; "planes" keeps the direction
+# planes in HBM and walks them through the skewed LDS window
+@pytest.fixture(params=["checkpoints", "planes"])
+def bits_mode(request, monkeypatch):
+    if request.param == "planes":
+        monkeypatch.setenv("CSADP_BITS_CKPT", "0")
+    return request.param
+
+
+def related(r, n, m, sub=0.1, indel=0.02):
+    a = bytes(r.choice(b"ACGT") for _ in range(n))
+    out = bytearray()
+    for ch in a:
+        x = r.random()
+        if x < indel:
+            continue
+        if x < 2 * indel:
+            out.append(r.choice(b"ACGT"))
+        out.append(r.choice(b"ACGT") if r.random() < sub else ch)
+    b = bytes(out[:m]) if m is not None else bytes(out)
+    return a, (b or b"A")
+
+
+def check(tasks):
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["status"] == 0 and g["consensus"] == cons, (len(t[0][0]), len(t[0][1]))
+        assert g["aligned"] == strs, (len(t[0][0]), len(t[0][1]))
+        assert g["score"] == st.last_score
+
+
+def test_word_strip_and_block_boundaries(bits_mode):
+    """Lengths around 32 (word), 2048 (strip = wave) and 32 / 64 rows (hand-off block, lane skew).
+    The shorter sequence is the profile (columns), the longer one the rows."""
+    r = rng(101)
+    tasks = []
+    for cols in (1, 31, 32, 33, 63, 64, 65, 2047, 2048, 2049, 4095, 4096, 4097):
+        for extra in (0, 1, 31, 33, 95):
+            a, b = related(r, cols + extra, cols)
+            if len(b) < cols:
+                b = b + bytes(r.choice(b"ACGT") for _ in range(cols - len(b)))
+            tasks.append(([a, b], None, None, None))
+    check(tasks)
+
+
+def test_many_strips_few_rows_and_few_strips_many_rows(bits_mode):
+    r = rng(102)
+    wide = bytes(r.choice(b"ACGT") for _ in range(9000))
+    tasks = [([wide[100:100 + n], wide], None, None, None) for n in (1, 2, 30, 33, 64, 65, 130)]
+    # equal lengths: the reference keeps input order, so the first sequence is the profile
+    tall = bytes(r.choice(b"ACGT") for _ in range(7000))
+    tasks += [([tall[:40], tall[:40]], None, None, None)]
+    check(tasks)
+
+
+def test_sixteen_strips_and_the_fallback_beyond(bits_mode):
+    """32768 columns = 16 waves in one workgroup (the maximum); 32769+ columns leave the
+    bit-parallel path (tiled kernels) inside the same call sequence."""
+    r = rng(103)
+    for cols in (32768, 32800):
+        a, b = related(r, cols + 40, None, sub=0.05, indel=0.005)
+        b = (b + bytes(r.choice(b"ACGT") for _ in range(cols)))[:cols]
+        rows = a[:600] + a[-600:]                       # 1200 rows against a 32 k profile: large drift
+        got = csa_amd.align_batch([([rows, b], None, None, None)])[0]
+        assert got["status"] == 0
+        assert degap(got["aligned"][0]) == rows and degap(got["aligned"][1]) == b
+        assert got["score"] == sp_score(got["aligned"])
+        cons, strs, st = oracle_progressive([rows, b], None)
+        assert got["aligned"] == strs and got["score"] == st.last_score
+
+
+def test_paths_that_leave_the_diagonal(bits_mode):
+    """Long horizontal and vertical stretches (the replay must follow the path through many
+    blocks of one strip, and across strip boundaries), borders reached early."""
+    r = rng(104)
+    core = bytes(r.choice(b"ACGT") for _ in range(3000))
+    junk = bytes(r.choice(b"AC") for _ in range(2500))
+    tasks = [
+        ([core, junk + core], None, None, None),            # 2500 leading columns unmatched
+        ([core, core + junk], None, None, None),
+        ([junk[:700] + core, core], None, None, None),
+        ([core[:1500] + junk + core[1500:], core], None, None, None),   # a 2500-row insertion in the middle
+        ([b"G" * 2100, b"T" * 2300], None, None, None),     # nothing matches
+        ([b"GT" * 1100, b"TG" * 1200], None, None, None),   # everything ties
+        ([core, core], [17, 17], None, None),
+    ]
+    check(tasks)
+
+
+def test_batch_of_mixed_sizes_in_one_launch(bits_mode):
+    """Jobs with 1..5 strips share a launch (block size = the largest job)."""
+    r = rng(105)
+    tasks = []
+    for n in (50, 700, 2048, 3000, 5000, 9000, 300, 2049):
+        a, b = related(r, n, None)
+        tasks.append(([a, b], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    check(tasks)
+
+
+def test_pair_batch_pipelined_passes_agree(bits_mode):
+    """The device-resident batch API with several merged passes in flight: every pass must leave
+    the same results (slots are independent)."""
+    r = rng(106)
+    tasks = []
+    for n in (1500, 2500, 4100):
+        a, b = related(r, n, None)
+        tasks.append(([a, b], None, None, None))
+    pb = csa_amd.PairBatch(tasks)
+    for _ in range(11):
+        pb.run()
+    pb.sync()
+    got = pb.fetch()
+    pb.close()
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["aligned"] == strs and g["score"] == st.last_score
+
+
+def test_first_step_of_families_uses_unit_borders_only():
+    """Progressive tasks: step 1 runs bit-parallel, later steps the profile kernel; sub-regions and
+    rotations included.  (Golden families cover this too; this one adds longer sequences.)"""
+    r = rng(107)
+    tasks = []
+    for n in (3, 5):
+        fam = random_family(r, n, 2600, mut=0.08, indel=0.03)
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["status"] == 0 and g["aligned"] == strs
+        for s, row in zip(t[0], g["aligned"]):
+            assert degap(row) in (rotated(s, t[1][t[0].index(s)]),)
