@@ -105,8 +105,8 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
     ap.add_argument("--len", type=int, default=16384, dest="length")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -37,10 +37,13 @@ constexpr int kSpinMax = 1 << 22;        /* bound of every wait (~0.5 s) */
 constexpr uint32_t LA = 0xF0, LB = 0xCC, LC = 0xAA;
 #define BITOP3(a, b, c, expr) ((uint32_t)__builtin_amdgcn_bitop3_b32((a), (b), (c), (unsigned char)((expr) & 0xff)))
 
-/* value of lane-1 (lane 0 keeps `old`) */
+/* value of lane-1: over the whole wave (lane 0 keeps `old`), or inside each row of 16 lanes (the
+ * first lane of every row keeps `old`) */
+template <bool ROWS>
 __device__ __forceinline__ uint32_t from_left(uint32_t old, uint32_t src)
 {
-	return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);   /* wave_shr:1 */
+	if (ROWS) return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
+	return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
 }
 
 /*
@@ -55,15 +58,21 @@ struct BitState {
 
 /* 32 steps.  inject[t] is the hand-off word entering lane 0 at step t; ringout (lane 63 of a strip
  * that has a right neighbour) receives the word leaving the strip.  RAMPIN: lanes whose row index
- * is still negative keep an empty row above. */
+ * is still negative keep an empty row above.
+ * FEEDS: lanes with `writes` store their hand-off word of step t to lanebuf[t] (LDS, per lane).
+ * OUT_GLOBAL: dirs = this strip's direction planes in HBM.  OUT_TILE (replay): the wave is four
+ * independent 16-lane pieces of strips (DPP stays inside a row, `inject` is per lane and only
+ * the first lane of a row uses it, `lane` is the lane's index in its strip) and dirs = the
+ * row's [32][16] tile. */
 enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
 
 template <bool RAMPIN, bool FEEDS, int OUT>
 __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1, const uint32_t *inject,
-                                           uint32_t *ringout, uint2 *dirs, int l0, int lane)
+                                           uint32_t *lanebuf, bool writes, uint2 *dirs, int l0, int lane)
 {
-	/* OUT_GLOBAL: dirs = this strip's direction planes in HBM; OUT_TILE: dirs = a [32][64] tile */
-	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + lane;
+	constexpr bool ROWS = (OUT == OUT_TILE);
+	constexpr int ostride = ROWS ? 16 : kLanes;
+	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15);
 	/* all 32 words entering lane 0 are fetched up front: no LDS latency inside the step chain */
 	uint32_t inj[kBitBlock];
 #pragma unroll
@@ -74,11 +83,9 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 		inj[t + 2] = v.z;
 		inj[t + 3] = v.w;
 	}
-	uint32_t roff = (uint32_t)(l0 % kRingSteps);
-	asm volatile("" : "+v"(roff));                              /* keep the LDS offset in a VGPR */
 #pragma unroll
 	for (int t = 0; t < kBitBlock; ++t) {
-		const uint32_t in = from_left(inj[t], S.PP);
+		const uint32_t in = from_left<ROWS>(inj[t], S.PP);
 		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 0, 1);
 		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 1, 1);
 		const uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
@@ -118,14 +125,14 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 		if (OUT != OUT_NONE) {
 			const uint32_t notdiag = C0 & nE;
 			const uint32_t left = notdiag & nT0;
-			out[t * kLanes] = make_uint2(notdiag, left);
+			out[t * ostride] = make_uint2(notdiag, left);
 		}
 
 		const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);         /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
 		const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);         /* byte 3 <- O0 byte 3 */
 		S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
 		if (FEEDS) {
-			if (lane == kLanes - 1) ringout[roff + t] = S.PP;
+			if (writes) lanebuf[t] = S.PP;                     /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks of this block */
 		}
 		if (RAMPIN) {
 			const uint32_t live = (l0 + t >= lane) ? ~0u : 0u;
@@ -167,6 +174,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 	constexpr int OUT = CKPT ? OUT_NONE : OUT_GLOBAL;
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
+	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	const BitJob &J = jobs[blockIdx.x];
 	const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -183,6 +191,10 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
 	uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
 	const bool feeds = s + 1 < J.nstrips;
+	/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
+	 * LDS and copied out once per block as four streams [4][steps_pad] per strip */
+	uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad : nullptr;
+	const bool writes = (lane == kLanes - 1) ? feeds : (CKPT && (lane & 15) == 15);
 
 	BitState S;
 	S.nH0 = ~0u;
@@ -203,41 +215,58 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[s][lane] = word;
+		uint32_t *lanebuf = (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
 			if (!wait_at_least(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[s], ring[s], dirs, b * kBitBlock, lane);
-			else bits_block<false, true, OUT>(S, B0, B1, inject[s], ring[s], dirs, b * kBitBlock, lane);
-			if (CKPT && lane < kBitBlock)                       /* the words that left this strip, for the traceback */
-				reinterpret_cast<uint32_t *>(arena + J.hand)[(size_t)s * J.steps_pad + b * kBitBlock + lane] =
-				    ring[s][(b * kBitBlock + lane) % kRingSteps];
+		}
+		if (feeds || CKPT) {
+			if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[s], lanebuf, writes, dirs, b * kBitBlock, lane);
+			else bits_block<false, true, OUT>(S, B0, B1, inject[s], lanebuf, writes, dirs, b * kBitBlock, lane);
+		} else {
+			if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[s], nullptr, false, dirs, b * kBitBlock, lane);
+			else bits_block<false, false, OUT>(S, B0, B1, inject[s], nullptr, false, dirs, b * kBitBlock, lane);
+		}
+		if (CKPT) {
+			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring (strips that feed) */
+			const int g = lane >> 4 >> 1, t = lane & 31;          /* lanes 0..31 -> stream 0, 32..63 -> stream 1 */
+			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[s][g][t];
+			marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
+			    (g == 0) ? mbuf[s][2][t] : (feeds ? ring[s][(b * kBitBlock + t) % kRingSteps] : 0u);
+			reinterpret_cast<uint4 *>(arena + J.ckpt)[((size_t)s * nb + b) * kLanes + lane] = make_uint4(S.nH0, S.H1, S.H2, S.PP);
+		}
+		if (feeds) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (lane == kLanes - 1) __hip_atomic_store(&made[s], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		} else {
-			if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
-			else bits_block<false, false, OUT>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
 		}
-		if (CKPT)
-			reinterpret_cast<uint4 *>(arena + J.ckpt)[((size_t)s * nb + b) * kLanes + lane] = make_uint4(S.nH0, S.H1, S.H2, S.PP);
 	}
 }
 
 /*
- * K2c.  Traceback in checkpoint mode: no direction planes exist in HBM.  The workgroup finds the
- * block (strip, 32 steps) that holds the current cell; its kReplay waves restore the strip's lane
- * state from the checkpoints before that block and the kReplay-1 blocks above it and replay them
- * with the fill's own step function, each into its own LDS tile; wave 0 then walks inside the
- * tiles (run-batched like K2b) until the path leaves them.  A diagonal crosses a block in ~31
- * cells, so a job replays (nrows + ncols) / 62 blocks or so: about an eighth of the fill's work
- * for square matrices, traded for 93 % less HBM traffic.
+ * K2c.  Traceback in checkpoint mode: no direction planes exist in HBM.  A round starts at the
+ * current cell, in block `btop` (32 steps) of strip s, lane L.  Going up its diagonal the path
+ * reaches block btop-d around lane L-d, so piece d = (block btop-d, the 16-lane group holding lane
+ * L-d) is replayed with the fill's own step function: lane state from the checkpoint before the
+ * block, the words entering the group's first lane from the fill's marks (or, for group 0, from the
+ * strip to the left).  A wave replays 4 pieces at once (one per DPP row), 4 waves = 16 pieces =
+ * ~500 path cells per round; wave 0 then walks inside the 16 LDS tiles (run-batched like K2b)
+ * until the path leaves them.  Replay work: ~(nrows + ncols) / 31 pieces of 16 lanes x 32 steps,
+ * 3 % of the fill's work for square matrices.
  */
 constexpr int kReplay = 4;
+constexpr int kPieces = 4 * kReplay;
+
+__device__ __forceinline__ int piece_group(int lane0, int d)
+{
+	const int l = lane0 - d;
+	return (l < 0 ? 0 : l) >> 4;
+}
 
 __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
-	__shared__ __attribute__((aligned(16))) uint2 tile[kReplay][kBitBlock * kLanes];
-	__shared__ __attribute__((aligned(16))) uint32_t inject[kReplay][kBitBlock];
+	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[kPieces][kBitBlock];
 	__shared__ int pos[4];
 
 	const BitJob &J = jobs[blockIdx.x];
@@ -246,7 +275,7 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
 	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
 	const uint4 *ck = reinterpret_cast<const uint4 *>(arena + J.ckpt);
-	const uint32_t *hand = reinterpret_cast<const uint32_t *>(arena + J.hand);
+	const uint32_t *marks = reinterpret_cast<const uint32_t *>(arena + J.hand);
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 	const int nb = J.steps_pad / kBitBlock;
 	int r = J.nrows, k = J.ncols;
@@ -255,12 +284,17 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	while (r > 0 && k > 0) {
 		const int w0 = (k - 1) >> 5;
 		const int s = w0 >> 6;
-		const int btop = ((r - 1) + (w0 & 63)) / kBitBlock;
-		const int b = btop - wv;                               /* this wave's block */
-		if (b >= 0) {
+		const int lane0 = w0 & 63;
+		const int btop = ((r - 1) + lane0) / kBitBlock;
+		{
+			/* this lane's piece */
+			const int d = 4 * wv + (lane >> 4);
+			const int b = btop - d < 0 ? 0 : btop - d;       /* pieces above block 0 replay block 0 and are never read */
+			const int g = piece_group(lane0, d);
+			const int sl = 16 * g + (lane & 15);               /* lane index in the strip */
 			BitState S;
 			if (b > 0) {
-				const uint4 v = ck[((size_t)s * nb + (b - 1)) * kLanes + lane];
+				const uint4 v = ck[((size_t)s * nb + (b - 1)) * kLanes + sl];
 				S.nH0 = v.x;
 				S.H1 = v.y;
 				S.H2 = v.z;
@@ -270,28 +304,40 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				S.H1 = S.H2 = 0;
 				S.PP = 0;
 			}
-			const uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
-			uint32_t word = 0;
-			const int ps = b * kBitBlock + 63 + (lane & 31);
-			if (s > 0 && ps < J.steps_pad) word = hand[(size_t)(s - 1) * J.steps_pad + ps] & 0xffffff00u;
-			const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
-			word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
-			if (lane < kBitBlock) inject[wv][lane] = word;
-			if (b < 2) bits_block<true, false, OUT_TILE>(S, B0, B1, inject[wv], nullptr, tile[wv], b * kBitBlock, lane);
-			else bits_block<false, false, OUT_TILE>(S, B0, B1, inject[wv], nullptr, tile[wv], b * kBitBlock, lane);
+			const uint32_t B0 = cp[s * kLanes + sl], B1 = cp[J.nwords_pad + s * kLanes + sl];
+			/* words entering the piece's first lane: lane j of the row prepares steps j and j + 16 */
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int t = (lane & 15) + 16 * h;
+				uint32_t word = 0;
+				if (g == 0) {
+					const int ps = b * kBitBlock + 63 + t;     /* lane 63 of the strip to the left is 63 steps ahead */
+					if (s > 0 && ps < J.steps_pad) word = marks[((size_t)(s - 1) * 4 + 3) * J.steps_pad + ps] & 0xffffff00u;
+					const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
+					word |= ((a0 >> t) & 1u) | (((a1 >> t) & 1u) << 1);
+				} else {
+					const int ps = b * kBitBlock + t - 1;      /* lane 16g-1 after the previous step */
+					if (ps >= 0) word = marks[((size_t)s * 4 + (g - 1)) * J.steps_pad + ps];
+				}
+				inject[d][t] = word;
+			}
+			const bool ramp = btop - 4 * wv - 3 < 2;            /* wave-uniform: some piece of this wave is in block 0 or 1 */
+			if (ramp) bits_block<true, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, false, tile[d], b * kBitBlock, sl);
+			else bits_block<false, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, false, tile[d], b * kBitBlock, sl);
 		}
 		__syncthreads();
 		if (wv == 0) {
 			for (;;) {
 				const int ri = r - lane, ki = k - lane;
-				uint32_t code = 3;                             /* 3 = stop: border or outside the tiles */
+				uint32_t code = 3;                             /* 3 = stop: border or outside the replayed pieces */
 				if (ri > 0 && ki > 0) {
 					const int kc = ki - 1;
 					const int wi = kc >> 5;
-					const int l = (ri - 1) + (wi & 63);
-					const int d = btop - l / kBitBlock;          /* which tile */
-					if ((wi >> 6) == s && d >= 0 && d < kReplay) {
-						const uint2 dd = tile[d][(l % kBitBlock) * kLanes + (wi & 63)];
+					const int sl = wi & 63;
+					const int l = (ri - 1) + sl;
+					const int d = btop - l / kBitBlock;
+					if ((wi >> 6) == s && d >= 0 && d < kPieces && d <= btop && (sl >> 4) == piece_group(lane0, d)) {
+						const uint2 dd = tile[d][(l % kBitBlock) * 16 + (sl & 15)];
 						const uint32_t bit = 1u << (kc & 31);
 						code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
 					}

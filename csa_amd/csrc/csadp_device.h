@@ -124,7 +124,8 @@ struct BitJob {
 	                          /*     32 columns of lane L in row (step - L).  Unused (0 bytes) in checkpoint mode         */
 	uint64_t ckpt;            /* checkpoint mode: u32 [nstrips][steps_pad/32][64][4] lane state (nH0, H1, H2, hand-off     */
 	                          /*     word) after every block of 32 steps                                                  */
-	uint64_t hand;            /* checkpoint mode: u32 [nstrips][steps_pad] hand-off word leaving lane 63 after each step   */
+	uint64_t hand;            /* checkpoint mode: u32 [nstrips][4][steps_pad] hand-off words leaving lanes 15, 31, 47 and   */
+	                          /*     63 after each step: a replay can restart at any 16-lane boundary of a strip           */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;

@@ -598,7 +598,7 @@ int FillBatch::layout_bits()
 	if (bits_ckpt_) {                              /* no direction planes: lane state per block + hand-off words */
 		dir_bytes_ = 0;
 		for (const BitJob &B : bjobs_)
-			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 + (long long)(B.nstrips - 1) * B.steps_pad * 4;
+			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 + (long long)B.nstrips * B.steps_pad * 16;
 	}
 	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
 	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
@@ -659,7 +659,7 @@ int FillBatch::layout_bits()
 			B.ckpt = off;
 			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16, 256);
 			B.hand = off;
-			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * 4, 256);
+			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * 16, 256);
 		}
 	}
 	total_bytes_ = off;
