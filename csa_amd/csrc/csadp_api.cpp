@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -34,29 +37,87 @@ std::mutex g_batch_mutex;
 FillBatch *g_batch = nullptr;
 
 /* Per-task host work (validation, table packing, traceback application, string building) is
- * independent across tasks: spread it over host threads (CSADP_HOST_THREADS, default
- * min(16, hardware threads)); n small -> run inline. */
+ * independent across tasks: spread it over a persistent pool of host threads
+ * (CSADP_HOST_THREADS, default min(16, hardware threads): more only adds allocator contention,
+ * and creating threads per call cost ~2 ms per phase, both measured); n small -> run inline. */
+class HostPool {
+public:
+	static HostPool &get()
+	{
+		static HostPool *pool = new HostPool;        /* never destroyed: workers may outlive static destructors */
+		return *pool;
+	}
+	int size() const { return nthreads_; }
+	/* run body() on all workers and on the caller, return when every one has finished */
+	void run(const std::function<void()> &body, int workers)
+	{
+		std::unique_lock<std::mutex> busy(run_mutex_);       /* one parallel region at a time */
+		{
+			std::lock_guard<std::mutex> lock(m_);
+			body_ = &body;
+			want_ = workers - 1;
+			started_ = 0;
+			done_ = 0;
+			++epoch_;
+		}
+		cv_.notify_all();
+		body();
+		std::unique_lock<std::mutex> lock(m_);
+		cv_done_.wait(lock, [&] { return done_ == want_; });
+		body_ = nullptr;
+	}
+
+private:
+	HostPool()
+	{
+		const char *e = getenv("CSADP_HOST_THREADS");
+		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
+		nthreads_ = t < 1 ? 1 : (t > 16 ? 16 : t);
+		for (int w = 1; w < nthreads_; ++w) std::thread([this] { loop(); }).detach();
+	}
+	void loop()
+	{
+		unsigned long long seen = 0;
+		for (;;) {
+			const std::function<void()> *body = nullptr;
+			{
+				std::unique_lock<std::mutex> lock(m_);
+				cv_.wait(lock, [&] { return epoch_ != seen; });
+				seen = epoch_;
+				if (started_ >= want_) continue;             /* this region needs fewer workers */
+				++started_;
+				body = body_;
+			}
+			(*body)();
+			{
+				std::lock_guard<std::mutex> lock(m_);
+				++done_;
+			}
+			cv_done_.notify_one();
+		}
+	}
+	int nthreads_ = 1;
+	std::mutex run_mutex_, m_;
+	std::condition_variable cv_, cv_done_;
+	const std::function<void()> *body_ = nullptr;
+	int want_ = 0, started_ = 0, done_ = 0;
+	unsigned long long epoch_ = 0;
+};
+
 template <class F>
 void parallel_for(int n, F &&fn)
 {
-	static const int nthreads = [] {
-		const char *e = getenv("CSADP_HOST_THREADS");
-		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
-		return t < 1 ? 1 : (t > 16 ? 16 : t);
-	}();
+	const int nthreads = HostPool::get().size();
 	const int workers = n < 4 ? 1 : (nthreads < n ? nthreads : n);
 	if (workers <= 1) {
 		for (int i = 0; i < n; ++i) fn(i);
 		return;
 	}
 	std::atomic<int> next(0);
-	auto body = [&]() {
+	const std::function<void()> body = [&]() {
 		for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
 	};
-	std::vector<std::thread> pool;
-	for (int w = 1; w < workers; ++w) pool.emplace_back(body);
-	body();
-	for (auto &t : pool) t.join();
+	HostPool::get().run(body, workers);
 }
 
 void release_cached_batch()
@@ -215,10 +276,19 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
 	std::vector<char> pending((size_t)ntasks, 0);
 	csadp_pairbatch *bp = b.get();
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto tick = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!trace) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "csadp_pairs_create: %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+		tick = now;
+	};
 	parallel_for(ntasks, [&](int t) {
 		bp->status[(size_t)t] = bp->tasks[(size_t)t].init(tasks[t]);
 		pending[(size_t)t] = (bp->status[(size_t)t] == CSADP_OK && advance(bp->tasks[(size_t)t])) ? 1 : 0;
 	});
+	lap("task init");
 	for (int t = 0; t < ntasks; ++t)
 		if (pending[(size_t)t]) b->active.push_back(t);
 	if (!b->active.empty()) {
@@ -231,6 +301,7 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 		b->fb.allow_bits(unit);
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
+		lap("layout");
 		parallel_for((int)b->active.size(), [&](int j) {
 			Progressive &p = bp->tasks[(size_t)bp->active[(size_t)j]];
 			FillBatch &fb = bp->fb;
@@ -238,8 +309,10 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 			else if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 			else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 		});
+		lap("tables");
 		if ((rc = b->fb.upload()) != CSADP_OK) return rc;
 		if ((rc = b->fb.sync()) != CSADP_OK) return rc;
+		lap("upload");
 	}
 	*out = b.release();
 	return CSADP_OK;

@@ -179,21 +179,33 @@ void Progressive::write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel,
 
 void Progressive::write_tables_bits(uint32_t *cols, int nwords, uint32_t *rows, int rowwords) const
 {
+	/* the destination is pinned staging memory: one store per finished word, no read-modify-write */
 	const int ncols = consensus_;
-	for (int k = 1; k <= ncols; ++k) {
-		const int *col = &sv_[(size_t)k * kSym];
-		int c = 0;
-		while (c < 3 && col[c] == 0) ++c;                 /* the one letter of this column */
-		const int w = (k - 1) >> 5, b = (k - 1) & 31;
-		cols[w] |= (uint32_t)(c & 1) << b;
-		cols[nwords + w] |= (uint32_t)(c >> 1) << b;
+	for (int w = 0; w * 32 < ncols; ++w) {
+		uint32_t p0 = 0, p1 = 0;
+		const int kend = std::min(ncols, 32 * w + 32);
+		for (int k = 32 * w + 1; k <= kend; ++k) {
+			const int *col = &sv_[(size_t)k * kSym];
+			int c = 0;
+			while (c < 3 && col[c] == 0) ++c;             /* the one letter of this column */
+			p0 |= (uint32_t)(c & 1) << ((k - 1) & 31);
+			p1 |= (uint32_t)(c >> 1) << ((k - 1) & 31);
+		}
+		cols[w] = p0;
+		cols[nwords + w] = p1;
 	}
 	const int n = order_[step_];
 	const int start = starts_[n];
-	for (int j = 0; j < nrows_; ++j) {
-		const int c = code_of(char_at(start + j, n));
-		rows[j >> 5] |= (uint32_t)(c & 1) << (j & 31);
-		rows[rowwords + (j >> 5)] |= (uint32_t)(c >> 1) << (j & 31);
+	for (int w = 0; w * 32 < nrows_; ++w) {
+		uint32_t p0 = 0, p1 = 0;
+		const int jend = std::min(nrows_, 32 * w + 32);
+		for (int j = 32 * w; j < jend; ++j) {
+			const int c = code_of(char_at(start + j, n));
+			p0 |= (uint32_t)(c & 1) << (j & 31);
+			p1 |= (uint32_t)(c >> 1) << (j & 31);
+		}
+		rows[w] = p0;
+		rows[rowwords + w] = p1;
 	}
 }
 
