@@ -42,8 +42,11 @@ constexpr uint32_t LA = 0xF0, LB = 0xCC, LC = 0xAA;
 template <bool ROWS>
 __device__ __forceinline__ uint32_t from_left(uint32_t old, uint32_t src)
 {
-	if (ROWS) return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x111, 0xf, 0xf, false);   /* row_shr:1 */
-	return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)src, 0x138, 0xf, 0xf, false);             /* wave_shr:1 */
+	/* written as the instruction itself so that the register holding `old` IS the destination
+	 * (the builtin costs a v_mov plus two wait states per step) */
+	if (ROWS) asm("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+	else asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+	return old;
 }
 
 /*
@@ -73,19 +76,16 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 	constexpr bool ROWS = (OUT == OUT_TILE);
 	constexpr int ostride = ROWS ? 16 : kLanes;
 	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15);
-	/* all 32 words entering lane 0 are fetched up front: no LDS latency inside the step chain */
-	uint32_t inj[kBitBlock];
-#pragma unroll
-	for (int t = 0; t < kBitBlock; t += 4) {
-		const uint4 v = *reinterpret_cast<const uint4 *>(inject + t);
-		inj[t] = v.x;
-		inj[t + 1] = v.y;
-		inj[t + 2] = v.z;
-		inj[t + 3] = v.w;
-	}
+	/* the word entering the row's first lane is fetched from LDS one step ahead, straight into the
+	 * register the DPP move then completes (address kept in a VGPR) */
+	uint32_t ioff = 0;
+	asm volatile("" : "+v"(ioff));
+	uint32_t cur = inject[ioff];
 #pragma unroll
 	for (int t = 0; t < kBitBlock; ++t) {
-		const uint32_t in = from_left<ROWS>(inj[t], S.PP);
+		const uint32_t nxt = inject[ioff + (t + 1 < kBitBlock ? t + 1 : t)];
+		const uint32_t in = from_left<ROWS>(cur, S.PP);
+		cur = nxt;
 		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 0, 1);
 		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 1, 1);
 		const uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
@@ -114,6 +114,15 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 		const uint32_t O0 = BITOP3(w, nE, nH0, LA | (LB & LC));
 		const uint32_t G0 = __builtin_amdgcn_alignbit(O0, in, 31);             /* (O0 << 1) | carry */
 
+		/* hand-off word for the right neighbour, early: the next step's DPP read then has the rest
+		 * of this step between it and the write (no wait states) */
+		const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);         /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
+		const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);         /* byte 3 <- O0 byte 3 */
+		S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
+		if (FEEDS) {
+			if (writes) lanebuf[t] = S.PP;                     /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks of this block */
+		}
+
 		/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
 		const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
 		const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
@@ -128,12 +137,6 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 			out[t * ostride] = make_uint2(notdiag, left);
 		}
 
-		const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);         /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
-		const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);         /* byte 3 <- O0 byte 3 */
-		S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
-		if (FEEDS) {
-			if (writes) lanebuf[t] = S.PP;                     /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks of this block */
-		}
 		if (RAMPIN) {
 			const uint32_t live = (l0 + t >= lane) ? ~0u : 0u;
 			nT0 |= ~live;
