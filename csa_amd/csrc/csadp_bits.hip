@@ -247,6 +247,114 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 }
 
 /*
+ * K1b for jobs wider than one workgroup (more than 16 strips; checkpoint mode only): the same
+ * step function, strips taken in chunks of 16 -- all rows of a chunk, then the next chunk, whose
+ * first strip reads the recorded hand-off words of the last strip of the chunk before (stream 3
+ * of the marks) instead of an LDS ring.  Kept apart from nw_fill_bits: the extra loop level costs
+ * the common case 7 % (measured).
+ */
+__global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8_t *__restrict__ arena,
+                                                                      const BitJob *__restrict__ jobs,
+                                                                      int *__restrict__ abort_word)
+{
+	constexpr bool CKPT = true;
+	constexpr int OUT = OUT_NONE;
+	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
+	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
+	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
+	__shared__ int dead;
+	const BitJob &J = jobs[blockIdx.x];
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+	const int nwaves = (int)(blockDim.x >> 6);
+	const int nb = J.steps_pad / kBitBlock;
+	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
+	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
+	if (threadIdx.x == 0) dead = 0;
+
+	/* Jobs wider than the workgroup (checkpoint mode only) are done in chunks of nwaves strips:
+	 * all rows of a chunk, then the next chunk, whose first strip reads the recorded hand-off
+	 * words of the last strip of the chunk before (stream 3 of the marks) instead of the ring. */
+	for (int c0 = 0; c0 < J.nstrips; c0 += nwaves) {
+		if (threadIdx.x < kBitMaxStrips) {
+			made[threadIdx.x] = 0;
+			taken[threadIdx.x] = 0;
+		}
+		__syncthreads();
+		const int s = c0 + wv;                                 /* this wave's strip */
+		bool ok = s < J.nstrips && dead == 0;
+		if (ok) {
+			const uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
+			uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
+			const bool feeds = wv + 1 < nwaves && s + 1 < J.nstrips;      /* a wave of this chunk reads my ring */
+			const bool records = CKPT && s + 1 < J.nstrips;                /* lane 63's words are needed later */
+			/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
+			 * LDS and copied out once per block as four streams [4][steps_pad] per strip */
+			uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad : nullptr;
+			const uint32_t *left_marks = (CKPT && wv == 0 && s > 0)
+			    ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
+			const bool writes = (lane == kLanes - 1) ? (feeds || records) : (CKPT && (lane & 15) == 15);
+
+			BitState S;
+			S.nH0 = ~0u;
+			S.H1 = S.H2 = 0;
+			S.PP = 0;
+			for (int b = 0; b < nb && ok; ++b) {
+				/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
+				 * the producer's step 32b + t + 63, row letter of row 32b + t */
+				uint32_t word = 0;
+				const int ps = b * kBitBlock + 63 + (lane & 31);
+				if (wv > 0) {
+					const int need = (b + 3 < nb) ? b + 3 : nb;         /* producer steps up to 32b + 94 */
+					if (!wait_at_least(&made[wv - 1], need)) { ok = false; break; }
+					if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				} else if (left_marks != nullptr) {
+					if (ps < J.steps_pad) word = left_marks[ps] & 0xffffff00u;
+				}
+				const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
+				word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
+				if (lane < kBitBlock) inject[wv][lane] = word;
+				uint32_t *lanebuf = (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
+				if (feeds) {
+					/* the ring slots of this block last held block b - kRing, whose words the consumer
+					 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
+					if (!wait_at_least(&taken[wv + 1], b - kRing)) { ok = false; break; }
+				}
+				if (feeds || CKPT) {
+					if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[wv], lanebuf, writes, dirs, b * kBitBlock, lane);
+					else bits_block<false, true, OUT>(S, B0, B1, inject[wv], lanebuf, writes, dirs, b * kBitBlock, lane);
+				} else {
+					if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[wv], nullptr, false, dirs, b * kBitBlock, lane);
+					else bits_block<false, false, OUT>(S, B0, B1, inject[wv], nullptr, false, dirs, b * kBitBlock, lane);
+				}
+				if (CKPT) {
+					/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
+					const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
+					marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
+					marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
+					    (g == 0) ? mbuf[wv][2][t] : ((feeds || records) ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u);
+					reinterpret_cast<uint4 *>(arena + J.ckpt)[((size_t)s * nb + b) * kLanes + lane] = make_uint4(S.nH0, S.H1, S.H2, S.PP);
+				}
+				if (feeds) {
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+					if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+				}
+			}
+			if (!ok) {                                           /* a wait timed out: fail the batch, let the others run out */
+				if (lane == 0) {
+					atomicExch(abort_word, 1);
+					dead = 1;
+				}
+			}
+		}
+		__threadfence();                                         /* the marks of this chunk must be visible to the next one */
+		__syncthreads();
+	}
+}
+
+/*
  * K2c.  Traceback in checkpoint mode: no direction planes exist in HBM.  A round starts at the
  * current cell, in block `btop` (32 steps) of strip s, lane L.  Going up its diagonal the path
  * reaches block btop-d around lane L-d, so piece d = (block btop-d, the 16-lane group holding lane
@@ -472,12 +580,14 @@ __global__ __launch_bounds__(64) void nw_traceback_bits(uint8_t *__restrict__ ar
 	}
 }
 
-hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
-                            hipStream_t st)
+hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, bool wide,
+                            int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
 	if (maxstrips < 1 || maxstrips > kBitMaxStrips) return hipErrorInvalidValue;
-	if (checkpoints) hipLaunchKernelGGL(nw_fill_bits<true>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
+	if (checkpoints && wide) hipLaunchKernelGGL(nw_fill_bits_wide, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
+	else if (wide) return hipErrorInvalidValue;
+	else if (checkpoints) hipLaunchKernelGGL(nw_fill_bits<true>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
 	else hipLaunchKernelGGL(nw_fill_bits<false>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
 	return hipGetLastError();
 }

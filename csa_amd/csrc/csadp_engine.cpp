@@ -174,8 +174,14 @@ int FillBatch::layout()
 	bits_ = false;
 	if (bits_allowed_ && nj >= 1 && env_int("CSADP_BITS", 1) != 0) {
 		bits_ = true;
-		for (const FillJob &J : jobs_)
-			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0 || J.ncols > kBitMaxStrips * kLanes * 32) bits_ = false;
+		bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
+		for (const FillJob &J : jobs_) {
+			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) bits_ = false;
+			/* more than 16 strips: one workgroup takes them in chunks (checkpoint mode only).  That is
+			 * one workgroup per matrix however wide it is, so with few jobs the tiled kernels, which
+			 * spread a matrix over the chip, are faster (8 x 100 kbp: 42 vs 76 ms, measured) */
+			if (J.ncols > kBitMaxStrips * kLanes * 32 && (!bits_ckpt_ || nj < 32)) bits_ = false;
+		}
 	}
 	if (bits_) return layout_bits();
 	if (nj >= 2 && C == 16 && R <= 2 && env_int("CSADP_PK16", 1) != 0) {
@@ -578,6 +584,7 @@ int FillBatch::layout_bits()
 	tiles_.clear();
 	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
 	bits_maxstrips_ = 1;
+	bits_wide_ = false;
 	for (int j = 0; j < nj; ++j) {
 		const FillJob &J = jobs_[(size_t)j];
 		BitJob &B = bjobs_[(size_t)j];
@@ -589,7 +596,8 @@ int FillBatch::layout_bits()
 		B.nwords_pad = B.nstrips * kLanes;
 		B.steps_pad = (int)align_up((size_t)J.nrows + 64, kBitBlock);
 		B.rowwords = B.steps_pad / 32;
-		bits_maxstrips_ = std::max(bits_maxstrips_, B.nstrips);
+		bits_maxstrips_ = std::max(bits_maxstrips_, std::min(B.nstrips, kBitMaxStrips));
+		if (B.nstrips > kBitMaxStrips) bits_wide_ = true;
 		extra_[(size_t)j].ncols_pad = B.nwords_pad * 32;
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)J.nrows * words * 8;
@@ -777,7 +785,7 @@ int FillBatch::flush_bits(int k)
 		const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
 		HIP_TRY(hipEventRecord(ev[0], st));
 		HIP_TRY(hipMemsetAsync(arena_ + flags_off_[first], 0, flags_bytes_, st));
-		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
+		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, bits_wide_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
 		HIP_TRY(hipEventRecord(ev[1], st));
 		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, st));
 		HIP_TRY(hipEventRecord(ev[2], st));

@@ -126,7 +126,7 @@ private:
 	int finish_layout();             /* arena / staging allocation shared by the layouts */
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
-	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false;
+	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false;
 	int bits_maxstrips_ = 1;
 	int run_slot(int sl, bool persistent);
 	int run_merged(int npasses);

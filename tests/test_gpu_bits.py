@@ -72,20 +72,26 @@ def test_many_strips_few_rows_and_few_strips_many_rows(bits_mode):
     check(tasks)
 
 
-def test_sixteen_strips_and_the_fallback_beyond(bits_mode):
-    """32768 columns = 16 waves in one workgroup (the maximum); 32769+ columns leave the
-    bit-parallel path (tiled kernels) inside the same call sequence."""
+def test_sixteen_strips_and_beyond(bits_mode):
+    """32768 columns = 16 waves in one workgroup.  Wider jobs: in a batch of 32 or more jobs and
+    checkpoint mode they run bit-parallel in chunks of 16 strips (the first strip of a chunk reads
+    the recorded hand-off words of the chunk before); otherwise on the tiled kernels."""
     r = rng(103)
-    for cols in (32768, 32800):
+
+    def wide_task(cols):
         a, b = related(r, cols + 40, None, sub=0.05, indel=0.005)
         b = (b + bytes(r.choice(b"ACGT") for _ in range(cols)))[:cols]
-        rows = a[:600] + a[-600:]                       # 1200 rows against a 32 k profile: large drift
-        got = csa_amd.align_batch([([rows, b], None, None, None)])[0]
-        assert got["status"] == 0
-        assert degap(got["aligned"][0]) == rows and degap(got["aligned"][1]) == b
-        assert got["score"] == sp_score(got["aligned"])
-        cons, strs, st = oracle_progressive([rows, b], None)
-        assert got["aligned"] == strs and got["score"] == st.last_score
+        rows = a[:600] + a[-600:]                       # 1200 rows against a wide profile: large drift
+        return ([rows, b], None, None, None)
+
+    for cols in (32768, 32800):
+        check([wide_task(cols)])
+    # 32 jobs, two of them wider than one workgroup
+    small = []
+    for n in range(30):
+        a, b = related(r, 300 + 37 * n, None)
+        small.append(([a, b], None, None, None))
+    check([wide_task(70001)] + small + [wide_task(33000)])
 
 
 def test_paths_that_leave_the_diagonal(bits_mode):
