@@ -155,3 +155,49 @@ def test_first_step_of_families_uses_unit_borders_only():
         assert g["status"] == 0 and g["aligned"] == strs
         for s, row in zip(t[0], g["aligned"]):
             assert degap(row) in (rotated(s, t[1][t[0].index(s)]),)
+
+
+def _properties(tasks, got):
+    for t, g in zip(tasks, got):
+        assert g["status"] == 0
+        rots = t[1] or [0, 0]
+        assert degap(g["aligned"][0]) == rotated(t[0][0], rots[0])
+        assert degap(g["aligned"][1]) == rotated(t[0][1], rots[1])
+        assert len(g["aligned"][0]) == len(g["aligned"][1]) == g["consensus"]
+        assert g["score"] == sp_score(g["aligned"])
+
+
+def test_thousands_of_small_jobs_in_one_batch(bits_mode):
+    """4096 pairs of ~400 letters: one single-wave workgroup each, 4096 replay workgroups."""
+    r = rng(108)
+    base = bytes(r.choice(b"ACGT") for _ in range(6000))
+    tasks = []
+    for i in range(4096):
+        o = r.randrange(5000)
+        a = base[o:o + 350 + i % 97]
+        b = bytearray(a)
+        for _ in range(len(a) // 12):
+            b[r.randrange(len(b))] = r.choice(b"ACGT")
+        del b[10:10 + i % 7]
+        tasks.append(([a, bytes(b)], None, None, None))
+    pb = csa_amd.PairBatch(tasks)
+    for _ in range(5):
+        pb.run()
+    got = pb.fetch()
+    pb.close()
+    _properties(tasks, got)
+    cons, strs, st = oracle_progressive(tasks[77][0], None)
+    assert got[77]["aligned"] == strs and got[77]["score"] == st.last_score
+
+
+def test_extreme_aspect_ratios(bits_mode):
+    r = rng(109)
+    long = bytes(r.choice(b"ACGT") for _ in range(150000))
+    tasks = [
+        ([long, long[70000:70016]], None, None, None),      # 16 columns x 150 k rows: 4690 blocks, one strip
+        ([long[:9], long[:120000]], None, None, None),      # 9 columns again (the shorter one is the profile)
+        ([long[:1], long[5:6]], None, None, None),
+        ([long[:40000], long[100:40100]], None, None, None),   # 40 k x 40 k: 20 strips, tiled kernels (1 wide job)
+    ]
+    got = csa_amd.align_batch(tasks)
+    _properties(tasks, got)
