@@ -62,7 +62,9 @@ struct BitState {
 /* 32 steps.  inject[t] is the hand-off word entering lane 0 at step t; ringout (lane 63 of a strip
  * that has a right neighbour) receives the word leaving the strip.  RAMPIN: lanes whose row index
  * is still negative keep an empty row above.
- * FEEDS: lanes with `writes` store their hand-off word of step t to lanebuf[t] (LDS, per lane).
+ * FEEDS: every lane stores its hand-off word of step t to lanebuf[t] (LDS; a per-lane pointer
+ * that is the ring / the marks buffer for the lanes that matter and a shared scrap row for the
+ * rest -- no EXEC juggling in the step).
  * OUT_GLOBAL: dirs = this strip's direction planes in HBM.  OUT_TILE (replay): the wave is four
  * independent 16-lane pieces of strips (DPP stays inside a row, `inject` is per lane and only
  * the first lane of a row uses it, `lane` is the lane's index in its strip) and dirs = the
@@ -71,7 +73,7 @@ enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
 
 template <bool RAMPIN, bool FEEDS, int OUT>
 __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1, const uint32_t *inject,
-                                           uint32_t *lanebuf, bool writes, uint2 *dirs, int l0, int lane)
+                                           uint32_t *lanebuf, uint2 *dirs, int l0, int lane)
 {
 	constexpr bool ROWS = (OUT == OUT_TILE);
 	constexpr int ostride = ROWS ? 16 : kLanes;
@@ -119,9 +121,7 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 		const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);         /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
 		const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);         /* byte 3 <- O0 byte 3 */
 		S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
-		if (FEEDS) {
-			if (writes) lanebuf[t] = S.PP;                     /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks of this block */
-		}
+		if (FEEDS) lanebuf[t] = S.PP;                          /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks of this block, all others -> a scrap row */
 
 		/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
 		const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
+	__shared__ uint32_t scrap[kBitMaxStrips][kBitBlock];
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	const BitJob &J = jobs[blockIdx.x];
 	const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -218,18 +219,18 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[s][lane] = word;
-		uint32_t *lanebuf = (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
+		uint32_t *lanebuf = !writes ? &scrap[s][0] : (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
 			if (!wait_at_least(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
 		if (feeds || CKPT) {
-			if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[s], lanebuf, writes, dirs, b * kBitBlock, lane);
-			else bits_block<false, true, OUT>(S, B0, B1, inject[s], lanebuf, writes, dirs, b * kBitBlock, lane);
+			if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
+			else bits_block<false, true, OUT>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
 		} else {
-			if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[s], nullptr, false, dirs, b * kBitBlock, lane);
-			else bits_block<false, false, OUT>(S, B0, B1, inject[s], nullptr, false, dirs, b * kBitBlock, lane);
+			if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
+			else bits_block<false, false, OUT>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
 		}
 		if (CKPT) {
 			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring (strips that feed) */
@@ -262,6 +263,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
+	__shared__ uint32_t scrap[kBitMaxStrips][kBitBlock];
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	__shared__ int dead;
 	const BitJob &J = jobs[blockIdx.x];
@@ -316,18 +318,18 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 				const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
 				word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 				if (lane < kBitBlock) inject[wv][lane] = word;
-				uint32_t *lanebuf = (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
+				uint32_t *lanebuf = !writes ? &scrap[wv][0] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
 				if (feeds) {
 					/* the ring slots of this block last held block b - kRing, whose words the consumer
 					 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
 					if (!wait_at_least(&taken[wv + 1], b - kRing)) { ok = false; break; }
 				}
 				if (feeds || CKPT) {
-					if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[wv], lanebuf, writes, dirs, b * kBitBlock, lane);
-					else bits_block<false, true, OUT>(S, B0, B1, inject[wv], lanebuf, writes, dirs, b * kBitBlock, lane);
+					if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
+					else bits_block<false, true, OUT>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
 				} else {
-					if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[wv], nullptr, false, dirs, b * kBitBlock, lane);
-					else bits_block<false, false, OUT>(S, B0, B1, inject[wv], nullptr, false, dirs, b * kBitBlock, lane);
+					if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
+					else bits_block<false, false, OUT>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
 				}
 				if (CKPT) {
 					/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
@@ -433,8 +435,8 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				inject[d][t] = word;
 			}
 			const bool ramp = btop - 4 * wv - 3 < 2;            /* wave-uniform: some piece of this wave is in block 0 or 1 */
-			if (ramp) bits_block<true, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, false, tile[d], b * kBitBlock, sl);
-			else bits_block<false, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, false, tile[d], b * kBitBlock, sl);
+			if (ramp) bits_block<true, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
+			else bits_block<false, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
 		}
 		__syncthreads();
 		if (wv == 0) {
