@@ -54,10 +54,14 @@ __device__ __forceinline__ uint32_t from_left(uint32_t old, uint32_t src)
  *   bit 31 / 23 / 15  top bit of the outgoing vertical-step planes ">= 0" / ">= 1" / ">= 2"
  *   bits 1..0          letter of the row both lanes are working on (the right lane is one step behind)
  */
+template <int W>            /* W words of 32 columns per lane */
 struct BitState {
-	uint32_t nH0, H1, H2;    /* horizontal steps of the row above: NOT ">= 0", ">= 1", ">= 2" */
-	uint32_t PP;             /* hand-off word of the previous step */
+	uint32_t nH0[W], H1[W], H2[W];   /* horizontal steps of the row above: NOT ">= 0", ">= 1", ">= 2" */
+	uint32_t PP;                     /* hand-off word of the previous step */
 };
+
+/* words per lane in checkpoint mode (csadp_device.h); always 1 with direction planes in HBM */
+constexpr int kCkptWords = kBitCkptWords;
 
 /* 32 steps.  inject[t] is the hand-off word entering lane 0 at step t; ringout (lane 63 of a strip
  * that has a right neighbour) receives the word leaving the strip.  RAMPIN: lanes whose row index
@@ -71,13 +75,14 @@ struct BitState {
  * row's [32][16] tile. */
 enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
 
-template <bool RAMPIN, bool FEEDS, int OUT>
-__device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1, const uint32_t *inject,
+template <bool RAMPIN, bool FEEDS, int OUT, int W>
+__device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[W], const uint32_t (&B1)[W], const uint32_t *inject,
                                            uint32_t *lanebuf, uint2 *dirs, int l0, int lane)
 {
+	static_assert(OUT != OUT_GLOBAL || W == 1, "direction planes in HBM are laid out for one word per lane");
 	constexpr bool ROWS = (OUT == OUT_TILE);
 	constexpr int ostride = ROWS ? 16 : kLanes;
-	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15);
+	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15) * W;
 	/* the word entering the row's first lane is fetched from LDS one step ahead, straight into the
 	 * register the DPP move then completes (address kept in a VGPR) */
 	uint32_t ioff = 0;
@@ -90,62 +95,100 @@ __device__ __forceinline__ void bits_block(BitState &S, uint32_t B0, uint32_t B1
 		cur = nxt;
 		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 0, 1);
 		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 1, 1);
-		const uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
-		const uint32_t c1 = __builtin_amdgcn_ubfe(in, 23, 1);
-		const uint32_t nH0 = S.nH0, H1 = S.H1, H2 = S.H2;
-		const uint32_t x0 = B0 ^ R0;
-		const uint32_t nE = BITOP3(x0, B1, R1, LA | (LB ^ LC));                 /* 1 = mismatch */
+		uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
+		uint32_t c1 = __builtin_amdgcn_ubfe(in, 23, 1);
+		uint32_t below = in;                                  /* its bit 31 enters the ">= 0" plane */
+		uint32_t O0 = 0, O1 = 0, O2 = 0;
+		[[maybe_unused]] const uint32_t live = RAMPIN ? ((l0 + t >= lane) ? ~0u : 0u) : ~0u;
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			const uint32_t nH0 = S.nH0[h], H1 = S.H1[h], H2 = S.H2[h];
+			const uint32_t x0 = B0[h] ^ R0;
+			const uint32_t nE = BITOP3(x0, B1[h], R1, LA | (LB ^ LC));          /* 1 = mismatch */
 
-		/* vertical step >= 2: generated by a match over w = -1, carried through mismatches over w = -1 */
-		const uint32_t g2 = BITOP3(nE, nH0, nH0, ~LA & LB);
-		const uint32_t s2 = nH0 + g2 + c2;
-		const uint32_t G2 = BITOP3(s2, nH0, g2, LA ^ LB ^ LC);                 /* incoming: u >= 2 */
-		const uint32_t O2 = BITOP3(g2, nH0, G2, LA | (LB & LC));               /* outgoing */
+			/* vertical step >= 2: generated by a match over w = -1, carried through mismatches over w = -1 */
+			const uint32_t g2 = BITOP3(nE, nH0, nH0, ~LA & LB);
+			const uint32_t s2 = nH0 + g2 + c2;
+			const uint32_t G2 = BITOP3(s2, nH0, g2, LA ^ LB ^ LC);             /* incoming: u >= 2 */
+			O2 = BITOP3(g2, nH0, G2, LA | (LB & LC));                         /* outgoing */
 
-		/* >= 1: match over w <= 0, or mismatch over w = 0 with u >= 2; carried over w = -1 */
-		const uint32_t t1 = BITOP3(nE, nH0, G2, ~LA | (~LB & LC));
-		const uint32_t g1 = BITOP3(t1, H1, H1, LA & ~LB);
-		const uint32_t A1 = BITOP3(g1, nE, nH0, LA | (LB & LC));
-		const uint32_t s1 = A1 + g1 + c1;
-		const uint32_t G1 = BITOP3(s1, A1, g1, LA ^ LB ^ LC);
-		const uint32_t O1 = BITOP3(g1, A1, G1, LA | (LB & LC));
+			/* >= 1: match over w <= 0, or mismatch over w = 0 with u >= 2; carried over w = -1 */
+			const uint32_t t1 = BITOP3(nE, nH0, G2, ~LA | (~LB & LC));
+			const uint32_t g1 = BITOP3(t1, H1, H1, LA & ~LB);
+			const uint32_t A1 = BITOP3(g1, nE, nH0, LA | (LB & LC));
+			const uint32_t s1 = A1 + g1 + c1;
+			const uint32_t G1 = BITOP3(s1, A1, g1, LA ^ LB ^ LC);
+			O1 = BITOP3(g1, A1, G1, LA | (LB & LC));
 
-		/* >= 0: no chain.  match: w <= 1; mismatch: w = -1, or w = 0 and u >= 1, or w = 1 and u >= 2 */
-		const uint32_t v = BITOP3(H1, G2, G1, (LA & LB) | (~LA & LC));
-		const uint32_t w = BITOP3(nE, v, H2, ~LC & (~LA | LB));
-		const uint32_t O0 = BITOP3(w, nE, nH0, LA | (LB & LC));
-		const uint32_t G0 = __builtin_amdgcn_alignbit(O0, in, 31);             /* (O0 << 1) | carry */
+			/* >= 0: no chain.  match: w <= 1; mismatch: w = -1, or w = 0 and u >= 1, or w = 1 and u >= 2 */
+			const uint32_t v = BITOP3(H1, G2, G1, (LA & LB) | (~LA & LC));
+			const uint32_t w = BITOP3(nE, v, H2, ~LC & (~LA | LB));
+			O0 = BITOP3(w, nE, nH0, LA | (LB & LC));
+			const uint32_t G0 = __builtin_amdgcn_alignbit(O0, below, 31);        /* (O0 << 1) | carry */
+			if (h == W - 1) {
+				/* hand-off word for the right neighbour (top bits of the last word's outgoing planes),
+				 * early: the rest of the step lies between this write and the next step's DPP read */
+				const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);      /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
+				const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);      /* byte 3 <- O0 byte 3 */
+				S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
+				if (FEEDS) lanebuf[t] = S.PP;                       /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks, all others -> a scrap row */
+			}
 
-		/* hand-off word for the right neighbour, early: the next step's DPP read then has the rest
-		 * of this step between it and the write (no wait states) */
-		const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);         /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
-		const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);         /* byte 3 <- O0 byte 3 */
-		S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
-		if (FEEDS) lanebuf[t] = S.PP;                          /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks of this block, all others -> a scrap row */
-
-		/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
-		const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
-		const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
-		uint32_t T2 = BITOP3(C1, G0, G0, LA & ~LB);
-		const uint32_t a1 = BITOP3(C1, G1, G1, LA & ~LB);
-		uint32_t T1 = BITOP3(G0, a1, C0, (LA & LB) | (~LA & LC));
-		const uint32_t b0 = BITOP3(C0, G1, G0, LC & (~LA | LB));
-		uint32_t nT0 = BITOP3(b0, C1, G2, LA & (~LB | LC));
-		if (OUT != OUT_NONE) {
-			const uint32_t notdiag = C0 & nE;
-			const uint32_t left = notdiag & nT0;
-			out[t * ostride] = make_uint2(notdiag, left);
+			/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
+			const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
+			const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
+			uint32_t T2 = BITOP3(C1, G0, G0, LA & ~LB);
+			const uint32_t a1 = BITOP3(C1, G1, G1, LA & ~LB);
+			uint32_t T1 = BITOP3(G0, a1, C0, (LA & LB) | (~LA & LC));
+			const uint32_t b0 = BITOP3(C0, G1, G0, LC & (~LA | LB));
+			uint32_t nT0 = BITOP3(b0, C1, G2, LA & (~LB | LC));
+			if (OUT != OUT_NONE) {
+				const uint32_t notdiag = C0 & nE;
+				const uint32_t left = notdiag & nT0;
+				out[t * ostride * W + h] = make_uint2(notdiag, left);
+			}
+			if (RAMPIN) {
+				nT0 |= ~live;
+				T1 &= live;
+				T2 &= live;
+			}
+			S.nH0[h] = nT0;
+			S.H1[h] = T1;
+			S.H2[h] = T2;
+			if (h + 1 < W) {                                       /* carries into the lane's next word */
+				c2 = O2 >> 31;
+				c1 = O1 >> 31;
+				below = O0;
+			}
 		}
+	}
+}
 
-		if (RAMPIN) {
-			const uint32_t live = (l0 + t >= lane) ? ~0u : 0u;
-			nT0 |= ~live;
-			T1 &= live;
-			T2 &= live;
-		}
-		S.nH0 = nT0;
-		S.H1 = T1;
-		S.H2 = T2;
+/* lane state in the checkpoint array: W = 1: one uint4 (3 planes + hand-off word); W = 2: two */
+template <int W>
+__device__ __forceinline__ void save_state(uint4 *ck, size_t idx, const BitState<W> &S)
+{
+	if (W == 1) {
+		ck[idx] = make_uint4(S.nH0[0], S.H1[0], S.H2[0], S.PP);
+	} else {
+		ck[idx * 2] = make_uint4(S.nH0[0], S.H1[0], S.H2[0], S.PP);
+		ck[idx * 2 + 1] = make_uint4(S.nH0[W - 1], S.H1[W - 1], S.H2[W - 1], 0u);
+	}
+}
+
+template <int W>
+__device__ __forceinline__ void load_state(const uint4 *ck, size_t idx, BitState<W> &S)
+{
+	const uint4 v = ck[idx * W];
+	S.nH0[0] = v.x;
+	S.H1[0] = v.y;
+	S.H2[0] = v.z;
+	S.PP = v.w;
+	if (W > 1) {
+		const uint4 u = ck[idx * W + 1];
+		S.nH0[W - 1] = u.x;
+		S.H1[W - 1] = u.y;
+		S.H2[W - 1] = u.z;
 	}
 }
 
@@ -175,6 +218,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
                                                                       int *__restrict__ abort_word)
 {
 	constexpr int OUT = CKPT ? OUT_NONE : OUT_GLOBAL;
+	constexpr int W = CKPT ? kCkptWords : 1;
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
@@ -191,7 +235,12 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 
 	const int nb = J.steps_pad / kBitBlock;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
-	const uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
+	uint32_t B0[W], B1[W];
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		B0[h] = cp[(s * kLanes + lane) * W + h];
+		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
+	}
 	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
 	uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
 	const bool feeds = s + 1 < J.nstrips;
@@ -200,9 +249,12 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 	uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad : nullptr;
 	const bool writes = (lane == kLanes - 1) ? feeds : (CKPT && (lane & 15) == 15);
 
-	BitState S;
-	S.nH0 = ~0u;
-	S.H1 = S.H2 = 0;
+	BitState<W> S;
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		S.nH0[h] = ~0u;
+		S.H1[h] = S.H2[h] = 0;
+	}
 	S.PP = 0;
 	for (int b = 0; b < nb; ++b) {
 		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
@@ -226,11 +278,11 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 			if (!wait_at_least(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
 		if (feeds || CKPT) {
-			if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
-			else bits_block<false, true, OUT>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
+			if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
+			else bits_block<false, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
 		} else {
-			if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
-			else bits_block<false, false, OUT>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
+			if (b < 2) bits_block<true, false, OUT, W>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
+			else bits_block<false, false, OUT, W>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
 		}
 		if (CKPT) {
 			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring (strips that feed) */
@@ -238,7 +290,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[s][g][t];
 			marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
 			    (g == 0) ? mbuf[s][2][t] : (feeds ? ring[s][(b * kBitBlock + t) % kRingSteps] : 0u);
-			reinterpret_cast<uint4 *>(arena + J.ckpt)[((size_t)s * nb + b) * kLanes + lane] = make_uint4(S.nH0, S.H1, S.H2, S.PP);
+			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
 		if (feeds) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -260,6 +312,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 {
 	constexpr bool CKPT = true;
 	constexpr int OUT = OUT_NONE;
+	constexpr int W = kCkptWords;
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
@@ -286,8 +339,13 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 		const int s = c0 + wv;                                 /* this wave's strip */
 		bool ok = s < J.nstrips && dead == 0;
 		if (ok) {
-			const uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
-			uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
+			uint32_t B0[W], B1[W];
+#pragma unroll
+			for (int h = 0; h < W; ++h) {
+				B0[h] = cp[(s * kLanes + lane) * W + h];
+				B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
+			}
+			uint2 *dirs = nullptr;
 			const bool feeds = wv + 1 < nwaves && s + 1 < J.nstrips;      /* a wave of this chunk reads my ring */
 			const bool records = CKPT && s + 1 < J.nstrips;                /* lane 63's words are needed later */
 			/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
@@ -297,9 +355,12 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 			    ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
 			const bool writes = (lane == kLanes - 1) ? (feeds || records) : (CKPT && (lane & 15) == 15);
 
-			BitState S;
-			S.nH0 = ~0u;
-			S.H1 = S.H2 = 0;
+			BitState<W> S;
+#pragma unroll
+			for (int h = 0; h < W; ++h) {
+				S.nH0[h] = ~0u;
+				S.H1[h] = S.H2[h] = 0;
+			}
 			S.PP = 0;
 			for (int b = 0; b < nb && ok; ++b) {
 				/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
@@ -325,11 +386,11 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 					if (!wait_at_least(&taken[wv + 1], b - kRing)) { ok = false; break; }
 				}
 				if (feeds || CKPT) {
-					if (b < 2) bits_block<true, true, OUT>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
-					else bits_block<false, true, OUT>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
+					if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
+					else bits_block<false, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
 				} else {
-					if (b < 2) bits_block<true, false, OUT>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
-					else bits_block<false, false, OUT>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
+					if (b < 2) bits_block<true, false, OUT, W>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
+					else bits_block<false, false, OUT, W>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
 				}
 				if (CKPT) {
 					/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
@@ -337,7 +398,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 					marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
 					marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
 					    (g == 0) ? mbuf[wv][2][t] : ((feeds || records) ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u);
-					reinterpret_cast<uint4 *>(arena + J.ckpt)[((size_t)s * nb + b) * kLanes + lane] = make_uint4(S.nH0, S.H1, S.H2, S.PP);
+					save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 				}
 				if (feeds) {
 					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -367,18 +428,19 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
  * until the path leaves them.  Replay work: ~(nrows + ncols) / 31 pieces of 16 lanes x 32 steps,
  * 3 % of the fill's work for square matrices.
  */
-constexpr int kReplay = 4;
+constexpr int kReplay = kBitCkptWords == 1 ? 4 : 2;   /* waves: 64 KB of LDS tiles either way */
 constexpr int kPieces = 4 * kReplay;
 
 __device__ __forceinline__ int piece_group(int lane0, int d)
 {
-	const int l = lane0 - d;
+	const int l = lane0 - d / kCkptWords;                  /* a lane holds 32 * W columns: W blocks per lane on a diagonal */
 	return (l < 0 ? 0 : l) >> 4;
 }
 
 __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
-	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16];
+	constexpr int W = kCkptWords;
+	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16 * W];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kPieces][kBitBlock];
 	__shared__ int pos[4];
 
@@ -395,7 +457,7 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	int n = 0;
 
 	while (r > 0 && k > 0) {
-		const int w0 = (k - 1) >> 5;
+		const int w0 = (k - 1) / (32 * W);                   /* lane column of the current cell */
 		const int s = w0 >> 6;
 		const int lane0 = w0 & 63;
 		const int btop = ((r - 1) + lane0) / kBitBlock;
@@ -405,19 +467,23 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 			const int b = btop - d < 0 ? 0 : btop - d;       /* pieces above block 0 replay block 0 and are never read */
 			const int g = piece_group(lane0, d);
 			const int sl = 16 * g + (lane & 15);               /* lane index in the strip */
-			BitState S;
+			BitState<W> S;
 			if (b > 0) {
-				const uint4 v = ck[((size_t)s * nb + (b - 1)) * kLanes + sl];
-				S.nH0 = v.x;
-				S.H1 = v.y;
-				S.H2 = v.z;
-				S.PP = v.w;
+				load_state<W>(ck, ((size_t)s * nb + (b - 1)) * kLanes + sl, S);
 			} else {
-				S.nH0 = ~0u;
-				S.H1 = S.H2 = 0;
+#pragma unroll
+				for (int h = 0; h < W; ++h) {
+					S.nH0[h] = ~0u;
+					S.H1[h] = S.H2[h] = 0;
+				}
 				S.PP = 0;
 			}
-			const uint32_t B0 = cp[s * kLanes + sl], B1 = cp[J.nwords_pad + s * kLanes + sl];
+			uint32_t B0[W], B1[W];
+#pragma unroll
+			for (int h = 0; h < W; ++h) {
+				B0[h] = cp[(s * kLanes + sl) * W + h];
+				B1[h] = cp[J.nwords_pad + (s * kLanes + sl) * W + h];
+			}
 			/* words entering the piece's first lane: lane j of the row prepares steps j and j + 16 */
 #pragma unroll
 			for (int h = 0; h < 2; ++h) {
@@ -435,8 +501,8 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				inject[d][t] = word;
 			}
 			const bool ramp = btop - 4 * wv - 3 < 2;            /* wave-uniform: some piece of this wave is in block 0 or 1 */
-			if (ramp) bits_block<true, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
-			else bits_block<false, false, OUT_TILE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
+			if (ramp) bits_block<true, false, OUT_TILE, W>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
+			else bits_block<false, false, OUT_TILE, W>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
 		}
 		__syncthreads();
 		if (wv == 0) {
@@ -445,12 +511,12 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				uint32_t code = 3;                             /* 3 = stop: border or outside the replayed pieces */
 				if (ri > 0 && ki > 0) {
 					const int kc = ki - 1;
-					const int wi = kc >> 5;
+					const int wi = kc / (32 * W);
 					const int sl = wi & 63;
 					const int l = (ri - 1) + sl;
 					const int d = btop - l / kBitBlock;
 					if ((wi >> 6) == s && d >= 0 && d < kPieces && d <= btop && (sl >> 4) == piece_group(lane0, d)) {
-						const uint2 dd = tile[d][(l % kBitBlock) * 16 + (sl & 15)];
+						const uint2 dd = tile[d][((l % kBitBlock) * 16 + (sl & 15)) * W + ((kc >> 5) % W)];
 						const uint32_t bit = 1u << (kc & 31);
 						code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
 					}

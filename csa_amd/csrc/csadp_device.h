@@ -116,14 +116,17 @@ struct PairJob {
  */
 constexpr int kBitMaxStrips = 16;    /* waves per workgroup: jobs up to 32768 columns */
 constexpr int kBitBlock = 32;        /* steps per hand-off block between strips */
+constexpr int kBitCkptWords = 1;     /* words of 32 columns per lane in checkpoint mode.  2 works (tests pass) and */
+                                     /* needs 15 % fewer VALU instructions per cell, but halves the waves per job and  */
+                                     /* doubles the dependency chain of a step: 36.0 vs 37.4 TCUPS measured, so 1      */
 
 struct BitJob {
 	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */
 	uint64_t rowplanes;       /* u32 [2][rowwords]   same for the rows (0-based), zero padded                             */
 	uint64_t dirs;            /* u32 [nstrips][steps_pad][64][2]: word 0 = NOT-diagonal mask, word 1 = left mask of the   */
 	                          /*     32 columns of lane L in row (step - L).  Unused (0 bytes) in checkpoint mode         */
-	uint64_t ckpt;            /* checkpoint mode: u32 [nstrips][steps_pad/32][64][4] lane state (nH0, H1, H2, hand-off     */
-	                          /*     word) after every block of 32 steps                                                  */
+	uint64_t ckpt;            /* checkpoint mode: u32 [nstrips][steps_pad/32][64][words][4] lane state (per word of a lane: */
+	                          /*     nH0, H1, H2; + the hand-off word) after every block of 32 steps                      */
 	uint64_t hand;            /* checkpoint mode: u32 [nstrips][4][steps_pad] hand-off words leaving lanes 15, 31, 47 and   */
 	                          /*     63 after each step: a replay can restart at any 16-lane boundary of a strip           */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */

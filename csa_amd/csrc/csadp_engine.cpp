@@ -180,7 +180,7 @@ int FillBatch::layout()
 			/* more than 16 strips: one workgroup takes them in chunks (checkpoint mode only).  That is
 			 * one workgroup per matrix however wide it is, so with few jobs the tiled kernels, which
 			 * spread a matrix over the chip, are faster (8 x 100 kbp: 42 vs 76 ms, measured) */
-			if (J.ncols > kBitMaxStrips * kLanes * 32 && (!bits_ckpt_ || nj < 32)) bits_ = false;
+			if (J.ncols > kBitMaxStrips * kLanes * 32 * (bits_ckpt_ ? kBitCkptWords : 1) && (!bits_ckpt_ || nj < 32)) bits_ = false;
 		}
 	}
 	if (bits_) return layout_bits();
@@ -592,8 +592,9 @@ int FillBatch::layout_bits()
 		B.nrows = J.nrows;
 		B.ncols = J.ncols;
 		const int words = (J.ncols + 31) / 32;
-		B.nstrips = (words + kLanes - 1) / kLanes;
-		B.nwords_pad = B.nstrips * kLanes;
+		const int wpl = bits_ckpt_ ? kBitCkptWords : 1;        /* words of 32 columns per lane */
+		B.nstrips = (words + wpl * kLanes - 1) / (wpl * kLanes);
+		B.nwords_pad = B.nstrips * kLanes * wpl;
 		B.steps_pad = (int)align_up((size_t)J.nrows + 64, kBitBlock);
 		B.rowwords = B.steps_pad / 32;
 		bits_maxstrips_ = std::max(bits_maxstrips_, std::min(B.nstrips, kBitMaxStrips));
@@ -606,7 +607,7 @@ int FillBatch::layout_bits()
 	if (bits_ckpt_) {                              /* no direction planes: lane state per block + hand-off words */
 		dir_bytes_ = 0;
 		for (const BitJob &B : bjobs_)
-			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 + (long long)B.nstrips * B.steps_pad * 16;
+			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 * kBitCkptWords + (long long)B.nstrips * B.steps_pad * 16;
 	}
 	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
 	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
@@ -618,8 +619,7 @@ int FillBatch::layout_bits()
 	if (pipelined_) {
 		const int want = 2 * std::max(E.compute_units(), 1);
 		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
-		bits_group_ = std::min(bits_group_, env_int("CSADP_BITS_GROUP", bits_group_));
-		bits_group_ = std::max(bits_group_, 1);
+		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
 		/* launches in flight: 2 with direction planes in HBM (8.6 GB per bench pass), 3 in
 		 * checkpoint mode (0.6 GB), where the long replay traceback of one launch should hide
 		 * under the fills of the next two */
@@ -665,7 +665,7 @@ int FillBatch::layout_bits()
 			B.dirs = off;
 			if (!bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * kLanes * 8, 256);
 			B.ckpt = off;
-			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16, 256);
+			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 * kBitCkptWords, 256);
 			B.hand = off;
 			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * 16, 256);
 		}
