@@ -344,9 +344,18 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 {
 	if (!b || !results) return CSADP_ERR_ARG;
 	if (!b->ran || b->fetched) return CSADP_ERR_STATE;
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto tick = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!trace) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "csadp_pairs_fetch:  %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
+		tick = now;
+	};
 	if (!b->active.empty()) {
 		const int rc = b->fb.download();
 		if (rc != CSADP_OK) return rc;
+		lap("download");
 		parallel_for((int)b->active.size(), [&](int j) {
 			const int32_t *sm = b->fb.summary(j);
 			const size_t t = (size_t)b->active[(size_t)j];
@@ -354,11 +363,13 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 			if (a != CSADP_OK) b->status[t] = a;
 		});
 	}
+	lap("apply trace");
 	parallel_for((int)b->tasks.size(), [&](int t) {
 		memset(&results[t], 0, sizeof(results[t]));
 		if (b->status[(size_t)t] == CSADP_OK) b->status[(size_t)t] = b->tasks[(size_t)t].finish(&results[t]);
 		results[t].status = b->status[(size_t)t];
 	});
+	lap("result strings");
 	b->fetched = true;
 	return CSADP_OK;
 }

@@ -271,12 +271,15 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 		if (dj != nrows || dk != ncols) return CSADP_ERR_HIP;
 	}
 
+	/* The profile is only read again by a later step of the same task (and by
+	 * DeleteGappedColumns, i > 1): the last step of a 2-sequence task need not maintain it. */
+	const bool profile = !(nseq_ == 2 && i == 1);
 	std::vector<int> newsv;
 	std::vector<std::string> newstr;
 	std::vector<int> *svp = &sv_;
 	std::vector<std::string> *strp = &str_;
 	if (!inplace) {
-		newsv.assign((size_t)(newcons + 1) * kSym, 0);
+		if (profile) newsv.assign((size_t)(newcons + 1) * kSym, 0);
 		newstr.assign(nseq_, std::string());
 		for (int l = 0; l < i; ++l) newstr[order_[l]].assign((size_t)newcons, '\0');
 		svp = &newsv;
@@ -286,14 +289,18 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 	int j = nrows, k = ncols, m = newcons - 1;
 	int pos = ends_[n] - 1;
 	auto copy_column = [&](int kk, int mm) {               /* :1075-1079 */
-		for (int l = 0; l < kSym; ++l) (*svp)[(size_t)(mm + 1) * kSym + l] = sv_[(size_t)kk * kSym + l];
+		if (profile)
+			for (int l = 0; l < kSym; ++l) (*svp)[(size_t)(mm + 1) * kSym + l] = sv_[(size_t)kk * kSym + l];
 		for (int l = 0; l < i; ++l) { const int p = order_[l]; (*strp)[p][mm] = str_[p][kk - 1]; }
 	};
 	auto new_column = [&](int mm) {                         /* :1100-1105 / :1116-1120 */
 		for (int l = 0; l < i; ++l) {
 			(*strp)[order_[l]][mm] = '-';
-			(*svp)[(size_t)(mm + 1) * kSym + kGap]++;
+			if (profile) (*svp)[(size_t)(mm + 1) * kSym + kGap]++;
 		}
+	};
+	auto count = [&](int mm, int sym) {                     /* the new row's symbol joins column mm */
+		if (profile) (*svp)[(size_t)(mm + 1) * kSym + sym]++;
 	};
 	long long score = 0;                                    /* sum of move scores, :993-998 */
 	for (int t = 0; t < nops; ++t, --m) {                   /* :1072-1114 */
@@ -305,21 +312,21 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 			score += kMatch * col[c] + kIndel * col[kGap] + kMismatch * (i - (col[c] + col[kGap]));
 			if (!inplace) copy_column(k, m);
 			cur[m] = ch;
-			(*svp)[(size_t)(m + 1) * kSym + c]++;
+			count(m, c);
 			--pos; --j; --k;
 		} else if (op == DIR_L) {
 			const int g = sv_[(size_t)k * kSym + kGap];
 			score += kDoubleGap * g + kIndel * (i - g);
 			if (!inplace) copy_column(k, m);
 			cur[m] = '-';
-			(*svp)[(size_t)(m + 1) * kSym + kGap]++;
+			count(m, kGap);
 			--k;
 		} else {
 			score += kIndel * i;
 			if (!inplace) new_column(m);
 			const char ch = char_at(pos, n);
 			cur[m] = ch;
-			(*svp)[(size_t)(m + 1) * kSym + code_of(ch)]++;
+			count(m, code_of(ch));
 			--pos; --j;
 		}
 	}
@@ -330,16 +337,16 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 		new_column(m);
 		const char ch = char_at(pos, n);
 		cur[m] = ch;
-		(*svp)[(size_t)(m + 1) * kSym + code_of(ch)]++;
+		count(m, code_of(ch));
 		--pos;
 	}
 	for (; k > 0; --k, --m) {                               /* :1128-1138 */
 		if (!inplace) copy_column(k, m);
 		cur[m] = '-';
-		(*svp)[(size_t)(m + 1) * kSym + kGap]++;
+		count(m, kGap);
 	}
 	if (!inplace) {                                         /* :1139-1153 */
-		sv_.swap(newsv);
+		if (profile) sv_.swap(newsv);
 		for (int l = 0; l < i; ++l) str_[order_[l]].swap(newstr[order_[l]]);
 	}
 	str_[n].swap(cur);
