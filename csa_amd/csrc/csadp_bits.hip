@@ -1,7 +1,12 @@
 /*
  * csadp_bits.hip -- bit-parallel form of the pairwise fill (dynamicprogramming.c:990-1029 for a
- * profile of ONE sequence: i = 1, scores +1 match / -1 mismatch / -1 gap, fresh borders) and the
- * traceback that reads its direction planes.  gfx950, wave64.
+ * profile of ONE sequence: i = 1, scores +1 match / -1 mismatch / -1 gap, fresh borders) and its
+ * tracebacks (dynamicprogramming.c:1037-1047).  gfx950, wave64.
+ *
+ *   nw_fill_bits<CKPT>    K1b: one workgroup per matrix, one wave per strip of 2048 columns
+ *   nw_fill_bits_wide     K1b for matrices wider than 16 strips, strips in chunks of 16
+ *   nw_traceback_replay   K2c: checkpoint mode -- replays the blocks on the path, then walks them
+ *   nw_traceback_bits     K2b: direction planes in HBM -- walks them through an LDS window
  *
  * Why it is exact.  Let u = H[r][k-1] - H[r-1][k-1] (vertical step left of the cell), w =
  * H[r-1][k] - H[r-1][k-1] (horizontal step above it), both in {-1,0,1,2}.  The reference's cell
@@ -14,9 +19,11 @@
  * and the ">= 0" plane needs no chain.  tools/bitproto.py checks these formulas against the plain
  * recurrence, tie-breaks included.
  *
- * Work per lane and step: one row of 32 columns in 34 VALU instructions (1.06 per cell against 4 in
- * the packed-16 kernel: 26 for the recurrence, written as explicit v_bitop3 truth tables, 8 for
- * the hand-off to the right neighbour), two direction words (2 bit per cell, as before).
+ * Work per lane and step: one row of 32 columns in 32 VALU instructions (1 per cell against 4 in
+ * the packed-16 kernel: 23 for the recurrence, written as explicit v_bitop3 truth tables, 9 for
+ * the hand-off to the right neighbour).  Output: two direction words per step (2 bit per cell), or
+ * -- checkpoint mode, the default -- the lane state every 32 steps and four hand-off words per
+ * step, 7 % of that, from which the traceback re-derives the directions it needs.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
