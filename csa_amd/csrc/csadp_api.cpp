@@ -190,6 +190,15 @@ bool advance(Progressive &p)
 /* one lock-step round: every task with a pending fill contributes one job */
 int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, FillBatch &fb, std::vector<int> &status)
 {
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto tick = std::chrono::steady_clock::now();
+	double ms[5] = {0, 0, 0, 0, 0};
+	int phase = 0;
+	auto lap = [&]() {
+		const auto now = std::chrono::steady_clock::now();
+		ms[phase++] = std::chrono::duration<double, std::milli>(now - tick).count();
+		tick = now;
+	};
 	fb.clear();
 	bool unit = true;
 	for (int t : active) {
@@ -199,20 +208,27 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	fb.allow_bits(unit);
 	int rc = fb.layout();
 	if (rc != CSADP_OK) return rc;
+	lap();
 	parallel_for((int)active.size(), [&](int j) {
 		Progressive &p = tasks[active[(size_t)j]];
 		if (fb.bits()) p.write_tables_bits(fb.bit_cols(j), fb.bit_nwords(j), fb.bit_rows(j), fb.bit_rowwords(j));
 		else if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 		else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 	});
+	lap();
 	if ((rc = fb.upload()) != CSADP_OK) return rc;
 	if ((rc = fb.run()) != CSADP_OK) return rc;
 	if ((rc = fb.download()) != CSADP_OK) return rc;
+	lap();
 	parallel_for((int)active.size(), [&](int j) {
 		const int32_t *sm = fb.summary(j);
 		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2]);
 		if (a != CSADP_OK) status[active[(size_t)j]] = a;
 	});
+	lap();
+	if (trace)
+		fprintf(stderr, "csadp round: %3d jobs  layout %.2f  tables %.2f  device %.2f  apply %.2f ms\n", (int)active.size(), ms[0], ms[1],
+		        ms[2], ms[3]);
 	return CSADP_OK;
 }
 
