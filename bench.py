@@ -100,15 +100,17 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
     out = {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
            "sample": "%d of the step's 16 kbp pairs, whole ProgressiveDP (fill+traceback), %.1f s, "
                      "GPU strings %s" % (n, secs, "identical" if mismatches == 0 else "MISMATCH x%d" % mismatches)}
-    out["many_cores"] = cpu_many_cores(tasks, run)
     return out
 
 
-def cpu_many_cores(tasks, run, per_proc=2):
+def cpu_many_cores(tasks, per_proc=2):
     """The same CPU code in P independent processes (the reference keeps global state, so no
     threads), `per_proc` pairs each: what a host-only deployment of the reference would reach on a
     share of this node's cores.  Reported beside the single-core figure, wall clock of the slowest
-    process.  Bounded: ~1.5 s per pair and process."""
+    process.  Bounded: ~1.5 s per pair and process.  Runs BEFORE this process touches the GPU, so
+    the forked children never hold a device context."""
+    from helpers import have_ref, oracle_progressive, ref_progressive
+    run = ref_progressive if have_ref() else (lambda t, r: oracle_progressive(t, r))
     procs = max(1, min(32, (os.cpu_count() or 2) // 2, len(tasks) // per_proc))
     pids = []
     t0 = time.perf_counter()
@@ -145,6 +147,11 @@ def main():
                          "N>1 flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
+
+    many_cores = None
+    if args.gpus == 1 and not args.no_cpu_baseline:
+        from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
+        many_cores = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length))
 
     import torch
     import csa_amd
@@ -254,6 +261,7 @@ def main():
         }
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)
+            line["cpu_baseline"]["many_cores"] = many_cores
     batch.close()
     group.barrier()
     group.close()
