@@ -18,15 +18,20 @@
  * chain, SetAlignmentMapSegments) is order dependent down to which list neighbour a node is
  * parked in while hidden, so it is restated operation by operation on index-linked arrays.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <limits>
 #include <thread>
 #include <vector>
 
 #include "csadp.h"
+#include "csadp_hostpar.h"
+
+using csadp::host_parallel_for;
 
 namespace {
 
@@ -89,29 +94,6 @@ struct Automaton {
 	}
 };
 
-int host_threads()
-{
-	const char *e = getenv("CSADP_HOST_THREADS");
-	int n = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-	return std::max(1, std::min(n, 64));
-}
-
-template <class F>
-void for_each_index(int n, F &&fn)
-{
-	const int nt = std::min(host_threads(), n);
-	if (nt <= 1) {
-		for (int i = 0; i < n; ++i) fn(i);
-		return;
-	}
-	std::vector<std::thread> pool;
-	for (int t = 0; t < nt; ++t)
-		pool.emplace_back([&, t]() {
-			for (int i = t; i < n; i += nt) fn(i);
-		});
-	for (auto &th : pool) th.join();
-}
-
 /* ---- border nodes ------------------------------------------------------------------------ */
 
 struct Border {
@@ -126,12 +108,12 @@ int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Bor
 {
 	const int N = (int)rev.size();
 	std::vector<Automaton> sam((size_t)N);
-	for_each_index(N, [&](int t) { sam[(size_t)t].build(rev[(size_t)t].data(), (int)rev[(size_t)t].size()); });
+	host_parallel_for(N, [&](int t) { sam[(size_t)t].build(rev[(size_t)t].data(), (int)rev[(size_t)t].size()); });
 
 	/* common[s][p] = length of the longest prefix of T_s[p..] found in every sequence;
 	 * ident[s][p]  = state of that prefix (reversed) in sequence 0's automaton */
 	std::vector<std::vector<int>> common((size_t)N), ident((size_t)N);
-	for_each_index(N, [&](int s) {
+	host_parallel_for(N, [&](int s) {
 		const std::vector<unsigned char> &R = rev[(size_t)s];
 		const int n = (int)R.size();
 		std::vector<int> &L = common[(size_t)s];
@@ -184,11 +166,20 @@ int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Bor
 			if (len == 0) continue;          /* credited to the root, which is the list's sentinel (alignment.c:47) */
 			credits.push_back({(long long)ident[(size_t)s][(size_t)p] * span + len, s, p});
 		}
-	std::sort(credits.begin(), credits.end(), [](const Credit &a, const Credit &b) {
-		if (a.key != b.key) return a.key < b.key;
-		if (a.seq != b.seq) return a.seq < b.seq;
-		return a.pos < b.pos;
-	});
+	/* order by (key, seq, pos): the credits were generated in (seq, pos) order, so a STABLE sort on
+	 * the key alone does it -- LSD radix, 11 bits a pass */
+	{
+		long long maxkey = 0;
+		for (const Credit &c : credits) maxkey = std::max(maxkey, c.key);
+		std::vector<Credit> tmp(credits.size());
+		for (int shift = 0; (maxkey >> shift) != 0; shift += 11) {
+			size_t count[2049] = {0};
+			for (const Credit &c : credits) ++count[((c.key >> shift) & 2047) + 1];
+			for (int i = 0; i < 2048; ++i) count[i + 1] += count[i];
+			for (const Credit &c : credits) tmp[count[(c.key >> shift) & 2047]++] = c;
+			credits.swap(tmp);
+		}
+	}
 
 	struct Group {
 		size_t from, to;
@@ -594,23 +585,37 @@ int csadp_build_anchor_map(int nseq, const char *const *texts, const int *sizes,
 	 * reference's suffix walk (morenodeslinkedlists.c:590-617) into the other sequence's rotation
 	 * leaves: it records positions past the end of the text, depends on the processing order and
 	 * need not end.  No defined result to reproduce. */
-	for (int j = 0; j < nseq; ++j)
-		for (int i = 0; i < nseq; ++i) {
-			const size_t ni = fwd[(size_t)i].size(), nj = fwd[(size_t)j].size();
-			if (i == j || ni >= nj) continue;
+	{
+		std::vector<char> collides((size_t)nseq, 0);
+		host_parallel_for(nseq, [&](int i) {
+			const size_t ni = fwd[(size_t)i].size();
 			std::vector<unsigned char> twice(fwd[(size_t)i]);
 			twice.insert(twice.end(), fwd[(size_t)i].begin(), fwd[(size_t)i].end());
-			if (memmem(twice.data(), twice.size(), fwd[(size_t)j].data() + (nj - ni), ni) != NULL) return CSADP_ERR_RANGE;
-		}
+			for (int j = 0; j < nseq; ++j) {
+				const size_t nj = fwd[(size_t)j].size();
+				if (i == j || ni >= nj) continue;
+				if (memmem(twice.data(), twice.size(), fwd[(size_t)j].data() + (nj - ni), ni) != NULL) collides[(size_t)i] = 1;
+			}
+		});
+		for (int i = 0; i < nseq; ++i)
+			if (collides[(size_t)i]) return CSADP_ERR_RANGE;
+	}
 
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto t0 = std::chrono::steady_clock::now();
 	Loop loop;
 	loop.N = nseq;
 	loop.sizes = sizes;
 	const int rc = collect_border_nodes(rev, &loop.B);
 	if (rc != CSADP_OK) return rc;
 	out->border_nodes = (int)loop.B.size.size() - 1;
+	auto t1 = std::chrono::steady_clock::now();
 	loop.init();
 	loop.run();
+	if (trace)
+		fprintf(stderr, "csadp_build_anchor_map: border nodes %.1f ms, anchor loop %.1f ms\n",
+		        std::chrono::duration<double, std::milli>(t1 - t0).count(),
+		        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
 
 	int count = 0;
 	for (int g = 0; g != NIL; g = loop.seg[(size_t)g].next) ++count;

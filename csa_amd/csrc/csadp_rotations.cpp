@@ -28,6 +28,9 @@
 #include <vector>
 
 #include "csadp.h"
+#include "csadp_hostpar.h"
+
+using csadp::host_parallel_for;
 
 namespace {
 
@@ -159,9 +162,11 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 	std::vector<Sam> sam((size_t)nseq);
 	std::vector<std::vector<int>> state_at((size_t)nseq);     /* automaton state after end position e */
 	std::vector<int> M((size_t)n0, cap);
+	std::vector<std::vector<int>> Ms((size_t)nseq);           /* per sequence, reduced below */
 	const int qlen = 2 * n0;                                  /* doubled query */
-	for (int s = 0; s < nseq; ++s) {
+	host_parallel_for(nseq, [&](int s) {
 		sam[(size_t)s].build(seq[(size_t)s]);
+		Ms[(size_t)s].assign((size_t)n0, 0);
 		const Sam &A = sam[(size_t)s];
 		std::vector<int> ms_end((size_t)qlen);
 		state_at[(size_t)s].assign((size_t)qlen, 0);
@@ -187,9 +192,11 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 			int len = 0;
 			if (e - ms_end[(size_t)e] + 1 <= p) len = e - p + 1;
 			len = std::min(len, std::min(cap, sizes[s] - 1));
-			M[(size_t)p] = std::min(M[(size_t)p], len);
+			Ms[(size_t)s][(size_t)p] = len;
 		}
-	}
+	});
+	for (int s = 0; s < nseq; ++s)
+		for (int p = 0; p < n0; ++p) M[(size_t)p] = std::min(M[(size_t)p], Ms[(size_t)s][(size_t)p]);
 
 	/* ---- blocks ---------------------------------------------------------------------------- */
 	std::vector<Block> blocks;
