@@ -112,6 +112,14 @@ DEF_KERNEL(med3, OP8(F_MED3), "v_med3_i32 %0, %0, %1, %2")
 DEF_KERNEL(bitop3, OP8(F_BITOP3), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
 DEF_KERNEL(or3, OP8(F_OR3), "v_or3_b32 %0, %0, %1, %2")
 DEF_KERNEL(not, OP8(F_NOT), "v_not_b32 %0, %0")
+/* mixed streams around v_bitop3 (the bit-parallel kernel's mix): does a 4-cycle instruction slow its
+ * 2.6-cycle neighbours down? */
+#define MIX8(a, b) F_BITOP3("%0") "\n" F_BITOP3("%1") "\n" F_BITOP3("%2") "\n" a("%3") "\n" F_BITOP3("%4") "\n" F_BITOP3("%5") "\n" F_BITOP3("%6") "\n" b("%7")
+DEF_KERNEL(mix_b3_add3, MIX8(F_ADD3, F_ADD3), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF_KERNEL(mix_b3_add, MIX8(F_ADD, F_ADD), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF_KERNEL(mix_b3_bfe, MIX8(F_BFE, F_PERM), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF_KERNEL(mix_b3_dpp, MIX8(F_DPP, F_BITOP3), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
+DEF_KERNEL(mix_b3_and, MIX8(F_AND, F_LSHR), "v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96")
 
 // in-kernel clock under an all-CU integer VALU load: shader cycles (s_memtime) per 100 MHz
 // reference tick (s_memrealtime), MI355X_MICROARCH.md 'DVFS give-back' item 6
@@ -356,6 +364,6 @@ int main()
 	RUN(pkadd16); RUN(pkmin16); RUN(dpp);
 	RUN(add_sdwa); RUN(add_sdwaw); RUN(cndmask64); RUN(cndmask32); RUN(perm); RUN(lshl); RUN(lshr); RUN(or); RUN(xor);
 	RUN(sub); RUN(minf); RUN(min3f); RUN(addf); RUN(cmp); RUN(andor); RUN(bfi); RUN(mad24); RUN(mul24); RUN(minu16);
-	RUN(mov); RUN(addc); RUN(lshlor); RUN(med3); RUN(bitop3); RUN(or3); RUN(not);
+	RUN(mov); RUN(addc); RUN(lshlor); RUN(med3); RUN(bitop3); RUN(or3); RUN(not); RUN(mix_b3_add3); RUN(mix_b3_add); RUN(mix_b3_bfe); RUN(mix_b3_dpp); RUN(mix_b3_and);
 	return 0;
 }
