@@ -242,15 +242,18 @@ def main():
                          "launch_us_pipelined": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
                          "implementation_bytes_per_launch": round(lp * impl_bytes / launches),
                          "mode": {0: "tiled", 1: "bit-parallel, direction planes in HBM", 2: "bit-parallel, checkpoints + replay traceback"}[tm["bit_parallel"]],
-                         "note": "checkpoint mode writes implementation_bytes_per_launch instead of the direction planes "
-                                 "(the traceback replays the path), so frac can exceed what HBM could stream; see DESIGN.md 5. "
-                                 "algorithmic bytes = 0.25 B/cell of direction output (SURVEY 8d) x cells of the "
-                                 "`passes_per_launch` passes one launch carries. avg_launch_us = HIP events around ONE "
-                                 "such launch run alone on its stream (agrees with rocprofv3 --stats AverageNs, "
-                                 "profiles/); per_launch_achieved = bytes_per_launch / avg_launch_us. achieved = "
-                                 "algorithmic bytes of all timed passes / timed wall time (launches alternate on two "
-                                 "streams, so the next launch fills the tail of the previous one and hides its traceback). "
-                                 "roofline_valu prices the same kernel against VALU issue"},
+                         "note": "frac > 1 is not an accounting error: `achieved` counts the ALGORITHMIC bytes SURVEY 8(d) "
+                                 "defines (0.25 B/cell, the 2-bit direction of every cell), but the default checkpoint "
+                                 "mode does not write direction planes -- it writes `implementation_bytes_per_launch` "
+                                 "(lane-state checkpoints + hand-off marks; equal to the PMC `traffic`) and the traceback "
+                                 "replays the blocks on the path. With planes in HBM (CSADP_BITS_CKPT=0) the same metric "
+                                 "reads 0.65 and the kernel sits at 88 % of the measured HBM write ceiling (DESIGN.md 3, 5). "
+                                 "bytes_per_launch = algorithmic bytes of the `passes_per_launch` passes one launch "
+                                 "carries; avg_launch_us = HIP events around ONE such launch alone on its stream (agrees "
+                                 "with rocprofv3 --stats on a single stream, profiles/r01_kernel_stats_solo.csv); "
+                                 "per_launch_achieved = bytes_per_launch / avg_launch_us; achieved = algorithmic bytes of "
+                                 "all timed passes / timed wall time (three launches in flight, so tails and tracebacks "
+                                 "hide under the next fill). The binding resource is VALU issue: roofline_valu"},
             "roofline_valu": {"bound": "valu-issue", "ops_per_cell": VALU_OPS_PER_CELL,
                               "issue_cycles_per_64_cells": VALU_ISSUE_CYCLES_PER_CELL_WAVE,
                               "achieved": round(eff_cups / 1e9, 1), "peak": round(VALU_PEAK_CUPS / 1e9, 1),
