@@ -13,6 +13,8 @@ Outputs (all data, no reference source text):
   pipeline.json        (--pipeline) md5 of <set>-Aligned.fasta / -Rotated.fasta written by the
                        unmodified reference program in mode N (oracle/_ref/CSA_ref)
 
+  config4_pairs.json   (--config4) the first 32 pairs of the benchmark workload (SURVEY 8d config 4,
+                       csa_amd/synth.py) through the compiled reference: length, SP score, FNV-1a
   anchors.json         (--anchors) the anchor stage of the compiled reference (ref_shim.c:
                        csa_ref_alignment_map): small families with their rotations, border-node
                        count, final alignment map and the rows SaveAlignment wrote; and the
@@ -122,6 +124,17 @@ def real_pairs(all_pairs):
     return out
 
 
+def config4_pairs(n=32):
+    from csa_amd.synth import synth_pair
+    out = []
+    for p in range(n):
+        a, b, ra, rb = synth_pair(p)
+        cons, strs, sec = ref_progressive([a, b], [ra, rb])
+        out.append({"pair": p, "consensus": cons, "sp": sp_score(strs), "fnv1a": "%08x" % fnv1a(strs)})
+        print("config4 pair", p, cons, out[-1]["sp"], out[-1]["fnv1a"], "%.1fs" % sec, flush=True)
+    return out
+
+
 def pipeline():
     """Whole-program goldens: run the UNMODIFIED reference binary (oracle/_ref/CSA_ref, built by
     `make -C oracle _dropin`) in mode N on the example sets and record the md5 of its outputs."""
@@ -198,6 +211,10 @@ def main():
     if "--pipeline" in sys.argv:
         with open(os.path.join(HERE, "pipeline.json"), "w") as f:
             json.dump(pipeline(), f, indent=1)
+        return
+    if "--config4" in sys.argv:
+        with open(os.path.join(HERE, "config4_pairs.json"), "w") as f:
+            json.dump(config4_pairs(), f, indent=1)
         return
     if "--anchors" in sys.argv:
         with open(os.path.join(HERE, "anchors.json"), "w") as f:

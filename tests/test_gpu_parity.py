@@ -297,3 +297,43 @@ def test_packed_mode_long_homopolymers(fill_mode):
     assert got[0]["score"] == n and got[0]["aligned"] == [b"T" * n, b"T" * n]
     assert got[1]["score"] == n - 200 and got[1]["consensus"] == n
     assert got[1]["aligned"][1].count(b"-") == 100 and got[1]["aligned"][0] == b"T" * n
+
+
+def test_benchmark_workload_against_reference_digests():
+    """The bench's own workload: the first 32 pairs of config 4 must reproduce the compiled
+    reference's strings (length, SP score, FNV-1a digest committed in config4_pairs.json)."""
+    gold = load_golden("config4_pairs.json")
+    pairs = [synth_pair(g["pair"]) for g in gold]
+    got = csa_amd.align_batch([([a, b], [ra, rb], None, None) for a, b, ra, rb in pairs])
+    for g, r in zip(gold, got):
+        assert r["status"] == 0
+        assert (r["consensus"], r["score"], "%08x" % fnv1a(r["aligned"])) == (g["consensus"], g["sp"], g["fnv1a"]), g["pair"]
+
+
+def test_whole_config4_properties():
+    """All 1024 pairs of config 4 (2.75e11 cells) in one device-resident batch, three passes:
+    de-gapped rows re-spell the rotated inputs, equal lengths, SP(aligned) == DP score; the first
+    32 results equal the reference digests; a second fetch-free pass leaves the same results."""
+    n = 1024
+    pairs = [synth_pair(p) for p in range(n)]
+    tasks = [([a, b], [ra, rb], None, None) for a, b, ra, rb in pairs]
+    pb = csa_amd.PairBatch(tasks)
+    for _ in range(3):
+        pb.run()
+    pb.sync()
+    t = pb.timing()
+    got = pb.fetch()
+    pb.close()
+    assert t["cells"] == sum(len(a) * len(b) for a, b, _, _ in pairs)
+    gold = {g["pair"]: g for g in load_golden("config4_pairs.json")}
+    total = 0
+    for p, ((a, b, ra, rb), g) in enumerate(zip(pairs, got)):
+        assert g["status"] == 0
+        assert len(g["aligned"][0]) == len(g["aligned"][1]) == g["consensus"]
+        assert degap(g["aligned"][0]) == rotated(a, ra) and degap(g["aligned"][1]) == rotated(b, rb)
+        if p % 16 == 0 or p in gold:
+            assert sp_score(g["aligned"]) == g["score"]
+        if p in gold:
+            assert (g["consensus"], g["score"], "%08x" % fnv1a(g["aligned"])) == (gold[p]["consensus"], gold[p]["sp"], gold[p]["fnv1a"])
+        total += g["score"]
+    assert total > 0
