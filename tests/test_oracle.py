@@ -100,3 +100,14 @@ def test_oracle_vs_compiled_reference_fuzz():
         c1, s1, _ = oracle_progressive(fam, rots, starts, ends)
         c2, s2, _ = ref_progressive(fam, rots, starts, ends)
         assert c1 == c2 and s1 == s2, (it, fam, rots, starts, ends)
+
+
+def test_oracle_reproduces_benchmark_pair_digests():
+    """Two pairs of the benchmark workload (config 4): the oracle's strings carry the digests the
+    compiled reference produced (tests/golden/config4_pairs.json)."""
+    from helpers import oracle_progressive, sp_score, synth_pair
+    for g in load_golden("config4_pairs.json")[:2]:
+        a, b, ra, rb = synth_pair(g["pair"])
+        cons, strs, st = oracle_progressive([a, b], [ra, rb])
+        assert (cons, sp_score(strs), "%08x" % fnv1a(strs)) == (g["consensus"], g["sp"], g["fnv1a"])
+        assert st.last_score == g["sp"]
