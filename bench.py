@@ -202,7 +202,7 @@ def main():
         lp = max(tm["launch_passes"], 1)                        # passes per launch (1 unless bit-parallel)
         impl_bytes = tm["dir_bytes"] + tm["border_bytes"]      # what the kernels write per pass (directions or checkpoints, + tile borders)
         alg_bytes = ALG_BYTES_PER_CELL * tm["cells"] + (tm["border_bytes"] if not tm["bit_parallel"] else 0)
-        # the fill kernel is in flight during the whole timed region (launches alternate on two
+        # the fill kernel is in flight during the whole timed region (launches rotate over three
         # streams, the traceback of one hides under the next fill), so its sustained rate is:
         # work of all timed passes / wall time of the timed region
         rank_cells = tm["cells"]

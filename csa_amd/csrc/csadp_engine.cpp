@@ -612,7 +612,7 @@ int FillBatch::layout_bits()
 	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
 	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
 	 * group * nj workgroups, aiming at two workgroups per compute unit, and two such groups are
-	 * kept in flight on two streams so that the tail and the traceback of one overlap the next. */
+	 * kept in flight on 2-3 streams so that the tail and the traceback of one overlap the next. */
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	bits_group_ = 1;
 	nslots_ = 1;
