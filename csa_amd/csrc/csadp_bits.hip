@@ -4,7 +4,7 @@
  * tracebacks (dynamicprogramming.c:1037-1047).  gfx950, wave64.
  *
  *   nw_fill_bits<CKPT>    K1b: one workgroup per matrix, one wave per strip of 2048 columns
- *   nw_fill_bits_wide     K1b for matrices wider than 16 strips, strips in chunks of 16
+ *   nw_fill_bits_wide     K1b for matrices wider than 16 strips: a workgroup per chunk of 16 strips
  *   nw_traceback_replay   K2c: checkpoint mode -- replays the blocks on the path, then walks them
  *   nw_traceback_bits     K2b: direction planes in HBM -- walks them through an LDS window
  *
@@ -308,16 +308,28 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 
 /*
  * K1b for jobs wider than one workgroup (more than 16 strips; checkpoint mode only): the same
- * step function, strips taken in chunks of 16 -- all rows of a chunk, then the next chunk, whose
- * first strip reads the recorded hand-off words of the last strip of the chunk before (stream 3
- * of the marks) instead of an LDS ring.  Kept apart from nw_fill_bits: the extra loop level costs
- * the common case 7 % (measured).
+ * step function, one workgroup per CHUNK of 16 strips, all chunks of a job in flight at once.
+ * The first strip of chunk c reads the hand-off words recorded by the last strip of chunk c-1
+ * (stream 3 of its marks, in HBM) and follows that strip's published block counter
+ * (BitJob::progress, agent scope) at the usual distance of three blocks.  blockIdx.y = chunk:
+ * workgroups are dispatched in linear order, so the chunk a workgroup waits for is resident or done;
+ * the waits are bounded all the same.  Kept apart from nw_fill_bits, whose common case would pay
+ * for the extra cases (7 % measured).
  */
+__device__ __forceinline__ bool wait_global(const int *counter, int need)
+{
+	int spins = 0;
+	while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
+		__builtin_amdgcn_s_sleep(8);
+		if (++spins > kSpinMax) return false;
+	}
+	return true;
+}
+
 __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8_t *__restrict__ arena,
                                                                       const BitJob *__restrict__ jobs,
                                                                       int *__restrict__ abort_word)
 {
-	constexpr bool CKPT = true;
 	constexpr int OUT = OUT_NONE;
 	constexpr int W = kCkptWords;
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
@@ -325,102 +337,83 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
 	__shared__ uint32_t scrap[kBitMaxStrips][kBitBlock];
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
-	__shared__ int dead;
 	const BitJob &J = jobs[blockIdx.x];
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-	const int nwaves = (int)(blockDim.x >> 6);
+	const int chunk = (int)blockIdx.y;
+	const int s = chunk * kBitMaxStrips + wv;                  /* this wave's strip */
+	if (threadIdx.x < kBitMaxStrips) {
+		made[threadIdx.x] = 0;
+		taken[threadIdx.x] = 0;
+	}
+	__syncthreads();
+	if (s >= J.nstrips) return;
+
 	const int nb = J.steps_pad / kBitBlock;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
 	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
-	if (threadIdx.x == 0) dead = 0;
-
-	/* Jobs wider than the workgroup (checkpoint mode only) are done in chunks of nwaves strips:
-	 * all rows of a chunk, then the next chunk, whose first strip reads the recorded hand-off
-	 * words of the last strip of the chunk before (stream 3 of the marks) instead of the ring. */
-	for (int c0 = 0; c0 < J.nstrips; c0 += nwaves) {
-		if (threadIdx.x < kBitMaxStrips) {
-			made[threadIdx.x] = 0;
-			taken[threadIdx.x] = 0;
-		}
-		__syncthreads();
-		const int s = c0 + wv;                                 /* this wave's strip */
-		bool ok = s < J.nstrips && dead == 0;
-		if (ok) {
-			uint32_t B0[W], B1[W];
+	uint32_t B0[W], B1[W];
 #pragma unroll
-			for (int h = 0; h < W; ++h) {
-				B0[h] = cp[(s * kLanes + lane) * W + h];
-				B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
-			}
-			uint2 *dirs = nullptr;
-			const bool feeds = wv + 1 < nwaves && s + 1 < J.nstrips;      /* a wave of this chunk reads my ring */
-			const bool records = CKPT && s + 1 < J.nstrips;                /* lane 63's words are needed later */
-			/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
-			 * LDS and copied out once per block as four streams [4][steps_pad] per strip */
-			uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad : nullptr;
-			const uint32_t *left_marks = (CKPT && wv == 0 && s > 0)
-			    ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
-			const bool writes = (lane == kLanes - 1) ? (feeds || records) : (CKPT && (lane & 15) == 15);
+	for (int h = 0; h < W; ++h) {
+		B0[h] = cp[(s * kLanes + lane) * W + h];
+		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
+	}
+	const bool feeds = wv + 1 < kBitMaxStrips && s + 1 < J.nstrips;   /* a wave of this workgroup reads my ring */
+	const bool publishes = wv + 1 == kBitMaxStrips && s + 1 < J.nstrips;   /* the next chunk reads my marks */
+	uint32_t *marks = reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad;
+	const bool from_left_chunk = wv == 0 && chunk > 0;
+	const uint32_t *left_marks = from_left_chunk ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
+	int *progress = reinterpret_cast<int *>(arena + J.progress);
+	const bool writes = (lane == kLanes - 1) ? (feeds || publishes) : ((lane & 15) == 15);
 
-			BitState<W> S;
+	BitState<W> S;
 #pragma unroll
-			for (int h = 0; h < W; ++h) {
-				S.nH0[h] = ~0u;
-				S.H1[h] = S.H2[h] = 0;
-			}
-			S.PP = 0;
-			for (int b = 0; b < nb && ok; ++b) {
-				/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
-				 * the producer's step 32b + t + 63, row letter of row 32b + t */
-				uint32_t word = 0;
-				const int ps = b * kBitBlock + 63 + (lane & 31);
-				if (wv > 0) {
-					const int need = (b + 3 < nb) ? b + 3 : nb;         /* producer steps up to 32b + 94 */
-					if (!wait_at_least(&made[wv - 1], need)) { ok = false; break; }
-					if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-				} else if (left_marks != nullptr) {
-					if (ps < J.steps_pad) word = left_marks[ps] & 0xffffff00u;
-				}
-				const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
-				word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
-				if (lane < kBitBlock) inject[wv][lane] = word;
-				uint32_t *lanebuf = !writes ? &scrap[wv][0] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
-				if (feeds) {
-					/* the ring slots of this block last held block b - kRing, whose words the consumer
-					 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
-					if (!wait_at_least(&taken[wv + 1], b - kRing)) { ok = false; break; }
-				}
-				if (feeds || CKPT) {
-					if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
-					else bits_block<false, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, dirs, b * kBitBlock, lane);
-				} else {
-					if (b < 2) bits_block<true, false, OUT, W>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
-					else bits_block<false, false, OUT, W>(S, B0, B1, inject[wv], nullptr, dirs, b * kBitBlock, lane);
-				}
-				if (CKPT) {
-					/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
-					const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
-					marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
-					marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
-					    (g == 0) ? mbuf[wv][2][t] : ((feeds || records) ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u);
-					save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
-				}
-				if (feeds) {
-					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-					if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-				}
-			}
-			if (!ok) {                                           /* a wait timed out: fail the batch, let the others run out */
-				if (lane == 0) {
-					atomicExch(abort_word, 1);
-					dead = 1;
-				}
-			}
+	for (int h = 0; h < W; ++h) {
+		S.nH0[h] = ~0u;
+		S.H1[h] = S.H2[h] = 0;
+	}
+	S.PP = 0;
+	for (int b = 0; b < nb; ++b) {
+		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
+		 * the producer's step 32b + t + 63, row letter of row 32b + t */
+		uint32_t word = 0;
+		const int ps = b * kBitBlock + 63 + (lane & 31);
+		const int need = (b + 3 < nb) ? b + 3 : nb;             /* producer steps up to 32b + 94 */
+		if (wv > 0) {
+			if (!wait_at_least(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		} else if (from_left_chunk) {
+			if (!wait_global(&progress[chunk - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (ps < J.steps_pad) word = __hip_atomic_load(&left_marks[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffff00u;
 		}
-		__threadfence();                                         /* the marks of this chunk must be visible to the next one */
-		__syncthreads();
+		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
+		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
+		if (lane < kBitBlock) inject[wv][lane] = word;
+		uint32_t *lanebuf = !writes ? &scrap[wv][0] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
+		if (feeds) {
+			/* the ring slots of this block last held block b - kRing, whose words the consumer
+			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
+			if (!wait_at_least(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+		}
+		if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
+		else bits_block<false, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
+		{
+			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
+			const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
+			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
+			marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
+			    (g == 0) ? mbuf[wv][2][t] : ((feeds || publishes) ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u);
+			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
+		}
+		if (feeds) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		if (publishes) {
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     /* the marks above, for another compute unit */
+			if (lane == 0) __hip_atomic_store(&progress[chunk], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+		}
 	}
 }
 
@@ -659,8 +652,9 @@ hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int m
                             int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	if (maxstrips < 1 || maxstrips > kBitMaxStrips) return hipErrorInvalidValue;
-	if (checkpoints && wide) hipLaunchKernelGGL(nw_fill_bits_wide, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
+	if (maxstrips < 1 || (!wide && maxstrips > kBitMaxStrips)) return hipErrorInvalidValue;
+	const int maxchunks = (maxstrips + kBitMaxStrips - 1) / kBitMaxStrips;
+	if (checkpoints && wide) hipLaunchKernelGGL(nw_fill_bits_wide, dim3(njobs, maxchunks), dim3(kBitMaxStrips * kLanes), 0, st, arena, jobs, abort_word);
 	else if (wide) return hipErrorInvalidValue;
 	else if (checkpoints) hipLaunchKernelGGL(nw_fill_bits<true>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
 	else hipLaunchKernelGGL(nw_fill_bits<false>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);

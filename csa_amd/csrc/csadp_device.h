@@ -129,6 +129,7 @@ struct BitJob {
 	                          /*     nH0, H1, H2; + the hand-off word) after every block of 32 steps                      */
 	uint64_t hand;            /* checkpoint mode: u32 [nstrips][4][steps_pad] hand-off words leaving lanes 15, 31, 47 and   */
 	                          /*     63 after each step: a replay can restart at any 16-lane boundary of a strip           */
+	uint64_t progress;        /* wide jobs: i32 [chunks] blocks finished by the last strip of each chunk of 16 strips      */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;

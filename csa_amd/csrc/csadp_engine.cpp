@@ -177,10 +177,9 @@ int FillBatch::layout()
 		bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 		for (const FillJob &J : jobs_) {
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) bits_ = false;
-			/* more than 16 strips: one workgroup takes them in chunks (checkpoint mode only).  That is
-			 * one workgroup per matrix however wide it is, so with few jobs the tiled kernels, which
-			 * spread a matrix over the chip, are faster (8 x 100 kbp: 42 vs 76 ms, measured) */
-			if (J.ncols > kBitMaxStrips * kLanes * 32 * (bits_ckpt_ ? kBitCkptWords : 1) && (!bits_ckpt_ || nj < 32)) bits_ = false;
+			/* more than 16 strips: a workgroup per chunk of 16 strips, chained through the recorded
+			 * hand-off words (checkpoint mode only) */
+			if (J.ncols > kBitMaxStrips * kLanes * 32 * (bits_ckpt_ ? kBitCkptWords : 1) && !bits_ckpt_) bits_ = false;
 		}
 	}
 	if (bits_) return layout_bits();
@@ -597,7 +596,7 @@ int FillBatch::layout_bits()
 		B.nwords_pad = B.nstrips * kLanes * wpl;
 		B.steps_pad = (int)align_up((size_t)J.nrows + 64, kBitBlock);
 		B.rowwords = B.steps_pad / 32;
-		bits_maxstrips_ = std::max(bits_maxstrips_, std::min(B.nstrips, kBitMaxStrips));
+		bits_maxstrips_ = std::max(bits_maxstrips_, B.nstrips);
 		if (B.nstrips > kBitMaxStrips) bits_wide_ = true;
 		extra_[(size_t)j].ncols_pad = B.nwords_pad * 32;
 		cells_ += (long long)J.nrows * J.ncols;
@@ -657,9 +656,15 @@ int FillBatch::layout_bits()
 			off = align_up(off + (size_t)B.nrows + B.ncols + 64, 256);
 		}
 		res_bytes_ = off - res_off_[sl];
-		flags_off_[sl] = off;                     /* abort word */
+		flags_off_[sl] = off;                     /* abort word | progress counters of wide jobs: zeroed before every launch */
 		off += 256;
-		flags_bytes_ = 256;
+		for (int j = 0; j < nj; ++j) {
+			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+			B.progress = off;
+			if (B.nstrips > kBitMaxStrips) off = align_up(off + (size_t)((B.nstrips + kBitMaxStrips - 1) / kBitMaxStrips) * 4, 64);
+		}
+		off = align_up(off, 256);
+		flags_bytes_ = off - flags_off_[sl];
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
 			B.dirs = off;
@@ -784,7 +789,8 @@ int FillBatch::flush_bits(int k)
 		hipEvent_t *ev = ev_[first + g - 1];
 		const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
 		HIP_TRY(hipEventRecord(ev[0], st));
-		HIP_TRY(hipMemsetAsync(arena_ + flags_off_[first], 0, flags_bytes_, st));
+		for (int sl = first; sl < first + g; ++sl)         /* abort word (of the first slot) and every slot's progress counters */
+			HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
 		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, bits_wide_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
 		HIP_TRY(hipEventRecord(ev[1], st));
 		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, st));

@@ -73,9 +73,9 @@ def test_many_strips_few_rows_and_few_strips_many_rows(bits_mode):
 
 
 def test_sixteen_strips_and_beyond(bits_mode):
-    """32768 columns = 16 waves in one workgroup.  Wider jobs: in a batch of 32 or more jobs and
-    checkpoint mode they run bit-parallel in chunks of 16 strips (the first strip of a chunk reads
-    the recorded hand-off words of the chunk before); otherwise on the tiled kernels."""
+    """32768 columns = 16 waves in one workgroup.  Wider jobs: in checkpoint mode a workgroup per
+    chunk of 16 strips, chained through the recorded hand-off words and a progress counter in HBM;
+    with direction planes on the tiled kernels."""
     r = rng(103)
 
     def wide_task(cols):
@@ -84,7 +84,7 @@ def test_sixteen_strips_and_beyond(bits_mode):
         rows = a[:600] + a[-600:]                       # 1200 rows against a wide profile: large drift
         return ([rows, b], None, None, None)
 
-    for cols in (32768, 32800):
+    for cols in (32768, 32800, 100003):
         check([wide_task(cols)])
     # 32 jobs, two of them wider than one workgroup
     small = []
