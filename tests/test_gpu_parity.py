@@ -337,3 +337,34 @@ def test_whole_config4_properties():
             assert (g["consensus"], g["score"], "%08x" % fnv1a(g["aligned"])) == (gold[p]["consensus"], gold[p]["sp"], gold[p]["fnv1a"])
         total += g["score"]
     assert total > 0
+
+
+def test_whole_config5_in_one_batch():
+    """Config 5: 256 pairs, lengths 1 k .. 200 k, 1.2e12 cells, as ONE device-resident
+    batch -- possible because checkpoint mode keeps no direction planes (0.3 TB of them otherwise).
+    Jobs of up to 98 strips run as chains of workgroups.  Size-independent properties on every
+    result; the short ones string for string against the oracle."""
+    from csa_amd.synth import config5_lengths
+    la, _ = config5_lengths(256)
+    tasks = []
+    for i, length in enumerate(la):
+        a, b, ra, rb = synth_pair(20000 + i, length=int(length))
+        tasks.append(([a, b], [ra, rb], None, None))
+    pb = csa_amd.PairBatch(tasks)
+    pb.run()
+    tm = pb.timing()
+    got = pb.fetch()
+    pb.close()
+    assert tm["cells"] > 1.1e12 and tm["bit_parallel"] == 2 and max(la) > 190000
+    checked = 0
+    for t, g in zip(tasks, got):
+        assert g["status"] == 0
+        assert len(g["aligned"][0]) == len(g["aligned"][1]) == g["consensus"]
+        assert degap(g["aligned"][0]) == rotated(t[0][0], t[1][0])
+        assert degap(g["aligned"][1]) == rotated(t[0][1], t[1][1])
+        assert sp_score(g["aligned"]) == g["score"]
+        if len(t[0][0]) <= 2500 and checked < 12:
+            cons, strs, st = oracle_progressive(t[0], t[1])
+            assert g["aligned"] == strs and g["score"] == st.last_score
+            checked += 1
+    assert checked >= 8
