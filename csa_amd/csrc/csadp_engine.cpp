@@ -634,6 +634,26 @@ int FillBatch::layout_bits()
 	}
 	off = align_up(off, 256);
 	tiles_off_ = off;
+	if (bits_wide_) {
+		/* work list of the chunked kernel: (job, chunk of 16 strips), the longest jobs first -- they
+		 * are the critical path of a mixed batch -- and a job's chunks in ascending order, so that the
+		 * workgroup a chunk waits for is always dispatched before it */
+		std::vector<int> order((size_t)nj);
+		for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+			return (long long)bjobs_[(size_t)a].steps_pad * bjobs_[(size_t)a].nstrips > (long long)bjobs_[(size_t)b].steps_pad * bjobs_[(size_t)b].nstrips;
+		});
+		for (int j : order)
+			for (int c = 0; c * kBitMaxStrips < bjobs_[(size_t)j].nstrips; ++c) {
+				TileRef t;
+				t.job = j;
+				t.a = c;
+				t.s = 0;
+				t.first = 0;
+				tiles_.push_back(t);
+			}
+		off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
+	}
 	for (int j = 0; j < nj; ++j) {
 		BitJob &B = bjobs_[(size_t)j];
 		bextra_[(size_t)j].in_cols = B.colplanes = off;
@@ -680,6 +700,7 @@ int FillBatch::layout_bits()
 	if (rc != CSADP_OK) return rc;
 	for (int sl = 0; sl < nslots_; ++sl)
 		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(BitJob));
+	if (!tiles_.empty()) memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
 	bjobs_ = slot_jobs[0];
 	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
 	return CSADP_OK;
@@ -791,7 +812,11 @@ int FillBatch::flush_bits(int k)
 		HIP_TRY(hipEventRecord(ev[0], st));
 		for (int sl = first; sl < first + g; ++sl)         /* abort word (of the first slot) and every slot's progress counters */
 			HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
-		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, bits_wide_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
+		if (bits_wide_)
+			HIP_TRY(launch_fill_bits_wide(arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(),
+			                              reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
+		else
+			HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
 		HIP_TRY(hipEventRecord(ev[1], st));
 		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, st));
 		HIP_TRY(hipEventRecord(ev[2], st));

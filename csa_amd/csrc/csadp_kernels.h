@@ -29,10 +29,13 @@ hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int n
 /* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;
  * chars = nseq x length bytes, sequence-major; out must be zeroed. */
 /* csadp_bits.hip: bit-parallel first fills, one workgroup per job, and their traceback */
-/* wide = some job has more than kBitMaxStrips strips (checkpoint mode only; maxstrips is then the
- * real maximum and the grid gets one workgroup per chunk of kBitMaxStrips strips) */
-hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, bool wide,
-                            int *abort_word, hipStream_t st);
+hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
+                            hipStream_t st);
+/* batches with jobs of more than kBitMaxStrips strips (checkpoint mode): one workgroup per work item
+ * = (job, chunk of kBitMaxStrips strips); `work` lists the items of ONE pass, `passes` consecutive
+ * passes (job tables of njobs entries each) share a launch */
+hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
+                                 int *abort_word, hipStream_t st);
 hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, hipStream_t st);
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st);
 
