@@ -222,7 +222,8 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	lap();
 	parallel_for((int)active.size(), [&](int j) {
 		const int32_t *sm = fb.summary(j);
-		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2]);
+		/* where the device has scored its path, the host's own sum along the trace must agree */
+		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2], fb.device_scores() ? &sm[3] : nullptr);
 		if (a != CSADP_OK) status[active[(size_t)j]] = a;
 	});
 	lap();
@@ -277,7 +278,16 @@ int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results
 	return CSADP_OK;
 }
 
+static int pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores);
+
 int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out)
+{
+	return pairs_create(tasks, ntasks, out, false);
+}
+
+/* device_scores: the caller only wants DP scores -- where the traceback kernel can sum its path
+ * itself it does, and the host never walks the traces */
+static int pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores)
 {
 	if (!tasks || !out || ntasks <= 0) return CSADP_ERR_ARG;
 	if (!Engine::get().ready()) {
@@ -315,6 +325,7 @@ int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **ou
 			unit = unit && b->tasks[t].unit_borders();
 		}
 		b->fb.allow_bits(unit);
+		b->fb.want_scores(device_scores);
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
 		lap("layout");
@@ -375,7 +386,7 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 		parallel_for((int)b->active.size(), [&](int j) {
 			const int32_t *sm = b->fb.summary(j);
 			const size_t t = (size_t)b->active[(size_t)j];
-			const int a = b->tasks[t].apply_trace(b->fb.ops(j), sm[0], sm[1], sm[2]);
+			const int a = b->tasks[t].apply_trace(b->fb.ops(j), sm[0], sm[1], sm[2], b->fb.device_scores() ? &sm[3] : nullptr);
 			if (a != CSADP_OK) b->status[t] = a;
 		});
 	}
@@ -396,7 +407,7 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 {
 	if (!tasks || !scores || ntasks <= 0) return CSADP_ERR_ARG;
 	csadp_pairbatch *b = nullptr;
-	int rc = csadp_pairs_create(tasks, ntasks, &b);
+	int rc = pairs_create(tasks, ntasks, &b, true);
 	if (rc != CSADP_OK) return rc;
 	if ((rc = csadp_pairs_run(b)) == CSADP_OK && !b->active.empty()) rc = b->fb.download();
 	if (rc != CSADP_OK) { delete b; return rc; }
@@ -404,6 +415,10 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 	parallel_for((int)b->active.size(), [&](int j) {
 		const int32_t *sm = b->fb.summary(j);
 		const size_t t = (size_t)b->active[(size_t)j];
+		if (b->fb.device_scores()) {                     /* the traceback kernel has already summed its path */
+			scores[t] = sm[3];
+			return;
+		}
 		const int a = b->tasks[t].score_from_trace(b->fb.ops(j), sm[0], sm[1], sm[2], &scores[t]);
 		if (a != CSADP_OK) b->status[t] = a;
 	});

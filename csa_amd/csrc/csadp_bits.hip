@@ -82,10 +82,14 @@ constexpr int kCkptWords = kBitCkptWords;
  * row's [32][16] tile. */
 enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
 
-template <bool RAMPIN, bool FEEDS, int OUT, int W>
+template <bool RAMPIN, bool FEEDS, int OUT, int W, bool MATCHES = false>
 __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[W], const uint32_t (&B1)[W], const uint32_t *inject,
-                                           uint32_t *lanebuf, uint2 *dirs, int l0, int lane)
+                                           uint32_t *lanebuf, uint2 *dirs, int l0, int lane, uint32_t *matches = nullptr)
 {
+	/* MATCHES (replay with scoring): `matches` is an LDS tile like dirs and receives the match masks.
+	 * It must stay an LDS-typed pointer: merged with nullptr it would become a flat pointer, and
+	 * flat accesses do not reach LDS beyond 64 KB. */
+	[[maybe_unused]] uint32_t *outm = MATCHES ? matches + (lane & 15) * W : nullptr;
 	static_assert(OUT != OUT_GLOBAL || W == 1, "direction planes in HBM are laid out for one word per lane");
 	constexpr bool ROWS = (OUT == OUT_TILE);
 	constexpr int ostride = ROWS ? 16 : kLanes;
@@ -153,6 +157,7 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[
 				const uint32_t notdiag = C0 & nE;
 				const uint32_t left = notdiag & nT0;
 				out[t * ostride * W + h] = make_uint2(notdiag, left);
+				if (MATCHES) outm[t * ostride * W + h] = ~nE;       /* match mask: the walk scores its path */
 			}
 			if (RAMPIN) {
 				nT0 |= ~live;
@@ -442,10 +447,12 @@ __device__ __forceinline__ int piece_group(int lane0, int d)
 	return (l < 0 ? 0 : l) >> 4;
 }
 
+template <bool SCORE>       /* SCORE: also sum the move scores of the path (score-only callers skip the host walk) */
 __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
 	constexpr int W = kCkptWords;
 	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16 * W];
+	__shared__ uint32_t mtile[SCORE ? kPieces : 1][SCORE ? kBitBlock * 16 * W : 1];    /* match masks of the same cells */
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kPieces][kBitBlock];
 	__shared__ int pos[4];
 
@@ -460,6 +467,7 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	const int nb = J.steps_pad / kBitBlock;
 	int r = J.nrows, k = J.ncols;
 	int n = 0;
+	int score = 0;                                             /* sum of the move scores along the path (:993-998 for i = 1) */
 
 	while (r > 0 && k > 0) {
 		const int w0 = (k - 1) / (32 * W);                   /* lane column of the current cell */
@@ -506,14 +514,15 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				inject[d][t] = word;
 			}
 			const bool ramp = btop - 4 * wv - 3 < 2;            /* wave-uniform: some piece of this wave is in block 0 or 1 */
-			if (ramp) bits_block<true, false, OUT_TILE, W>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
-			else bits_block<false, false, OUT_TILE, W>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl);
+			if (ramp) bits_block<true, false, OUT_TILE, W, SCORE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl, mtile[SCORE ? d : 0]);
+			else bits_block<false, false, OUT_TILE, W, SCORE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl, mtile[SCORE ? d : 0]);
 		}
 		__syncthreads();
 		if (wv == 0) {
 			for (;;) {
 				const int ri = r - lane, ki = k - lane;
 				uint32_t code = 3;                             /* 3 = stop: border or outside the replayed pieces */
+				bool match = false;
 				if (ri > 0 && ki > 0) {
 					const int kc = ki - 1;
 					const int wi = kc / (32 * W);
@@ -521,15 +530,19 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 					const int l = (ri - 1) + sl;
 					const int d = btop - l / kBitBlock;
 					if ((wi >> 6) == s && d >= 0 && d < kPieces && d <= btop && (sl >> 4) == piece_group(lane0, d)) {
-						const uint2 dd = tile[d][((l % kBitBlock) * 16 + (sl & 15)) * W + ((kc >> 5) % W)];
+						const int at = ((l % kBitBlock) * 16 + (sl & 15)) * W + ((kc >> 5) % W);
+						const uint2 dd = tile[d][at];
 						const uint32_t bit = 1u << (kc & 31);
 						code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
+						if (SCORE) match = (mtile[d][at] & bit) != 0;
 					}
 				}
 				const unsigned long long stop = __ballot(code != DIR_D);
 				const int run = stop ? __builtin_ctzll(stop) : kLanes;
 				if (run > 0) {
 					if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+					const unsigned long long hits = __ballot(match) & (run == kLanes ? ~0ull : ((1ull << run) - 1));
+					score += 2 * __builtin_popcountll(hits) - run;          /* +1 per match, -1 per mismatch */
 					n += run;
 					r -= run;
 					k -= run;
@@ -539,25 +552,28 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				if (c0 == 3) break;
 				if (lane == 0) ops[n] = (uint8_t)c0;
 				++n;
+				--score;                                        /* a gap in either sequence */
 				if (c0 == DIR_L) --k; else --r;
 			}
 			if (lane == 0) {
 				pos[0] = r;
 				pos[1] = k;
 				pos[2] = n;
+				pos[3] = score;
 			}
 		}
 		__syncthreads();
 		r = pos[0];
 		k = pos[1];
 		n = pos[2];
+		score = pos[3];
 		__syncthreads();
 	}
 	if (threadIdx.x == 0) {
 		summary[0] = n;
 		summary[1] = r;
 		summary[2] = k;
-		summary[3] = 0;
+		summary[3] = SCORE ? score - r - k : 0;               /* + the border cell the walk stopped on: H[r][0] = -r, H[0][k] = -k */
 	}
 }
 
@@ -679,10 +695,11 @@ hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, 
 	return hipGetLastError();
 }
 
-hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, hipStream_t st)
+hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	if (checkpoints) hipLaunchKernelGGL(nw_traceback_replay, dim3(njobs), dim3(kReplay * kLanes), 0, st, arena, jobs);
+	if (checkpoints && scores) hipLaunchKernelGGL(nw_traceback_replay<true>, dim3(njobs), dim3(kReplay * kLanes), 0, st, arena, jobs);
+	else if (checkpoints) hipLaunchKernelGGL(nw_traceback_replay<false>, dim3(njobs), dim3(kReplay * kLanes), 0, st, arena, jobs);
 	else hipLaunchKernelGGL(nw_traceback_bits, dim3(njobs), dim3(kLanes), 0, st, arena, jobs);
 	return hipGetLastError();
 }

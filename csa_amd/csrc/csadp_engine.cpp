@@ -613,6 +613,7 @@ int FillBatch::layout_bits()
 	 * group * nj workgroups, aiming at two workgroups per compute unit, and two such groups are
 	 * kept in flight on 2-3 streams so that the tail and the traceback of one overlap the next. */
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
+	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
 	bits_group_ = 1;
 	nslots_ = 1;
 	if (pipelined_) {
@@ -818,7 +819,7 @@ int FillBatch::flush_bits(int k)
 		else
 			HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
 		HIP_TRY(hipEventRecord(ev[1], st));
-		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, st));
+		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, st));
 		HIP_TRY(hipEventRecord(ev[2], st));
 		for (int sl = first; sl < first + g; ++sl) {
 			slot_used_[sl] = true;

@@ -111,7 +111,10 @@ public:
 	int sync();                      /* flush, then wait for all streams */
 	int download();                  /* results of the LAST run() -> host (blocking) */
 	const uint8_t *ops(int j) const;
-	const int32_t *summary(int j) const;   /* nops, remj, remk, 0 */
+	const int32_t *summary(int j) const;   /* nops, remj, remk, DP score if device_scores() else 0 */
+	/* the traceback kernel summed the move scores of its path (checkpoint mode of the bit-parallel path) */
+	void want_scores(bool on) { want_scores_ = on; }
+	bool device_scores() const { return bits_ && bits_ckpt_ && want_scores_; }
 	int timing(csadp_timing *t);
 
 private:
@@ -126,7 +129,7 @@ private:
 	int finish_layout();             /* arena / staging allocation shared by the layouts */
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
-	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false;
+	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false, want_scores_ = false;
 	int bits_maxstrips_ = 1;
 	int run_slot(int sl, bool persistent);
 	int run_merged(int npasses);

@@ -36,7 +36,8 @@ hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int m
  * passes (job tables of njobs entries each) share a launch */
 hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
                                  int *abort_word, hipStream_t st);
-hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, hipStream_t st);
+/* scores: the replay traceback also sums the move scores of its path into summary[3] */
+hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st);
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st);
 
 }  // namespace csadp

@@ -201,3 +201,25 @@ def test_extreme_aspect_ratios(bits_mode):
     ]
     got = csa_amd.align_batch(tasks)
     _properties(tasks, got)
+
+
+def test_device_path_scores_cross_checked(monkeypatch):
+    """CSADP_FORCE_SCORES=1: every replay traceback also sums the move scores of its path and every
+    fetch compares that with the host's own sum along the trace (a mismatch fails the task)."""
+    monkeypatch.setenv("CSADP_FORCE_SCORES", "1")
+    r = rng(110)
+    tasks = []
+    for n in (40, 130, 200, 700, 2048, 2100, 5000, 9000):
+        a, b = related(r, n, None)
+        tasks.append(([a, b], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    core = bytes(r.choice(b"ACGT") for _ in range(3000))
+    junk = bytes(r.choice(b"AC") for _ in range(2500))
+    tasks += [([core, junk + core], None, None, None), ([b"GT" * 1100, b"TG" * 1200], None, None, None),
+              ([b"G" * 2100, b"T" * 2300], None, None, None)]
+    check(tasks)
+    pb = csa_amd.PairBatch(tasks)
+    for _ in range(5):
+        pb.run()
+    got = pb.fetch()
+    pb.close()
+    assert all(g["status"] == 0 for g in got)

@@ -94,3 +94,34 @@ def test_csa_pairs_native_rotations_end_to_end(tmp_path):
         gold = json.load(f)["Primates"]
     with open(out, "rb") as f:
         assert hashlib.md5(f.read()).hexdigest() == gold["rotated_md5"]
+
+
+def test_score_pairs_device_scores_on_hard_inputs():
+    """Score-only calls take the path score from the traceback kernel (checkpoint mode): check it
+    on inputs whose paths hug borders, tie everywhere or wander far from the diagonal, on wide jobs
+    and on the benchmark pairs, against the score of the full alignment."""
+    csa_amd.init(device=0)
+    r = rng(31)
+    core = bytes(r.choice(b"ACGT") for _ in range(3000))
+    junk = bytes(r.choice(b"AC") for _ in range(2500))
+    wide = bytes(r.choice(b"ACGT") for _ in range(40000))
+    tasks = [
+        ([core, junk + core], None, None, None),
+        ([core[:1500] + junk + core[1500:], core], None, None, None),
+        ([b"G" * 2100, b"T" * 2300], None, None, None),
+        ([b"GT" * 1100, b"TG" * 1200], None, None, None),
+        ([b"A" * 5000, b"A" * 4993], None, None, None),
+        ([b"G", core], None, None, None),
+        ([core, core], [17, 1234], None, None),
+        ([wide[:700], wide], None, None, None),
+        ([wide[100:36000], wide], [5, 9], None, None),
+    ]
+    from csa_amd.synth import synth_pair
+    for p in range(6):
+        a, b, ra, rb = synth_pair(p)
+        tasks.append(([a, b], [ra, rb], None, None))
+    scores, status = csa_amd.score_pairs(tasks)
+    full = csa_amd.align_batch(tasks)
+    assert status == [0] * len(tasks)
+    assert scores == [g["score"] for g in full]
+    assert scores[-6:] == [c["sp"] for c in load_golden("config4_pairs.json")[:6]]
