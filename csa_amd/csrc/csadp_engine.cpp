@@ -778,22 +778,18 @@ int FillBatch::flush()
 	if (pending_ == 0) return CSADP_OK;
 	const int k = pending_;
 	pending_ = 0;
-	/* Default: pass i goes to slot i % slots on that slot's own stream; kernels of different
-	 * streams overlap.  CSADP_MERGE=1 selects the single-stream merged schedule instead --
-	 * measured SLOWER on the bench batch (5.3 vs 4.2 ms per pass: every merged launch is a
-	 * barrier over ~3300 single-wave workgroups), kept for experiments. */
 	if (bits_) return flush_bits(k);
-	if (k == 1 || nslots_ < 3 || env_int("CSADP_MERGE", 0) == 0) {
-		for (int i = 0; i < k; ++i) {
-			const int sl = next_slot_;
-			next_slot_ = (next_slot_ + 1) % nslots_;
-			last_slot_ = sl;
-			const int rc = run_slot(sl, pk_ && persist_);
-			if (rc != CSADP_OK) return rc;
-		}
-		return CSADP_OK;
+	/* pass i goes to slot i % slots on that slot's own stream; kernels of different streams overlap.
+	 * (A single-stream schedule that merged the current anti-diagonal of every pass in flight into
+	 * one launch was measured slower, 5.3 vs 4.2 ms per pass, and removed.) */
+	for (int i = 0; i < k; ++i) {
+		const int sl = next_slot_;
+		next_slot_ = (next_slot_ + 1) % nslots_;
+		last_slot_ = sl;
+		const int rc = run_slot(sl, pk_ && persist_);
+		if (rc != CSADP_OK) return rc;
 	}
-	return run_merged(k);
+	return CSADP_OK;
 }
 
 /* Bit-parallel mode: enqueue k passes as merged launches of up to bits_group_ consecutive slots.
@@ -842,7 +838,7 @@ int FillBatch::run_slot(int sl, bool persistent)
 	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);
 	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[0]);
 	const int per_slot = pk_ ? (int)pjobs_.size() : (int)jobs_.size();
-	if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));     /* a merged schedule may still own it */
+	if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));     /* the slot's previous pass */
 	HIP_TRY(hipEventRecord(ev[0], st));
 	if (persistent) {
 		/* one launch: a wave per (pair job, strip), strips synchronise through progress counters */
@@ -868,62 +864,6 @@ int FillBatch::run_slot(int sl, bool persistent)
 	else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]), (int)jobs_.size(), st));
 	HIP_TRY(hipEventRecord(ev[2], st));
 	slot_used_[sl] = true;
-	return CSADP_OK;
-}
-
-/*
- * Enqueue npasses passes as ONE sequence of launches on stream 0.  With S = slots-1 passes in
- * flight, pass j starts `stagger` = ceil(ndiag/S) launches after pass j-1; launch L carries
- * anti-diagonal L - j*stagger of every pass j that is in flight, so head, middle and tail
- * diagonals of different passes share a launch and its size stays near S/2 full diagonals.
- * Tracebacks run on stream 1; a slot is handed to pass j+slots only after the traceback of
- * pass j (one spare slot gives it `stagger` launches of slack).
- */
-int FillBatch::run_merged(int npasses)
-{
-	Engine &E = Engine::get();
-	hipStream_t fs = E.stream(0), ts = E.stream(1);
-	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);
-	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[0]);
-	const int per_slot = pk_ ? (int)pjobs_.size() : (int)jobs_.size();
-	const int ndiag = (int)diag_off_.size() - 1;
-	const int inflight = std::min(nslots_ - 1, (int)kMaxSegs);
-	const int stagger = (ndiag + inflight - 1) / inflight;
-	const int total = (npasses - 1) * stagger + ndiag;
-	const int first_slot = next_slot_;
-	for (int L = 0; L < total; ++L) {
-		SegList segs;
-		memset(&segs, 0, sizeof(segs));
-		const int jlo = std::max(0, (L - ndiag + stagger) / stagger);          /* first pass still running */
-		const int jhi = std::min(npasses - 1, L / stagger);
-		for (int j = jlo; j <= jhi; ++j) {
-			const int d = L - j * stagger;
-			if (d < 0 || d >= ndiag) continue;
-			const int sl = (first_slot + j) % nslots_;
-			if (d == 0) {
-				if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(fs, ev_[sl][2], 0));
-				HIP_TRY(hipEventRecord(ev_[sl][0], fs));
-			}
-			TileSeg &g = segs.seg[segs.n++];
-			g.tiles = tiles_off_ + diag_off_[(size_t)d] * sizeof(TileRef);
-			g.count = (int)(diag_off_[(size_t)d + 1] - diag_off_[(size_t)d]);
-			g.job_base = sl * per_slot;
-		}
-		if (pk_) HIP_TRY(launch_fill_pk(E.R(), E.TR(), arena_, dpairs, segs, fs));
-		else HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, segs, fs));
-		for (int j = jlo; j <= jhi; ++j) {
-			if (L - j * stagger != ndiag - 1) continue;                          /* pass j just finished its fill */
-			const int sl = (first_slot + j) % nslots_;
-			HIP_TRY(hipEventRecord(ev_[sl][1], fs));
-			HIP_TRY(hipStreamWaitEvent(ts, ev_[sl][1], 0));
-			if (pk_) HIP_TRY(launch_traceback_pk(E.R(), arena_, reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]), (int)pjobs_.size(), ts));
-			else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]), (int)jobs_.size(), ts));
-			HIP_TRY(hipEventRecord(ev_[sl][2], ts));
-			slot_used_[sl] = true;
-			last_slot_ = sl;
-		}
-	}
-	next_slot_ = (first_slot + npasses) % nslots_;
 	return CSADP_OK;
 }
 

@@ -102,10 +102,9 @@ public:
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
 	int upload();                    /* inputs -> HBM (async on the engine stream) */
-	/* Request one more pass.  Passes are enqueued at the next sync()/timing()/download(): pass i
-	 * on slot i % slots and that slot's stream (default), or -- CSADP_MERGE=1, experimental --
-	 * all together on one stream, staggered, every launch carrying the current anti-diagonal of
-	 * every pass in flight (one TileSeg each) with the tracebacks on a second stream. */
+	/* Request one more pass.  Passes are enqueued at the next sync()/timing()/download(): tiled
+	 * kernels: pass i on slot i % slots and that slot's stream; bit-parallel kernels: consecutive
+	 * passes merged into launches that rotate over 2-3 streams (flush_bits). */
 	int run();
 	int flush();                     /* enqueue what run() requested */
 	int sync();                      /* flush, then wait for all streams */
@@ -132,7 +131,6 @@ private:
 	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false, want_scores_ = false;
 	int bits_maxstrips_ = 1;
 	int run_slot(int sl, bool persistent);
-	int run_merged(int npasses);
 	std::vector<PairJob> pjobs_;
 	std::vector<PairExtra> pextra_;
 	std::vector<int> pair_of_, half_of_;
