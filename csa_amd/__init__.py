@@ -38,7 +38,7 @@ class Task(ctypes.Structure):
 class Result(ctypes.Structure):
     _fields_ = [("status", ctypes.c_int), ("score", ctypes.c_int), ("consensus", ctypes.c_int),
                 ("fills", ctypes.c_int), ("cells", ctypes.c_longlong),
-                ("aligned", ctypes.POINTER(ctypes.c_void_p))]
+                ("aligned", ctypes.POINTER(ctypes.c_void_p)), ("progress", ctypes.c_void_p)]
 
 
 class SpStats(ctypes.Structure):
@@ -75,10 +75,11 @@ class Timing(ctypes.Structure):
 # symbols declared in include/csadp.h and include/csadp_debug.h
 EXPORTS = [
     "csadp_init", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
-    "csadp_align_batch", "csadp_free_result",
+    "csadp_align_batch", "csadp_free_result", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
+    "csadp_align_batch_multi", "csadp_pairs_create_on",
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
-    "csadp_partition_lpt", "csadp_load_fasta", "csadp_free_fasta",
+    "csadp_partition_lpt", "csadp_fnv1a", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
     "csadp_build_anchor_map", "csadp_free_anchor_map", "csadp_msa", "csadp_free_rows", "csadp_write_aligned_fasta",
     "csadp_debug_align_with_filler",
@@ -176,7 +177,8 @@ def _unpack(results, nseqs):
         if r.status == OK and r.aligned:
             strs = [ctypes.string_at(r.aligned[i]) for i in range(n)]
         out.append({"status": r.status, "score": r.score, "consensus": r.consensus, "fills": r.fills,
-                    "cells": r.cells, "aligned": strs})
+                    "cells": r.cells, "aligned": strs,
+                    "progress": ctypes.string_at(r.progress).decode() if r.progress else ""})
         L.csadp_free_result(ctypes.byref(r), n)
     return out
 
@@ -189,13 +191,65 @@ def align_batch(tasks):
     return _unpack(res[:ta.n], ta.nseq)
 
 
+class MultiStats(ctypes.Structure):
+    _fields_ = [("ndevices", ctypes.c_int), ("tasks", ctypes.c_int * 16), ("cost", ctypes.c_longlong * 16),
+                ("ms", ctypes.c_double * 16), ("total_cost", ctypes.c_longlong), ("max_cost", ctypes.c_longlong),
+                ("wall_ms", ctypes.c_double)]
+
+
+def device_count():
+    n = ctypes.c_int()
+    rc = lib().csadp_device_count(ctypes.byref(n))
+    return n.value if rc == OK else 0
+
+
+def task_cost(task):
+    ta = TaskArray([task])
+    L = lib()
+    L.csadp_task_cost.restype = ctypes.c_longlong
+    L.csadp_task_cost.argtypes = [ctypes.POINTER(Task)]
+    return L.csadp_task_cost(ta.arr)
+
+
+def align_batch_on(device, tasks):
+    """csadp_align_batch_on: the batch on an explicitly named HIP device."""
+    ta = TaskArray(tasks)
+    res = (Result * max(ta.n, 1))()
+    L = lib()
+    L.csadp_align_batch_on.argtypes = [ctypes.c_int, ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(Result)]
+    _check(L.csadp_align_batch_on(device, ta.arr, ta.n, res), "csadp_align_batch_on")
+    return _unpack(res[:ta.n], ta.nseq)
+
+
+def align_batch_multi(tasks, devices):
+    """csadp_align_batch_multi: one batch over several GPUs of this node from one process
+    (LPT partition, one host thread per GPU).  devices = list of HIP ordinals.  Returns (results, stats)."""
+    ta = TaskArray(tasks)
+    res = (Result * max(ta.n, 1))()
+    st = MultiStats()
+    dev = (ctypes.c_int * len(devices))(*devices)
+    L = lib()
+    L.csadp_align_batch_multi.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(Result), ctypes.POINTER(ctypes.c_int),
+                                          ctypes.c_int, ctypes.POINTER(MultiStats)]
+    _check(L.csadp_align_batch_multi(ta.arr, ta.n, res, dev, len(devices), ctypes.byref(st)), "csadp_align_batch_multi")
+    n = st.ndevices
+    stats = {"ndevices": n, "tasks": list(st.tasks[:n]), "cost": list(st.cost[:n]), "ms": list(st.ms[:n]),
+             "total_cost": st.total_cost, "max_cost": st.max_cost, "wall_ms": st.wall_ms}
+    return _unpack(res[:ta.n], ta.nseq), stats
+
+
 class PairBatch:
     """Device-resident batch of 2-sequence tasks (csadp_pairs_*)."""
 
-    def __init__(self, tasks):
+    def __init__(self, tasks, device=None):
         self.ta = TaskArray(tasks)
         self.h = ctypes.c_void_p()
-        _check(lib().csadp_pairs_create(self.ta.arr, self.ta.n, ctypes.byref(self.h)), "csadp_pairs_create")
+        if device is None:
+            _check(lib().csadp_pairs_create(self.ta.arr, self.ta.n, ctypes.byref(self.h)), "csadp_pairs_create")
+        else:
+            L = lib()
+            L.csadp_pairs_create_on.argtypes = [ctypes.c_int, ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+            _check(L.csadp_pairs_create_on(device, self.ta.arr, self.ta.n, ctypes.byref(self.h)), "csadp_pairs_create_on")
 
     def run(self):
         _check(lib().csadp_pairs_run(self.h), "csadp_pairs_run")
@@ -310,6 +364,16 @@ def write_aligned_fasta(path, descs, rotations, rows):
     L.csadp_write_aligned_fasta.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_int),
                                             ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
     _check(L.csadp_write_aligned_fasta(path.encode(), d, rot, r, n), "csadp_write_aligned_fasta")
+
+
+def fnv1a(strs):
+    """csadp_fnv1a over a list of byte strings."""
+    n = len(strs)
+    arr = (ctypes.c_char_p * n)(*strs)
+    L = lib()
+    L.csadp_fnv1a.restype = ctypes.c_uint
+    L.csadp_fnv1a.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.c_int]
+    return L.csadp_fnv1a(arr, n)
 
 
 def partition_lpt(costs, nparts):

@@ -7,7 +7,10 @@
  * (tools.c:274-280) and the FNV-1a digest of the two aligned strings.
  *
  *   csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated <base>-Rotated.fasta] [--find-rotations]
- *             [--pair a,b] [--write-rotated out.fasta]
+ *             [--pair a,b] [--write-rotated out.fasta] [--gpus N]
+ *
+ * --gpus N (N > 1): the pairs are one batch over N GPUs of this node (csadp_align_batch_multi:
+ * longest-processing-time partition, one host thread per GPU, results gathered in host memory).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -54,7 +57,7 @@ int main(int argc, char **argv)
 	int *sizes, *rot;
 	int nseq = 0, i, a, b, rc, only_a = -1, only_b = -1, npairs = 0, p;
 	const char *rotated = NULL, *rotlist = NULL, *write_rot = NULL;
-	int find_rot = 0;
+	int find_rot = 0, gpus = 1;
 	csadp_task *tasks;
 	csadp_result *res;
 	csadp_pairbatch *batch;
@@ -64,7 +67,7 @@ int main(int argc, char **argv)
 	long long cells = 0;
 
 	if (argc < 2) {
-		fprintf(stderr, "usage: csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated file] [--find-rotations] [--pair a,b] [--write-rotated out]\n");
+		fprintf(stderr, "usage: csa_pairs <input.fasta> [--rot r0,r1,...] [--rotated file] [--find-rotations] [--pair a,b] [--write-rotated out] [--gpus N]\n");
 		return 1;
 	}
 	for (i = 2; i < argc; i++) {
@@ -72,6 +75,7 @@ int main(int argc, char **argv)
 		else if (!strcmp(argv[i], "--rotated") && i + 1 < argc) rotated = argv[++i];
 		else if (!strcmp(argv[i], "--write-rotated") && i + 1 < argc) write_rot = argv[++i];
 		else if (!strcmp(argv[i], "--find-rotations")) find_rot = 1;
+		else if (!strcmp(argv[i], "--gpus") && i + 1 < argc) gpus = atoi(argv[++i]);
 		else if (!strcmp(argv[i], "--pair") && i + 1 < argc) { if (sscanf(argv[++i], "%d,%d", &only_a, &only_b) != 2) return 1; }
 		else { fprintf(stderr, "csa_pairs: unknown argument %s\n", argv[i]); return 1; }
 	}
@@ -128,6 +132,26 @@ int main(int argc, char **argv)
 			cells += (long long)sizes[a] * sizes[b];
 			p++;
 		}
+	}
+	if (gpus > 1) {
+		csadp_multi_stats ms;
+		t0 = now_s();
+		if ((rc = csadp_align_batch_multi(tasks, npairs, res, NULL, gpus, &ms)) != CSADP_OK) die("align_batch_multi", rc);
+		t1 = now_s();
+		for (p = 0; p < npairs; p++) {
+			if (res[p].status != CSADP_OK) die("pair", res[p].status);
+			printf("pair %d %d len %d SP %lld score %d fnv1a %08x\n", pa[p], pb[p], res[p].consensus,
+			       sp2(res[p].aligned[0], res[p].aligned[1]), res[p].score, fnv1a2(res[p].aligned[0], res[p].aligned[1]));
+			csadp_free_result(&res[p], 2);
+		}
+		for (i = 0; i < ms.ndevices; i++)
+			printf("> gpu %d: %d pairs, %lld cells, %.1f ms\n", i, ms.tasks[i], ms.cost[i], ms.ms[i]);
+		printf("> %d pairs, %lld cells over %d GPUs: imbalance %.3f, host-to-host %.1f ms = %.1f GCUPS\n", npairs, cells, gpus,
+		       ms.total_cost ? (double)ms.max_cost * ms.ndevices / (double)ms.total_cost : 1.0, (t1 - t0) * 1e3,
+		       (double)cells / ((t1 - t0) * 1e9));
+		csadp_shutdown();
+		csadp_free_fasta(texts, descs, sizes, nseq);
+		return 0;
 	}
 	setenv("CSADP_SLOTS", "1", 0);      /* one pass only: no need for pipelined scratch sets */
 	if ((rc = csadp_init(NULL)) != CSADP_OK) die("init", rc);

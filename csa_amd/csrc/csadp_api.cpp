@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -28,13 +29,6 @@ using csadp::FillBatch;
 using csadp::Progressive;
 
 namespace {
-
-/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) alive
- * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per
- * input set) and must not pay hipMalloc/hipHostMalloc every time.  Released by
- * csadp_shutdown(); deliberately not a static object (no HIP calls at process exit). */
-std::mutex g_batch_mutex;
-FillBatch *g_batch = nullptr;
 
 /* Per-task host work (validation, table packing, traceback application, string building) is
  * independent across tasks: spread it over a persistent pool of host threads
@@ -120,13 +114,6 @@ void parallel_for(int n, F &&fn)
 	HostPool::get().run(body, workers);
 }
 
-void release_cached_batch()
-{
-	std::lock_guard<std::mutex> lock(g_batch_mutex);
-	delete g_batch;
-	g_batch = nullptr;
-}
-
 }  // namespace
 
 extern "C" {
@@ -148,28 +135,42 @@ const char *csadp_strerror(int code)
 	}
 }
 
-int csadp_init(const csadp_config *cfg) { return Engine::get().init(cfg); }
-void csadp_shutdown(void)
+int csadp_init(const csadp_config *cfg)
 {
-	release_cached_batch();
-	Engine::get().shutdown();
+	int rc = CSADP_OK;
+	Engine::primary(cfg, &rc);
+	return rc;
 }
+
+void csadp_shutdown(void) { Engine::shutdown_all(); }
 
 int csadp_device_info(char *name, int namelen, int *compute_units)
 {
-	Engine &E = Engine::get();
-	if (!E.ready()) return CSADP_ERR_NO_DEVICE;
-	if (name && namelen > 0) snprintf(name, (size_t)namelen, "%s", E.name());
-	if (compute_units) *compute_units = E.compute_units();
+	Engine *E = Engine::primary_if_ready();
+	if (!E) return CSADP_ERR_NO_DEVICE;
+	if (name && namelen > 0) snprintf(name, (size_t)namelen, "%s", E->name());
+	if (compute_units) *compute_units = E->compute_units();
+	return CSADP_OK;
+}
+
+int csadp_device_count(int *count)
+{
+	if (!count) return CSADP_ERR_ARG;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { *count = 0; return CSADP_ERR_NO_DEVICE; }
+	*count = n;
 	return CSADP_OK;
 }
 
 void csadp_free_result(csadp_result *r, int nseq)
 {
-	if (!r || !r->aligned) return;
+	if (!r) return;
+	if (!r->aligned) { free(r->progress); r->progress = NULL; return; }
 	for (int s = 0; s < nseq; ++s) free(r->aligned[s]);
 	free(r->aligned);
 	r->aligned = NULL;
+	free(r->progress);
+	r->progress = NULL;
 }
 
 }  // extern "C"
@@ -236,6 +237,7 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 }  // namespace
 
 struct csadp_pairbatch {
+	explicit csadp_pairbatch(Engine *e) : fb(e) {}
 	std::vector<Progressive> tasks;
 	std::vector<int> status;
 	std::vector<int> active;     /* tasks that own a job of the batch */
@@ -243,15 +245,11 @@ struct csadp_pairbatch {
 	bool ran = false, fetched = false;
 };
 
-extern "C" {
+namespace {
 
-int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results)
+/* csadp_align_batch on one engine: lock-step rounds over the engine's cached arena */
+int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result *results)
 {
-	if (!tasks || !results || ntasks < 0) return CSADP_ERR_ARG;
-	if (!Engine::get().ready()) {
-		const int rc = csadp_init(NULL);
-		if (rc != CSADP_OK) return rc;
-	}
 	std::vector<Progressive> prog((size_t)ntasks);
 	std::vector<int> status((size_t)ntasks, CSADP_OK);
 	parallel_for(ntasks, [&](int t) {
@@ -259,15 +257,15 @@ int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results
 		status[(size_t)t] = prog[(size_t)t].init(tasks[t]);
 	});
 	{
-		std::lock_guard<std::mutex> lock(g_batch_mutex);
-		if (!g_batch) g_batch = new (std::nothrow) FillBatch;
-		if (!g_batch) return CSADP_ERR_NOMEM;
+		std::lock_guard<std::mutex> lock(E->batch_mutex);
+		if (!E->cached_batch) E->cached_batch = new (std::nothrow) FillBatch(E);
+		if (!E->cached_batch) return CSADP_ERR_NOMEM;
 		for (;;) {
 			std::vector<int> active;
 			for (int t = 0; t < ntasks; ++t)
 				if (status[t] == CSADP_OK && advance(prog[t])) active.push_back(t);
 			if (active.empty()) break;
-			const int rc = run_round(prog, active, *g_batch, status);
+			const int rc = run_round(prog, active, *E->cached_batch, status);
 			if (rc != CSADP_OK) return rc;
 		}
 	}
@@ -278,23 +276,131 @@ int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results
 	return CSADP_OK;
 }
 
-static int pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores);
+}  // namespace
+
+extern "C" {
+
+int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results)
+{
+	if (!tasks || !results || ntasks < 0) return CSADP_ERR_ARG;
+	int rc = CSADP_OK;
+	Engine *E = Engine::primary(NULL, &rc);
+	if (!E) return rc;
+	return align_batch_on(E, tasks, ntasks, results);
+}
+
+int csadp_align_batch_on(int device, const csadp_task *tasks, int ntasks, csadp_result *results)
+{
+	if (!tasks || !results || ntasks < 0) return CSADP_ERR_ARG;
+	int rc = CSADP_OK;
+	Engine *E = Engine::open(device, NULL, &rc);
+	if (!E) return rc;
+	return align_batch_on(E, tasks, ntasks, results);
+}
+
+long long csadp_task_cost(const csadp_task *task)
+{
+	if (!task || task->nseq < 2 || task->nseq > CSADP_MAX_SEQS || !task->starts || !task->ends) return -1;
+	std::vector<long long> len((size_t)task->nseq);
+	for (int s = 0; s < task->nseq; ++s) {
+		len[(size_t)s] = (long long)task->ends[s] - task->starts[s];
+		if (len[(size_t)s] < 0) return -1;
+	}
+	std::sort(len.begin(), len.end());                    /* SortSequencesForDP, :276-308 */
+	long long cost = 0, consensus = len[0];
+	for (int i = 1; i < task->nseq; ++i) {               /* the consensus never shrinks below the longest row so far */
+		cost += len[(size_t)i] * consensus;
+		consensus = std::max(consensus, len[(size_t)i]);
+	}
+	return cost;
+}
+
+int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp_result *results, const int *devices, int ndevices,
+                            csadp_multi_stats *stats)
+{
+	if (!tasks || !results || ntasks < 0 || ndevices < 1 || ndevices > CSADP_MAX_DEVICES) return CSADP_ERR_ARG;
+	std::vector<long long> cost((size_t)ntasks);
+	for (int t = 0; t < ntasks; ++t) {
+		cost[(size_t)t] = csadp_task_cost(&tasks[t]);
+		if (cost[(size_t)t] < 0) return CSADP_ERR_ARG;
+	}
+	std::vector<int> part((size_t)ntasks);
+	long long maxload = 0;
+	int rc = csadp_partition_lpt(cost.data(), ntasks, ndevices, part.data(), &maxload);
+	if (rc != CSADP_OK) return rc;
+	/* engines first, on this thread: a missing device fails the call before any work starts */
+	std::vector<Engine *> eng((size_t)ndevices);
+	for (int d = 0; d < ndevices; ++d) {
+		eng[(size_t)d] = Engine::open(devices ? devices[d] : d, NULL, &rc);
+		if (!eng[(size_t)d]) return rc;
+	}
+	std::vector<std::vector<int>> mine((size_t)ndevices);
+	for (int t = 0; t < ntasks; ++t) mine[(size_t)part[(size_t)t]].push_back(t);
+	std::vector<int> drc((size_t)ndevices, CSADP_OK);
+	std::vector<double> dms((size_t)ndevices, 0.0);
+	const auto t0 = std::chrono::steady_clock::now();
+	/* one host thread per GPU: gathers its tasks, aligns them on its device, scatters the results back */
+	auto work = [&](int d) {
+		const std::vector<int> &idx = mine[(size_t)d];
+		if (idx.empty()) return;
+		const auto td = std::chrono::steady_clock::now();
+		std::vector<csadp_task> sub(idx.size());
+		std::vector<csadp_result> res(idx.size());
+		for (size_t i = 0; i < idx.size(); ++i) sub[i] = tasks[idx[i]];
+		int r = eng[(size_t)d]->bind();
+		if (r == CSADP_OK) r = align_batch_on(eng[(size_t)d], sub.data(), (int)sub.size(), res.data());
+		drc[(size_t)d] = r;
+		if (r == CSADP_OK)
+			for (size_t i = 0; i < idx.size(); ++i) results[idx[i]] = res[i];
+		dms[(size_t)d] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
+	};
+	std::vector<std::thread> threads;
+	for (int d = 1; d < ndevices; ++d) threads.emplace_back(work, d);
+	work(0);
+	for (std::thread &th : threads) th.join();
+	(void)eng[0]->bind();
+	if (stats) {
+		memset(stats, 0, sizeof(*stats));
+		stats->ndevices = ndevices;
+		stats->wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		stats->max_cost = maxload;
+		for (int t = 0; t < ntasks; ++t) {
+			stats->cost[part[(size_t)t]] += cost[(size_t)t];
+			stats->tasks[part[(size_t)t]]++;
+			stats->total_cost += cost[(size_t)t];
+		}
+		for (int d = 0; d < ndevices; ++d) stats->ms[d] = dms[(size_t)d];
+	}
+	for (int d = 0; d < ndevices; ++d)
+		if (drc[(size_t)d] != CSADP_OK) return drc[(size_t)d];
+	return CSADP_OK;
+}
+
+static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores);
 
 int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out)
 {
-	return pairs_create(tasks, ntasks, out, false);
+	if (!tasks || !out || ntasks <= 0) return CSADP_ERR_ARG;
+	int rc = CSADP_OK;
+	Engine *E = Engine::primary(NULL, &rc);
+	if (!E) return rc;
+	return pairs_create(E, tasks, ntasks, out, false);
+}
+
+int csadp_pairs_create_on(int device, const csadp_task *tasks, int ntasks, csadp_pairbatch **out)
+{
+	if (!tasks || !out || ntasks <= 0) return CSADP_ERR_ARG;
+	int rc = CSADP_OK;
+	Engine *E = Engine::open(device, NULL, &rc);
+	if (!E) return rc;
+	return pairs_create(E, tasks, ntasks, out, false);
 }
 
 /* device_scores: the caller only wants DP scores -- where the traceback kernel can sum its path
  * itself it does, and the host never walks the traces */
-static int pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores)
+static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores)
 {
-	if (!tasks || !out || ntasks <= 0) return CSADP_ERR_ARG;
-	if (!Engine::get().ready()) {
-		const int rc = csadp_init(NULL);
-		if (rc != CSADP_OK) return rc;
-	}
-	std::unique_ptr<csadp_pairbatch> b(new (std::nothrow) csadp_pairbatch);
+	std::unique_ptr<csadp_pairbatch> b(new (std::nothrow) csadp_pairbatch(E));
 	if (!b) return CSADP_ERR_NOMEM;
 	b->tasks = std::vector<Progressive>((size_t)ntasks);
 	b->status.assign((size_t)ntasks, CSADP_OK);
@@ -407,7 +513,10 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 {
 	if (!tasks || !scores || ntasks <= 0) return CSADP_ERR_ARG;
 	csadp_pairbatch *b = nullptr;
-	int rc = pairs_create(tasks, ntasks, &b, true);
+	int rc = CSADP_OK;
+	Engine *E = Engine::primary(NULL, &rc);
+	if (!E) return rc;
+	rc = pairs_create(E, tasks, ntasks, &b, true);
 	if (rc != CSADP_OK) return rc;
 	if ((rc = csadp_pairs_run(b)) == CSADP_OK && !b->active.empty()) rc = b->fb.download();
 	if (rc != CSADP_OK) { delete b; return rc; }
@@ -438,10 +547,9 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out)
 {
 	if (!aligned || !out || nseq < 2 || !aligned[0]) return CSADP_ERR_ARG;
-	if (!Engine::get().ready()) {
-		const int rc = csadp_init(NULL);
-		if (rc != CSADP_OK) return rc;
-	}
+	int erc = CSADP_OK;
+	Engine *E = Engine::primary(NULL, &erc);
+	if (!E) return erc;
 	const size_t len = strlen(aligned[0]);
 	for (int s = 1; s < nseq; ++s)
 		if (!aligned[s] || strlen(aligned[s]) != len) return CSADP_ERR_ARG;   /* tools.c:248-254 */
@@ -450,7 +558,7 @@ int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out)
 	if (len == 0) return CSADP_OK;
 	std::vector<char> host((size_t)nseq * len);
 	for (int s = 0; s < nseq; ++s) memcpy(&host[(size_t)s * len], aligned[s], len);
-	hipStream_t st = Engine::get().stream(0);
+	hipStream_t st = E->stream(0);
 	uint8_t *d_chars = nullptr;
 	long long *d_out = nullptr;
 	long long h_out[3] = {0, 0, 0};

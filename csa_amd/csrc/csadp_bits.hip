@@ -669,6 +669,15 @@ __global__ __launch_bounds__(64) void nw_traceback_bits(uint8_t *__restrict__ ar
 	}
 }
 
+/* 27 KB static + this = more than half of a compute unit's 160 KB: one nw_fill_bits_wide workgroup per unit */
+constexpr size_t kWideReserve = 56 * 1024;
+
+/* function attributes are per device: called by Engine::init with that device current */
+hipError_t configure_kernels()
+{
+	return hipFuncSetAttribute((const void *)nw_fill_bits_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
+}
+
 hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
                             hipStream_t st)
 {
@@ -683,15 +692,7 @@ hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, 
                                  int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0 || nwork <= 0 || passes <= 0) return hipSuccess;
-	/* 27 KB static + this = more than half of a compute unit's 160 KB: one workgroup per unit */
-	constexpr size_t kReserve = 56 * 1024;
-	static bool configured = false;
-	if (!configured) {
-		hipError_t e = hipFuncSetAttribute((const void *)nw_fill_bits_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReserve);
-		if (e != hipSuccess) return e;
-		configured = true;
-	}
-	hipLaunchKernelGGL(nw_fill_bits_wide, dim3(nwork, passes), dim3(kBitMaxStrips * kLanes), kReserve, st, arena, jobs, njobs, work, abort_word);
+	hipLaunchKernelGGL(nw_fill_bits_wide, dim3(nwork, passes), dim3(kBitMaxStrips * kLanes), kWideReserve, st, arena, jobs, njobs, work, abort_word);
 	return hipGetLastError();
 }
 

@@ -6,7 +6,7 @@
  * Packs the reference-shaped globals into one csadp_task, runs it on the GPU through
  * libcsadp.so and hands the malloc'd strings to the segment (freed later by
  * DeleteAlignmentMap, alignmentmap.c:174-179).  Prints the reference's progress tokens
- * (:917, :1156, :1159) so logs diff cleanly.  On a library error the process cannot
+ * (:917, :1156, :689, :1159) so logs diff cleanly.  On a library error the process cannot
  * continue meaningfully (the reference has no error path here either): the adapter prints
  * the reason and exits non-zero -- it never falls back to a CPU computation.
  */
@@ -45,7 +45,8 @@ void ProgressiveDP(struct _alignmapsegment *segment)
 		fprintf(stderr, "\ncsadp drop-in: ProgressiveDP failed: %s\n", csadp_strerror(rc));
 		exit(2);
 	}
-	for (s = 0; s < res.fills; s++) printf(".");                       /* :1156, one per fill */
+	fputs(res.progress ? res.progress : "", stdout);                    /* :1156 '.' per fill, :689 '!' per all-gap column */
+	free(res.progress);
 	printf("->%4d]\n", res.consensus);                                  /* :1159 */
 	fflush(stdout);
 	segment->alignedstrings = res.aligned;                              /* :1160 */

@@ -37,23 +37,76 @@ int env_int(const char *name, int dflt)
 
 }  // namespace
 
-Engine &Engine::get()
-{
-	static Engine e;
-	return e;
-}
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_registry_mutex;
+Engine *g_engines[kMaxDevices] = {};
+Engine *g_primary = nullptr;
+}  // namespace
 
-int Engine::init(const csadp_config *cfg)
+Engine *Engine::open(int device, const csadp_config *cfg, int *rc)
 {
-	if (ready_) return CSADP_OK;
+	std::lock_guard<std::mutex> lock(g_registry_mutex);
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
 		fprintf(stderr, "csadp: no HIP device available (this library has no CPU fallback)\n");
-		return CSADP_ERR_NO_DEVICE;
+		*rc = CSADP_ERR_NO_DEVICE;
+		return nullptr;
+	}
+	if (device < 0 || device >= kMaxDevices) { *rc = CSADP_ERR_ARG; return nullptr; }
+	if (device >= count) {
+		/* several ranks on one GPU give per-GPU numbers that are not per-GPU: only on request (rehearsals) */
+		if (env_int("CSADP_SHARE_DEVICE", 0) == 0) {
+			fprintf(stderr, "csadp: HIP device %d requested, %d visible (CSADP_SHARE_DEVICE=1 maps ranks onto the visible ones)\n", device, count);
+			*rc = CSADP_ERR_NO_DEVICE;
+			return nullptr;
+		}
+		device %= count;
+	}
+	if (!g_engines[device]) g_engines[device] = new Engine;       /* never deleted: no HIP calls at process exit */
+	Engine *e = g_engines[device];
+	*rc = e->ready_ ? e->bind() : e->init(device, cfg);
+	if (*rc != CSADP_OK) return nullptr;
+	if (!g_primary) g_primary = e;
+	return e;
+}
+
+Engine *Engine::primary(const csadp_config *cfg, int *rc)
+{
+	{
+		std::lock_guard<std::mutex> lock(g_registry_mutex);
+		if (g_primary && g_primary->ready_) {
+			*rc = g_primary->bind();
+			return *rc == CSADP_OK ? g_primary : nullptr;
+		}
 	}
 	int dev = cfg ? cfg->device : -1;
 	if (dev < 0) dev = env_int("LOCAL_RANK", 0);
-	if (dev >= count) dev %= count;
+	return open(dev, cfg, rc);
+}
+
+Engine *Engine::primary_if_ready()
+{
+	std::lock_guard<std::mutex> lock(g_registry_mutex);
+	return (g_primary && g_primary->ready_) ? g_primary : nullptr;
+}
+
+void Engine::shutdown_all()
+{
+	std::lock_guard<std::mutex> lock(g_registry_mutex);
+	for (Engine *e : g_engines)
+		if (e) e->shutdown();
+	g_primary = nullptr;
+}
+
+int Engine::bind() const
+{
+	HIP_TRY(hipSetDevice(device_));
+	return CSADP_OK;
+}
+
+int Engine::init(int dev, const csadp_config *cfg)
+{
 	HIP_TRY(hipSetDevice(dev));
 	hipDeviceProp_t prop;
 	HIP_TRY(hipGetDeviceProperties(&prop, dev));
@@ -74,6 +127,7 @@ int Engine::init(const csadp_config *cfg)
 	if (R_ != 1 && R_ != 2 && R_ != 4) return CSADP_ERR_ARG;
 	if (C_ == 32 && R_ == 4) return CSADP_ERR_ARG;
 	if (TR_ != 64 && TR_ != 128 && TR_ != 256) return CSADP_ERR_ARG;
+	HIP_TRY(configure_kernels());                     /* per-device function attributes (csadp_bits.hip) */
 	verbose_ = cfg && cfg->verbose;
 	ready_ = true;
 	return CSADP_OK;
@@ -108,6 +162,12 @@ void Engine::drop_arena_cache()
 void Engine::shutdown()
 {
 	if (!ready_) return;
+	(void)hipSetDevice(device_);
+	{
+		std::lock_guard<std::mutex> lock(batch_mutex);
+		delete cached_batch;
+		cached_batch = nullptr;
+	}
 	drop_arena_cache();
 	for (int i = 0; i < std::max(slots_, 2); ++i) {
 		(void)hipStreamSynchronize(streams_[i]);
@@ -121,7 +181,8 @@ void Engine::shutdown()
 
 FillBatch::~FillBatch()
 {
-	if (arena_) Engine::get().give_arena(arena_, arena_cap_);
+	(void)E_->bind();
+	if (arena_) E_->give_arena(arena_, arena_cap_);
 	if (h_in_) (void)hipHostFree(h_in_);
 	if (h_res_) (void)hipHostFree(h_res_);
 	if (h_abort_) (void)hipHostFree(h_abort_);
@@ -163,8 +224,9 @@ int FillBatch::add(int nrows, int ncols, int nprev, int left_i)
 
 int FillBatch::layout()
 {
-	Engine &E = Engine::get();
+	Engine &E = *E_;
 	if (!E.ready()) return CSADP_ERR_NO_DEVICE;
+	{ const int brc = E.bind(); if (brc != CSADP_OK) return brc; }
 	const int C = E.C(), R = E.R(), TR = E.TR(), W = C / 16;
 	const int nj = (int)jobs_.size();
 	extra_.assign(nj, Extra());
@@ -345,7 +407,7 @@ int FillBatch::ncols_pad(int j) const { return pk_ ? pextra_[(size_t)pair_of_[(s
  * the pair uses the geometry of the larger matrix.  Same arena structure as layout(). */
 int FillBatch::layout_pk()
 {
-	Engine &E = Engine::get();
+	Engine &E = *E_;
 	const int C = 16, R = E.R(), TR = E.TR();
 	const int nj = (int)jobs_.size();
 	std::vector<int> order((size_t)nj);
@@ -576,7 +638,7 @@ int32_t *FillBatch::pk_top(int j)
 /* Bit-parallel mode: one BitJob per fill, the whole matrix in one launch (csadp_bits.hip). */
 int FillBatch::layout_bits()
 {
-	Engine &E = Engine::get();
+	Engine &E = *E_;
 	const int nj = (int)jobs_.size();
 	bjobs_.assign((size_t)nj, BitJob());
 	bextra_.assign((size_t)nj, BitExtra());
@@ -710,7 +772,7 @@ int FillBatch::layout_bits()
 /* HBM arena, pinned staging mirrors (zeroed inputs), events */
 int FillBatch::finish_layout()
 {
-	Engine &E = Engine::get();
+	Engine &E = *E_;
 	if (total_bytes_ > arena_cap_) {
 		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
 		arena_ = E.take_arena(total_bytes_, &arena_cap_);
@@ -757,11 +819,12 @@ int FillBatch::bit_rowwords(int j) const { return bjobs_[(size_t)j].rowwords; }
 
 int FillBatch::upload()
 {
+	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!laid_out_) return CSADP_ERR_STATE;
 	/* every slot's stream must see the inputs: copy on slot 0 and wait (upload is not on the
 	 * timed path; run() calls may follow on any stream) */
-	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, Engine::get().stream(0)));
-	HIP_TRY(hipStreamSynchronize(Engine::get().stream(0)));
+	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, E_->stream(0)));
+	HIP_TRY(hipStreamSynchronize(E_->stream(0)));
 	return CSADP_OK;
 }
 
@@ -775,6 +838,7 @@ int FillBatch::run()
 
 int FillBatch::flush()
 {
+	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (pending_ == 0) return CSADP_OK;
 	const int k = pending_;
 	pending_ = 0;
@@ -797,7 +861,7 @@ int FillBatch::flush()
  * reused in stream order. */
 int FillBatch::flush_bits(int k)
 {
-	Engine &E = Engine::get();
+	Engine &E = *E_;
 	const int nj = (int)bjobs_.size();
 	while (k > 0) {
 		const int first = next_slot_;
@@ -832,7 +896,7 @@ int FillBatch::flush_bits(int k)
 /* Enqueue ONE pass (fill + traceback) of slot sl on stream sl. */
 int FillBatch::run_slot(int sl, bool persistent)
 {
-	Engine &E = Engine::get();
+	Engine &E = *E_;
 	hipStream_t st = E.stream(sl);
 	hipEvent_t *ev = ev_[sl];
 	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);
@@ -869,20 +933,22 @@ int FillBatch::run_slot(int sl, bool persistent)
 
 int FillBatch::sync()
 {
+	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	const int rc = flush();
 	if (rc != CSADP_OK) return rc;
-	for (int sl = 0; sl < std::max(Engine::get().slots(), 2); ++sl) HIP_TRY(hipStreamSynchronize(Engine::get().stream(sl)));
+	for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
 	return CSADP_OK;
 }
 
 int FillBatch::download()
 {
+	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!ran_) return CSADP_ERR_STATE;
 	{
 		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
 		if (rc != CSADP_OK) return rc;
 	}
-	hipStream_t st = Engine::get().stream(bits_ ? (nslots_ > 1 ? (last_slot_ / bits_group_) % bits_streams_ : 0) : last_slot_);
+	hipStream_t st = E_->stream(bits_ ? (nslots_ > 1 ? (last_slot_ / bits_group_) % bits_streams_ : 0) : last_slot_);
 	if (bits_) {
 		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + flags_off_[flag_slot_[last_slot_]], 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
@@ -913,6 +979,7 @@ const int32_t *FillBatch::summary(int j) const { return reinterpret_cast<const i
 
 int FillBatch::timing(csadp_timing *t)
 {
+	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!ran_) return CSADP_ERR_STATE;
 	{
 		const int rc = flush();

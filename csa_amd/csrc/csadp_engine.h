@@ -8,6 +8,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <vector>
 
 #include "csadp.h"
@@ -15,11 +16,24 @@
 
 namespace csadp {
 
+class FillBatch;
+
+/*
+ * One Engine per HIP device of the process (streams, arena cache, the cached csadp_align_batch
+ * arena).  The process-wide entry points (csadp_init, csadp_align_batch, ...) use the PRIMARY
+ * engine -- the device csadp_init selected -- and the *_on(device) entry points address any other
+ * one, so a host program can drive every GPU of a node from one thread per GPU.  HIP's current
+ * device is a per-thread setting: every entry point that touches HIP calls bind() first.
+ */
 class Engine {
 public:
-	static Engine &get();
-	int init(const csadp_config *cfg);
-	void shutdown();
+	/* the primary engine, created by the first csadp_init / first use; nullptr + rc on failure */
+	static Engine *primary(const csadp_config *cfg, int *rc);
+	/* get-or-create the engine of HIP device `device` (thread-safe) */
+	static Engine *open(int device, const csadp_config *cfg, int *rc);
+	static Engine *primary_if_ready();
+	static void shutdown_all();
+	int bind() const;                /* hipSetDevice(device_) on the calling thread */
 	bool ready() const { return ready_; }
 	static constexpr int kMaxSlots = 16;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
@@ -37,7 +51,14 @@ public:
 	uint8_t *take_arena(size_t need, size_t *got);
 	void drop_arena_cache();
 
+	/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) per device alive
+	 * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per input set) */
+	std::mutex batch_mutex;
+	FillBatch *cached_batch = nullptr;
+
 private:
+	int init(int device, const csadp_config *cfg);
+	void shutdown();
 	bool ready_ = false;
 	bool verbose_ = false;
 	int device_ = 0;
@@ -65,8 +86,9 @@ private:
  */
 class FillBatch {
 public:
-	FillBatch() = default;
+	explicit FillBatch(Engine *engine) : E_(engine) {}
 	~FillBatch();
+	Engine *engine() const { return E_; }
 	FillBatch(const FillBatch &) = delete;
 	FillBatch &operator=(const FillBatch &) = delete;
 
@@ -117,6 +139,7 @@ public:
 	int timing(csadp_timing *t);
 
 private:
+	Engine *E_;
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
 	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
 	struct BitExtra { size_t in_cols, in_rows; };

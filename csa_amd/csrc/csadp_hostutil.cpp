@@ -34,6 +34,22 @@ int csadp_partition_lpt(const long long *cost, int n, int nparts, int *assign, l
 	return CSADP_OK;
 }
 
+/* FNV-1a-32 over strings[0], strings[1], ...: the digest of SURVEY.md 8(c)'s golden values and of the
+ * fixed-size result records ranks exchange (bench.py, csa_amd/dist.py) */
+unsigned csadp_fnv1a(const char *const *strings, int n)
+{
+	unsigned h = 0x811c9dc5u;
+	if (!strings) return h;
+	for (int s = 0; s < n; ++s) {
+		if (!strings[s]) continue;
+		for (const unsigned char *p = (const unsigned char *)strings[s]; *p; ++p) {
+			h ^= *p;
+			h *= 0x01000193u;
+		}
+	}
+	return h;
+}
+
 /*
  * csamsa.c:433-519.  Records start at '>', the description runs to end of line; sequence
  * bytes: \n \r NUL '-' ' ' skipped; ACGT and the IUPAC codes RYSWKMDHBVN kept (lower case

@@ -356,6 +356,7 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 	last_score_ = (int)score;
 	cells_ += (long long)nrows * (long long)ncols;
 	++fills_;
+	tokens_.push_back('.');                                 /* :1156 */
 	if (i > 1) delete_gapped_columns(i + 1, (i + 1) / 2);   /* :1157 */
 	++step_;
 	pending_ = false;
@@ -391,7 +392,7 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			if (str_[s][col - 1] != '-') movers.push_back(s);
 		}
 		const int nmov = (int)movers.size();
-		if (nmov == 0) continue;                                      /* :688 (prints "!") */
+		if (nmov == 0) { tokens_.push_back('!'); continue; }          /* :688-690 */
 		int bestscore = 0, bestshift = 0;
 		block.assign(nmov, 0);
 		nextgaps.assign(nmov, 0);
@@ -524,10 +525,13 @@ int Progressive::finish(csadp_result *res)
 	res->cells = cells_;
 	res->fills = fills_;
 	res->aligned = nullptr;
+	res->progress = nullptr;
 	if (empty_task_) return CSADP_OK;
 	if (step_ < nseq_ || pending_) return CSADP_ERR_STATE;
 	char **out = (char **)calloc((size_t)nseq_, sizeof(char *));
 	if (!out) return CSADP_ERR_NOMEM;
+	res->progress = strdup(tokens_.c_str());
+	if (!res->progress) { free(out); return CSADP_ERR_NOMEM; }
 	for (int s = 0; s < nseq_; ++s) {
 		out[s] = (char *)malloc(str_[s].size() + 1);
 		if (!out[s]) {

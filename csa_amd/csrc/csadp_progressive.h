@@ -98,6 +98,7 @@ private:
 	int last_score_ = 0;
 	long long cells_ = 0;
 	int fills_ = 0;
+	std::string tokens_;                         /* '.' per fill (:1156), '!' per all-gap column met (:689) */
 };
 
 }  // namespace csadp

@@ -1,11 +1,18 @@
 """One-process-per-GPU plumbing for bench.py and the multi-rank tests.
 
-The DP hot path shards by independent tasks: every rank aligns its own
-slice of the batch and there is NO data-path collective.  torch.distributed (backend
-"nccl" = RCCL on ROCm, "gloo" in the CPU tests) is used only for the barriers around the
-timed region and for the max/sum reductions of the timing scalars."""
+The DP hot path shards by independent tasks: no collective inside a matrix.  The
+work split is: rank 0 owns the task list, partitions it by longest-processing-time-first over
+the task costs (csadp_partition_lpt) and BROADCASTS the assignment; every rank aligns its part;
+fixed 16-byte result records (task id, DP score, consensus, FNV-1a of the two rows) are
+ALL-GATHERED, so every rank -- rank 0 in particular -- holds the whole batch's outcome.
+torch.distributed: backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests.  Also the
+barriers around the timed region and the max/sum reductions of the timing scalars."""
 import os
+import subprocess
+import sys
 import time
+
+RECORD_INTS = 4          # one result record = 4 x int32 = 16 bytes: task id, score, consensus, fnv1a
 
 
 def env_world():
@@ -66,6 +73,97 @@ class Group:
     def close(self):
         if self._dist is not None and self._dist.is_initialized():
             self._dist.destroy_process_group()
+
+    def _dev(self):
+        return self.device if self.backend == "nccl" else "cpu"
+
+    def broadcast_ints(self, values, count):
+        """Rank 0's list of `count` ints on every rank (one broadcast)."""
+        if self._dist is None:
+            return list(values)
+        import torch
+        t = torch.tensor(list(values) if self.rank == 0 else [0] * count, dtype=torch.int32, device=self._dev())
+        self._dist.broadcast(t, src=0)
+        return t.cpu().tolist()
+
+    def all_gather_records(self, records):
+        """records: this rank's list of RECORD_INTS-tuples (ints that fit 32 bits).  Returns the
+        records of ALL ranks, rank order (one max-reduce for the padding, one all-gather)."""
+        if self._dist is None:
+            return [tuple(r) for r in records]
+        import torch
+        most = int(self.max(len(records)))
+        pad = torch.full((most + 1, RECORD_INTS), -1, dtype=torch.int32)
+        pad[0, 0] = len(records)
+        if records:
+            pad[1:len(records) + 1] = torch.tensor([[_i32(v) for v in r] for r in records], dtype=torch.int32)
+        pad = pad.to(self._dev())
+        out = [torch.empty_like(pad) for _ in range(self.world)]
+        self._dist.all_gather(out, pad)
+        res = []
+        for t in out:
+            t = t.cpu()
+            n = int(t[0, 0])
+            res.extend(tuple(int(v) for v in row) for row in t[1:n + 1].tolist())
+        return res
+
+
+def _i32(v):
+    v &= 0xFFFFFFFF
+    return v - (1 << 32) if v >= (1 << 31) else v
+
+
+def u32(v):
+    return v & 0xFFFFFFFF
+
+
+def lpt_assignment(group, costs):
+    """Rank 0 partitions `costs` (known to rank 0 at least) over group.world parts with the library's
+    LPT partitioner and broadcasts part-of-task; every rank returns the same list."""
+    n = len(costs)
+    part = None
+    if group.rank == 0:
+        import csa_amd
+        part, _ = csa_amd.partition_lpt([int(c) for c in costs], group.world)
+    return group.broadcast_ints(part, n)
+
+
+def run_sharded(group, costs, align_mine):
+    """The multi-GPU flow of one batch: LPT -> per-rank task lists -> align -> gather.
+    align_mine(ids) aligns the global task ids this rank owns and returns one
+    (score, consensus, fnv1a) per id.  Returns (records by task id, this rank's ids, imbalance)."""
+    part = lpt_assignment(group, costs)
+    mine = [t for t, p in enumerate(part) if p == group.rank]
+    got = align_mine(mine)
+    recs = group.all_gather_records([(t, sc, cons, dig) for t, (sc, cons, dig) in zip(mine, got)])
+    by_id = {r[0]: (r[1], r[2], u32(r[3])) for r in recs}
+    load = [0] * group.world
+    for t, p in enumerate(part):
+        load[p] += int(costs[t])
+    total = sum(load)
+    imbalance = max(load) * group.world / total if total else 1.0
+    return by_id, mine, imbalance
+
+
+def spawn_ranks(script, argv, world):
+    """`python bench.py --gpus N` invoked plainly: start one fresh child per GPU (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in its environment) BEFORE this process has touched a GPU, pass rank 0's
+    stdout through, return the worst exit code.  Never re-execs a process that holds a device."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def timed_steps(group, step_fn, sync_fn, steps, warmup):

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CSADP_VERSION 100
+#define CSADP_VERSION 200
 
 /* only the C-ABI below is exported from libcsadp.so */
 #define CSADP_API __attribute__((visibility("default")))
@@ -34,21 +34,29 @@ extern "C" {
 #define CSADP_ERR_STATE      -7   /* call sequence error (e.g. fetch before run)           */
 
 #define CSADP_MAX_SEQS 64         /* MAXNUMBEROFSEQS, csamsa.c:23 */
+#define CSADP_MAX_DEVICES 16      /* GPUs one host process may drive (csadp_align_batch_multi) */
 
 /* ---- library lifetime ------------------------------------------------------------ */
 
 typedef struct csadp_config {
-	int device;        /* HIP device ordinal; -1 = take LOCAL_RANK / 0                     */
+	int device;        /* HIP device ordinal of the PRIMARY device; -1 = take LOCAL_RANK / 0.  An   */
+	                   /* ordinal that does not exist is CSADP_ERR_NO_DEVICE (CSADP_SHARE_DEVICE=1 */
+	                   /* maps it onto the visible devices instead: multi-rank rehearsals only)    */
 	int tile_rows;     /* DP steps per tile launch (0 = default)                           */
 	int verbose;       /* 1 = print the reference's progress tokens in the drop-in adapter */
 } csadp_config;
 
-CSADP_API int csadp_init(const csadp_config *cfg);      /* idempotent; NULL = defaults */
+/* Selects the primary device (the one the entry points without a device argument use) and brings
+ * it up; idempotent, NULL = defaults.  Every entry point makes its device current on the calling
+ * thread (hipSetDevice is a per-thread setting), so calls may come from any host thread. */
+CSADP_API int csadp_init(const csadp_config *cfg);
 CSADP_API void csadp_shutdown(void);
 CSADP_API int csadp_version(void);
 CSADP_API const char *csadp_strerror(int code);
-/* name of the device in use, number of compute units; CSADP_ERR_NO_DEVICE before init */
+/* name of the primary device, number of compute units; CSADP_ERR_NO_DEVICE before init */
 CSADP_API int csadp_device_info(char *name, int namelen, int *compute_units);
+/* HIP devices visible to this process */
+CSADP_API int csadp_device_count(int *count);
 
 /* ---- one alignment task = one ProgressiveDP call ---------------------------------- */
 
@@ -95,12 +103,41 @@ typedef struct csadp_result {
 	int fills;
 	long long cells;
 	char **aligned;
+	char *progress;    /* the reference's stdout tokens between "[(min-max)" and "->": one '.' per fill  */
+	                   /* (:1156), each followed by one '!' per all-gap column DeleteGappedColumns met   */
+	                   /* (:689); malloc'd, NUL-terminated, released by csadp_free_result / free()       */
 } csadp_result;
 
 /* Align ntasks independent tasks (any nseq each) on the device: upload, fill, traceback,
  * progressive profile update.  results[t].status carries per-task errors. */
 CSADP_API int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results);
 CSADP_API void csadp_free_result(csadp_result *r, int nseq);
+
+/* ---- more than one GPU (independent tasks, no collective inside a matrix) -------- */
+
+/* The same on an explicitly named HIP device (brought up on first use).  Calls naming different
+ * devices may run concurrently from different host threads. */
+CSADP_API int csadp_align_batch_on(int device, const csadp_task *tasks, int ntasks, csadp_result *results);
+
+/* Work estimate of a task in DP cells (sum over its fills of rows x columns, the consensus taken
+ * as the longest region so far; exact for nseq = 2): the cost csadp_align_batch_multi balances. */
+CSADP_API long long csadp_task_cost(const csadp_task *task);
+
+typedef struct csadp_multi_stats {
+	int ndevices;
+	int tasks[CSADP_MAX_DEVICES];        /* tasks given to each device                      */
+	long long cost[CSADP_MAX_DEVICES];   /* their summed csadp_task_cost                    */
+	double ms[CSADP_MAX_DEVICES];        /* wall time of each device's host thread          */
+	long long total_cost, max_cost;      /* imbalance = max_cost * ndevices / total_cost    */
+	double wall_ms;
+} csadp_multi_stats;
+
+/* One batch over ndevices GPUs of this node from ONE host process: tasks are partitioned by
+ * longest-processing-time-first over their csadp_task_cost (csadp_partition_lpt), one host thread
+ * per GPU aligns its part (csadp_align_batch_on), results land in results[] in task order -- the
+ * gather is host memory.  devices = NULL means ordinals 0..ndevices-1.  stats may be NULL. */
+CSADP_API int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp_result *results,
+                                      const int *devices, int ndevices, csadp_multi_stats *stats);
 
 /* ---- device-resident pair batches (the benchmarked path) --------------------------- */
 
@@ -115,6 +152,7 @@ CSADP_API void csadp_free_result(csadp_result *r, int nseq);
 typedef struct csadp_pairbatch csadp_pairbatch;
 
 CSADP_API int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
+CSADP_API int csadp_pairs_create_on(int device, const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
 CSADP_API int csadp_pairs_run(csadp_pairbatch *b);
 CSADP_API int csadp_pairs_sync(csadp_pairbatch *b);
 CSADP_API int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results);
@@ -239,6 +277,10 @@ CSADP_API int csadp_write_aligned_fasta(const char *path, const char *const *des
 /* Longest-processing-time partition of n task costs over nparts devices.
  * assign[i] receives the part of task i; returns the maximum part load via *maxload. */
 CSADP_API int csadp_partition_lpt(const long long *cost, int n, int nparts, int *assign, long long *maxload);
+
+/* FNV-1a-32 over strings[0..n): the digest used for golden values and for the
+ * fixed-size result records that ranks exchange */
+CSADP_API unsigned csadp_fnv1a(const char *const *strings, int n);
 
 /* FASTA loader following the reference's rules (csamsa.c:433-519): skips \n \r NUL '-'
  * and space, uppercases, admits IUPAC letters, drops a record holding any other byte,

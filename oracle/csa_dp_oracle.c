@@ -603,6 +603,108 @@ fail:
 	return rc;
 }
 
+/* ---- linear-space score of the pairwise case ------------------------------------------------ */
+
+/*
+ * One row of :990-1029 for i = 1 without the direction matrix.  With a = max(diag, up) the
+ * left move only ever subtracts 1 per column, so new[k] = max over t <= k of (a[t] - (k - t)):
+ * a running maximum of a[t] + t.  The first loop has no loop-carried dependency (the compiler
+ * vectorises it), the second is one max per cell.
+ */
+#define PAIR_ROW_BODY                                                                       \
+	int k, run;                                                                             \
+	for (k = 1; k <= ncols; k++) {                                                          \
+		const int sc = (colcodes[k - 1] == rc) ? S_MATCH : S_MISMATCH;                      \
+		const int diag = prev[k - 1] + sc, up = prev[k] + S_INDEL;                          \
+		tmp[k] = (diag > up ? diag : up) + k;                                               \
+	}                                                                                       \
+	run = cur0;                         /* a[0] + 0 = H[j][0] */                            \
+	cur[0] = cur0;                                                                          \
+	for (k = 1; k <= ncols; k++) {                                                          \
+		run = tmp[k] > run ? tmp[k] : run;                                                  \
+		cur[k] = run - k;                                                                   \
+	}
+
+static void pair_row_plain(int ncols, const signed char *colcodes, int rc, const int *prev, int *cur, int *tmp, int cur0)
+{
+	PAIR_ROW_BODY
+}
+
+__attribute__((target("avx2"), optimize("O3"))) static void pair_row_avx2(int ncols, const signed char *colcodes, int rc,
+                                                                           const int *prev, int *cur, int *tmp, int cur0)
+{
+	PAIR_ROW_BODY
+}
+
+int odp_pair_score_linear(const char *const *texts, const int *textsizes, const int *rotations,
+                          const int *starts, const int *ends, long long *score)
+{
+	ctx_t c;
+	int s, j, k, col, row, nrows, ncols, rc = ODP_OK;
+	int *a = NULL, *b = NULL, *tmp = NULL;
+	signed char *colcodes = NULL;
+	const int fast = __builtin_cpu_supports("avx2");
+	if (!texts || !textsizes || !rotations || !starts || !ends || !score) return ODP_ERR_ARG;
+	memset(&c, 0, sizeof(c));
+	c.nseq = 2;
+	c.texts = texts; c.textsizes = textsizes; c.rotations = rotations; c.starts = starts; c.ends = ends;
+	for (s = 0; s < 2; s++)
+		if (!texts[s] || starts[s] < 0 || ends[s] < starts[s] || ends[s] > textsizes[s]) return ODP_ERR_ARG;
+	/* the shorter region seeds the profile = the columns (:290-307, first strict minimum) */
+	col = (ends[1] - starts[1] < ends[0] - starts[0]) ? 1 : 0;
+	row = 1 - col;
+	ncols = ends[col] - starts[col];
+	nrows = ends[row] - starts[row];
+	a = (int *)malloc(((size_t)ncols + 1) * sizeof(int));
+	b = (int *)malloc(((size_t)ncols + 1) * sizeof(int));
+	tmp = (int *)malloc(((size_t)ncols + 1) * sizeof(int));
+	colcodes = (signed char *)malloc((size_t)ncols + 1);
+	if (!a || !b || !tmp || !colcodes) { rc = ODP_ERR_NOMEM; goto done; }
+	for (k = 0; k < ncols; k++) {
+		colcodes[k] = (signed char)char_code(char_at(&c, starts[col] + k, col));
+		if (colcodes[k] < 0 || colcodes[k] > 3) { rc = ODP_ERR_ALPHABET; goto done; }
+	}
+	for (k = 0; k <= ncols; k++) a[k] = k * S_INDEL;                        /* :969-973, i = 1, no gaps in the seed */
+	for (j = 1; j <= nrows; j++) {
+		const int code = char_code(char_at(&c, starts[row] + j - 1, row));
+		int *t;
+		if (code < 0 || code > 3) { rc = ODP_ERR_ALPHABET; goto done; }
+		if (fast) pair_row_avx2(ncols, colcodes, code, a, b, tmp, j * S_INDEL);   /* H[j][0], :967 */
+		else pair_row_plain(ncols, colcodes, code, a, b, tmp, j * S_INDEL);
+		t = a; a = b; b = t;
+	}
+	*score = a[ncols];
+done:
+	free(a); free(b); free(tmp); free(colcodes);
+	return rc;
+}
+
+/* tools.c:259-281: per column gaps, conservation (all characters equal, gaps included) and the pair loop */
+int odp_sp_stats(int nseq, const char *const *aligned, int *consensus, long long *gaps, int *conserved, long long *sp)
+{
+	size_t n, len;
+	int i, j;
+	if (nseq < 2 || !aligned || !aligned[0]) return ODP_ERR_ARG;
+	len = strlen(aligned[0]);
+	for (i = 1; i < nseq; i++)
+		if (!aligned[i] || strlen(aligned[i]) != len) return ODP_ERR_ARG;             /* :248-254 */
+	*consensus = (int)len; *gaps = 0; *conserved = 0; *sp = 0;
+	for (n = 0; n < len; n++) {
+		for (i = 0; i < nseq; i++)
+			if (aligned[i][n] == '-') (*gaps)++;                                       /* :266 */
+		for (i = 1; i < nseq; i++)
+			if (aligned[i][n] != aligned[0][n]) break;
+		if (i == nseq) (*conserved)++;                                                 /* :268-272 */
+		for (i = 0; i <= nseq - 2; i++)
+			for (j = i + 1; j <= nseq - 1; j++) {
+				char x = aligned[i][n], y = aligned[j][n];
+				if (x == '-' && y == '-') continue;
+				if (x == y) (*sp)++; else (*sp)--;
+			}
+	}
+	return ODP_OK;
+}
+
 /* tools.c:274-280: gap/gap scores nothing, equal +1, anything else -1 */
 long long odp_sp_score(int nseq, const char *const *aligned)
 {

@@ -60,6 +60,22 @@ int odp_progressive_dp(int nseq, const char *const *texts, const int *textsizes,
 int odp_fill(int nrows, int ncols, const signed char *rowcodes, const int *sv, int nprev,
              const int *top, int left_i, int *H, char *dirs);
 
+/*
+ * Linear-space score of a 2-sequence task: dpmatrix[nrows][ncols] of the single fill
+ * ProgressiveDP runs for numberofseqs == 2 (:990-1029 with i = 1 on the fresh borders of
+ * :963-973), computed with two rows and no direction matrix, so that pairs far beyond what
+ * the reference's 5 B/cell matrices allow (200 kbp x 200 kbp) can still be checked for
+ * OPTIMALITY: an aligned pair is optimal iff its SP score (tools.c:274-280) equals this.
+ * Regions in rotated coordinates as in odp_progressive_dp.  Returns ODP_OK / ODP_ERR_*.
+ */
+int odp_pair_score_linear(const char *const *texts, const int *textsizes, const int *rotations,
+                          const int *starts, const int *ends, long long *score);
+
+/* The four statistics of tools.c:194-293 (CalculateSumOfPairsScore, the reference's mode S):
+ * consensus size, total '-' count (the tool prints total / nseq), conserved columns, SP score. */
+int odp_sp_stats(int nseq, const char *const *aligned, int *consensus, long long *gaps, int *conserved,
+                 long long *sp);
+
 /* Sum-of-pairs score of aligned strings (rule of tools.c:274-280). */
 long long odp_sp_score(int nseq, const char *const *aligned);
 

@@ -11,7 +11,12 @@ Outputs (all data, no reference source text):
   real_pairs.json      whole-sequence pairs of Primates/Mammals: length, SP score,
                        FNV-1a digest (the values quoted in SURVEY.md 8c included)
   pipeline.json        (--pipeline) md5 of <set>-Aligned.fasta / -Rotated.fasta written by the
-                       unmodified reference program in mode N (oracle/_ref/CSA_ref)
+                       unmodified reference program in mode N (oracle/_ref/CSA_ref), the rotations of its
+                       -Rotated.fasta headers, and the four statistics its mode S (tools.c:194-293,
+                       CalculateSumOfPairsScore) prints for that -Aligned.fasta.  Sets: Primates, Mammals
+                       and Set3 (website/Examples.zip; the one input with LARGE profile fills)
+  sp_stats.json        (--sp) mode S of the reference program on small alignments (the rows of
+                       anchors.json's families + adversarial column patterns): rows and the four numbers
 
   config4_pairs.json   (--config4) the first 32 pairs of the benchmark workload (SURVEY 8d config 4,
                        csa_amd/synth.py) through the compiled reference: length, SP score, FNV-1a
@@ -36,6 +41,7 @@ REF_MANUAL = "/root/reference/Manual"
 ROT = {
     "Primates": [1947, 1949, 1950, 2530, 1952, 1946, 1951, 1952, 1975, 1955, 1954, 2475, 1948, 1947, 1940, 1948],
     "Mammals": [1283, 1304, 1263, 1640, 1277, 1722, 1295, 1272, 1851, 1273, 1266, 1273],
+    "Set3": [2405, 2407, 2408, 2988, 2412, 2404, 2409, 2405, 2451, 2412, 2420, 2936, 2408, 2402, 2400, 2406, 2392, 3709, 5471],
 }
 
 
@@ -135,28 +141,73 @@ def config4_pairs(n=32):
     return out
 
 
+REF_BIN = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "CSA_ref")
+
+
+def ref_mode_s(path):
+    """The four numbers the reference program prints in mode S (csamsa.c:639-641 -> tools.c:194-293)."""
+    import re
+    import subprocess
+    with open(os.devnull) as devnull:
+        log = subprocess.run([REF_BIN, "S", os.path.basename(path)], cwd=os.path.dirname(path), stdin=devnull,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode(errors="replace")
+    m = re.search(r"Consensus size = (-?\d+)\s+Average gaps per sequence = (-?\d+)\s+"
+                  r"Number of conserved columns = (-?\d+)\s+Sum-of-Pairs score = (-?\d+)", log)
+    assert m, log
+    return {"consensus": int(m.group(1)), "avg_gaps": int(m.group(2)), "conserved": int(m.group(3)), "sp": int(m.group(4))}
+
+
 def pipeline():
     """Whole-program goldens: run the UNMODIFIED reference binary (oracle/_ref/CSA_ref, built by
-    `make -C oracle _dropin`) in mode N on the example sets and record the md5 of its outputs."""
+    `make -C oracle _dropin`) in mode N on the example sets, record the md5 of its outputs, the
+    rotations it chose and what its own mode S says about the alignment it wrote."""
     import hashlib
+    import re
     import shutil
     import subprocess
     import tempfile
-    ref = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "CSA_ref")
     out = {}
-    for name in ("Primates", "Mammals"):
+    for name in ("Primates", "Mammals", "Set3"):
         with tempfile.TemporaryDirectory() as tmp:
             shutil.copy(os.path.join(HERE, "data", name + ".txt"), tmp)
             with open(os.devnull) as devnull:
-                log = subprocess.run([ref, name + ".txt"], cwd=tmp, stdin=devnull, stdout=subprocess.PIPE,
+                log = subprocess.run([REF_BIN, name + ".txt"], cwd=tmp, stdin=devnull, stdout=subprocess.PIPE,
                                      stderr=subprocess.STDOUT).stdout.decode(errors="replace")
             rec = {}
             for kind in ("Aligned", "Rotated"):
                 with open(os.path.join(tmp, "%s-%s.fasta" % (name, kind)), "rb") as f:
                     rec[kind.lower() + "_md5"] = hashlib.md5(f.read()).hexdigest()
+            with open(os.path.join(tmp, name + "-Rotated.fasta"), "rb") as f:
+                rec["rotations"] = [int(ln.rsplit(b"@", 1)[1]) for ln in f if ln.startswith(b">")]
             rec["dp_calls"] = log.count("[(")
+            # the stdout tokens of every ProgressiveDP call (dynamicprogramming.c:917, :1156, :689, :1159)
+            rec["dp_log"] = re.findall(r"\[\([^\]]*\]", log)
+            rec["mode_s"] = ref_mode_s(os.path.join(tmp, name + "-Aligned.fasta"))
             out[name] = rec
             print(name, rec, flush=True)
+    return out
+
+
+def sp_stats():
+    """Mode S of the reference program on small alignments: rows + the four numbers."""
+    import tempfile
+    with open(os.path.join(HERE, "anchors.json")) as f:
+        fams = json.load(f)["families"]
+    cases = [f["rows"] for f in fams if len(f["rows"]) >= 2 and len(f["rows"][0]) > 0]
+    r = rng(4242)
+    for _ in range(40):                     # adversarial columns: all-gap, all-equal, one odd letter, IUPAC letters
+        n = r.choice([2, 3, 5, 9, 17, 33, 64])
+        length = r.choice([1, 2, 7, 64, 65, 257, 1000])
+        alphabet = r.choice(["ACGT-", "A-", "ACGTN-", "AC"])
+        cases.append(["".join(r.choice(alphabet) for _ in range(length)) for _ in range(n)])
+    out = []
+    for rows in cases:
+        with tempfile.TemporaryDirectory() as tmp:
+            path = os.path.join(tmp, "x.fasta")
+            with open(path, "w") as f:
+                for i, row in enumerate(rows):
+                    f.write(">s%d\n%s\n" % (i, row))
+            out.append({"rows": rows, "mode_s": ref_mode_s(path)})
     return out
 
 
@@ -188,21 +239,34 @@ def anchors():
             rows = [ln.rstrip(b"\n").decode() for ln in open(path, "rb") if not ln.startswith(b">")]
         out["families"].append({"seqs": [f.decode() for f in fam], "given": given is not None, "rotations": rot,
                                 "border_nodes": len(border), "segments": segs, "rows": rows})
-    for name in ("Primates", "Mammals"):
-        _, seqs = read_fasta(os.path.join(HERE, "data", name + ".txt"))
-        rc, rot, border, segs = ref_alignment_map(seqs, timeout=900)
-        assert rc == 0 and rot == ROT[name], (name, rc, rot)
-        out["sets"][name] = {"rotations": rot, "border_nodes": len(border), "segments": segs}
+    out["sets"] = anchor_sets()
     return out
 
 
+def anchor_sets():
+    """Alignment maps of the example sets (Set3: only two gaps survive the anchoring, 36 fills)."""
+    sets = {}
+    for name in ("Primates", "Mammals", "Set3"):
+        _, seqs = read_fasta(os.path.join(HERE, "data", name + ".txt"))
+        rc, rot, border, segs = ref_alignment_map(seqs, timeout=900)
+        assert rc == 0 and rot == ROT[name], (name, rc, rot)
+        sets[name] = {"rotations": rot, "border_nodes": len(border), "segments": segs}
+    return sets
+
+
 def copy_data():
+    import zipfile
     os.makedirs(os.path.join(HERE, "data"), exist_ok=True)
     for name in ("Primates", "Mammals"):
         with open(os.path.join(REF_MANUAL, name + ".txt"), "rb") as f:
             raw = f.read().replace(b"\r\n", b"\n")
         with open(os.path.join(HERE, "data", name + ".txt"), "wb") as f:
             f.write(raw)
+    # Set3 (19 sequences) ships only inside the web front end's example archive
+    with zipfile.ZipFile("/root/reference/website/Examples.zip") as z:
+        raw = z.read("Set3.txt").replace(b"\r\n", b"\n")
+    with open(os.path.join(HERE, "data", "Set3.txt"), "wb") as f:
+        f.write(raw)
 
 
 def main():
@@ -212,9 +276,20 @@ def main():
         with open(os.path.join(HERE, "pipeline.json"), "w") as f:
             json.dump(pipeline(), f, indent=1)
         return
+    if "--sp" in sys.argv:
+        with open(os.path.join(HERE, "sp_stats.json"), "w") as f:
+            json.dump(sp_stats(), f, indent=0)
+        return
     if "--config4" in sys.argv:
         with open(os.path.join(HERE, "config4_pairs.json"), "w") as f:
             json.dump(config4_pairs(), f, indent=1)
+        return
+    if "--anchor-sets" in sys.argv:          # keep the families, regenerate the example sets only
+        with open(os.path.join(HERE, "anchors.json")) as f:
+            cur = json.load(f)
+        cur["sets"] = anchor_sets()
+        with open(os.path.join(HERE, "anchors.json"), "w") as f:
+            json.dump(cur, f, indent=0)
         return
     if "--anchors" in sys.argv:
         with open(os.path.join(HERE, "anchors.json"), "w") as f:

@@ -112,6 +112,34 @@ def ref_progressive(texts, rots=None, starts=None, ends=None):
     return rc, strs, sec.value
 
 
+def oracle_pair_score_linear(texts, rots=None, starts=None, ends=None):
+    """dpmatrix[nrows][ncols] of a 2-sequence task from the oracle's two-row (linear-space) fill:
+    the optimality check for pairs too long for the reference's 5 B/cell matrices."""
+    lib = oracle_lib()
+    rots = rots or [0, 0]
+    starts = starts or [0, 0]
+    ends = ends or [len(t) for t in texts]
+    n, txt, sz, rt, st, en = _task_args(texts, rots, starts, ends)
+    assert n == 2
+    score = ctypes.c_longlong()
+    rc = lib.odp_pair_score_linear(txt, sz, rt, st, en, ctypes.byref(score))
+    assert rc == 0, rc
+    return score.value
+
+
+def oracle_sp_stats(strs):
+    """The reference's mode-S statistics (tools.c:194-293) from the oracle's restatement, shaped
+    like tests/golden/*'s "mode_s" records."""
+    lib = oracle_lib()
+    n = len(strs)
+    arr = (ctypes.c_char_p * n)(*[s if isinstance(s, bytes) else s.encode() for s in strs])
+    cons, conserved = ctypes.c_int(), ctypes.c_int()
+    gaps, sp = ctypes.c_longlong(), ctypes.c_longlong()
+    rc = lib.odp_sp_stats(n, arr, ctypes.byref(cons), ctypes.byref(gaps), ctypes.byref(conserved), ctypes.byref(sp))
+    assert rc == 0, rc
+    return {"consensus": cons.value, "avg_gaps": gaps.value // n, "conserved": conserved.value, "sp": sp.value}
+
+
 def sp_score(strs):
     """Sum-of-pairs score, rule of tools.c:274-280 (numpy restatement)."""
     arrs = [np.frombuffer(s, dtype=np.uint8) for s in strs]

@@ -76,7 +76,7 @@ def test_product_matches_golden_maps():
         assert segs == as_tuples(case["segments"])
 
 
-@pytest.mark.parametrize("name", ["Primates", "Mammals"])
+@pytest.mark.parametrize("name", ["Primates", "Mammals", "Set3"])
 def test_product_matches_golden_example_sets(name):
     want = golden()["sets"][name]
     _, seqs = H.read_fasta(os.path.join(H.ROOT, "tests", "golden", "data", name + ".txt"))

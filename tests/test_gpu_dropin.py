@@ -20,7 +20,7 @@ BIN = os.path.join(ROOT, "oracle", "_ref", "CSA_csadp")
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="oracle/_ref/CSA_csadp not built (needs /root/reference at build time)")
-@pytest.mark.parametrize("name", ["Primates", "Mammals"])
+@pytest.mark.parametrize("name", ["Primates", "Mammals", "Set3"])
 def test_reference_program_with_csadp_dropin(name, tmp_path):
     with open(os.path.join(GOLDEN, "pipeline.json")) as f:
         gold = json.load(f)[name]

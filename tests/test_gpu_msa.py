@@ -43,10 +43,13 @@ def test_msa_rows_match_reference_fixture():
     assert gaps > 100
 
 
-@pytest.mark.parametrize("name", ["Primates", "Mammals"])
+@pytest.mark.parametrize("name", ["Primates", "Mammals", "Set3"])
 def test_csa_msa_tool_writes_the_reference_files(name, tmp_path):
     """Mode N on the reference's example sets: -Rotated.fasta and -Aligned.fasta have the md5 of the
-    files the unmodified reference program writes."""
+    files the unmodified reference program writes, and csadp_sp_score (K3) says about the written
+    alignment what the reference's own mode S says (tools.c:194-293; SURVEY 8c's numbers).
+    Set3 is the input whose anchoring mostly fails: 36 fills up to 16979 x 20852 with profiles of up
+    to 18 sequences (5.4e9 cells) -- the profile-step kernel at full size."""
     want = H.load_golden("pipeline.json")[name]
     src = str(tmp_path / (name + ".txt"))
     shutil.copy(os.path.join(H.GOLDEN, "data", name + ".txt"), src)
@@ -56,6 +59,11 @@ def test_csa_msa_tool_writes_the_reference_files(name, tmp_path):
     assert md5(str(tmp_path / (name + "-Rotated.fasta"))) == want["rotated_md5"]
     assert md5(str(tmp_path / (name + "-Aligned.fasta"))) == want["aligned_md5"]
     assert "%d gaps by DP" % want["dp_calls"] in log
+    with open(str(tmp_path / (name + "-Aligned.fasta")), "rb") as f:
+        rows = [ln.rstrip(b"\n") for ln in f if not ln.startswith(b">")]
+    st = csa_amd.sp_score(rows)
+    assert {"consensus": st["consensus"], "avg_gaps": st["total_gaps"] // len(rows), "conserved": st["conserved_columns"],
+            "sp": st["sp_score"]} == want["mode_s"]
 
 
 def test_msa_mode_a_and_writer(tmp_path):

@@ -6,7 +6,7 @@ Bar: bit-exact -- integer scores, aligned strings byte for byte."""
 import pytest
 
 import csa_amd
-from helpers import (degap, fnv1a, golden_aligned, golden_task, load_golden, oracle_progressive,
+from helpers import (degap, fnv1a, golden_aligned, golden_task, load_golden, oracle_pair_score_linear, oracle_progressive,
                      random_family, read_fasta, rng, rotated, sp_score, synth_pair, GOLDEN)
 import os
 
@@ -222,6 +222,9 @@ def test_long_pair_properties_100kbp():
     assert degap(g["aligned"][0]) == rotated(a, ra) and degap(g["aligned"][1]) == rotated(b, rb)
     assert sp_score(g["aligned"]) == g["score"] == h["score"]
     assert g["score"] > 50000
+    # optimality: a valid but sub-optimal path passes all of the above; the oracle's two-row fill
+    # (odp_pair_score_linear, pinned to the reference in tests/test_oracle.py) knows the optimum
+    assert g["score"] == oracle_pair_score_linear([a, b], [ra, rb])
 
 
 def test_config5_mixed_lengths_sample():
@@ -368,3 +371,14 @@ def test_whole_config5_in_one_batch():
             assert g["aligned"] == strs and g["score"] == st.last_score
             checked += 1
     assert checked >= 8
+    # optimality of the LONG pairs (the reference cannot hold their matrices): the three longest
+    # (up to 200 kbp, 4e10 cells each) and five more spread over 40 k .. 150 k, against the
+    # oracle's linear-space score, on host threads (ctypes releases the GIL)
+    from concurrent.futures import ThreadPoolExecutor
+    order = sorted(range(len(tasks)), key=lambda i: -len(tasks[i][0][0]))
+    mid = [i for i in order if 40000 <= len(tasks[i][0][0]) <= 150000]
+    sample = order[:3] + mid[::max(1, len(mid) // 5)][:5]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 2)) as ex:
+        want = list(ex.map(lambda i: oracle_pair_score_linear(tasks[i][0], tasks[i][1]), sample))
+    assert [got[i]["score"] for i in sample] == want
+    assert max(len(tasks[i][0][0]) for i in sample) > 190000

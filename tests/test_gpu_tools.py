@@ -65,6 +65,21 @@ def test_sp_score_kernel_matches_tools_rule():
         csa_amd.sp_score([b"ACGT", b"ACG"])
 
 
+def _mode_s(st, nseq):
+    """csadp_sp_stats in the shape of the goldens' "mode_s" records (the tool prints total gaps / nseq, tools.c:284)."""
+    return {"consensus": st["consensus"], "avg_gaps": st["total_gaps"] // nseq, "conserved": st["conserved_columns"],
+            "sp": st["sp_score"]}
+
+
+def test_sp_score_kernel_equals_reference_mode_s():
+    """f-4 pinned to the reference PROGRAM: sp_stats.json holds the four numbers `CSA S` printed for
+    100 small alignments (rows of real runs + adversarial columns: all-gap, IUPAC letters, 64 rows)."""
+    csa_amd.init(device=0)
+    for case in load_golden("sp_stats.json"):
+        rows = [r.encode() for r in case["rows"]]
+        assert _mode_s(csa_amd.sp_score(rows), len(rows)) == case["mode_s"]
+
+
 def test_score_pairs_matches_alignment_scores():
     """csadp_score_pairs == score of csadp_align_batch == SP of the strings, incl. empty regions."""
     csa_amd.init(device=0)

@@ -67,3 +67,85 @@ def test_two_rank_gloo_timing_and_sums(tmp_path):
     # the reported time is the MAX over ranks: both ranks see rank 1's >= 5 * 20 ms
     assert abs(outs[0]["elapsed"] - outs[1]["elapsed"]) < 1e-6
     assert outs[0]["elapsed"] >= 0.1
+
+
+# ---- the real multi-GPU flow on two gloo ranks: LPT -> per-rank task lists -> align -> gather ----------------
+
+FLOW = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import csa_amd
+from csa_amd import dist as cdist
+from csa_amd.synth import config5_lengths, synth_pair
+from helpers import oracle_filler
+g = cdist.Group(backend="gloo")
+# a miniature of config 5: 40 pairs whose lengths spread 1:50, costs = cells
+la, lb = config5_lengths(40, seed=11)
+la = [max(8, x // 400) for x in la]
+pairs = [synth_pair(3000 + i, length=n) for i, n in enumerate(la)]
+costs = [len(a) * len(b) for a, b, _, _ in pairs]
+fill = oracle_filler()          # the DEVICE step is stubbed by the test seam (csadp_debug.h): no GPU here
+def align_mine(ids):
+    out = []
+    for t in ids:
+        a, b, ra, rb = pairs[t]
+        r = csa_amd.debug_align_with_filler(([a, b], [ra, rb], None, None), fill)
+        assert r["status"] == 0
+        out.append((r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])))
+    return out
+by_id, mine, imbalance = cdist.run_sharded(g, costs, align_mine)
+print(json.dumps({"rank": g.rank, "world": g.world, "mine": mine, "imbalance": imbalance,
+                  "records": sorted([k] + list(v) for k, v in by_id.items())}), flush=True)
+g.close()
+''' % (ROOT, ROOT)
+
+
+def _run_flow(tmp_path, world):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / ("flow%d.py" % world)
+    script.write_text(FLOW)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        out, err = p.communicate(timeout=300)
+        assert p.returncode == 0, err.decode()
+        outs.append(json.loads(out.decode().strip().splitlines()[-1]))
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+def test_two_rank_lpt_split_and_gather_equals_single_rank(tmp_path):
+    """World 2 (gloo): rank 0 partitions by LPT and broadcasts, each rank aligns only its tasks
+    (host logic of the product, fills from the test seam), the 16-byte records are all-gathered.
+    Every rank must end up with exactly the world-1 records; the split is disjoint, complete and
+    balanced within 5 %."""
+    one = _run_flow(tmp_path, 1)[0]
+    two = _run_flow(tmp_path, 2)
+    assert len(one["records"]) == 40 and one["mine"] == list(range(40))
+    for o in two:
+        assert o["records"] == one["records"]            # gathered == single rank, on BOTH ranks
+        assert o["imbalance"] <= 1.05
+    assert sorted(two[0]["mine"] + two[1]["mine"]) == list(range(40))
+    assert two[0]["mine"] and two[1]["mine"] and not set(two[0]["mine"]) & set(two[1]["mine"])
+
+
+def test_bench_spawns_its_own_ranks_and_refuses_nothing(tmp_path):
+    """`python bench.py --gpus 2` invoked PLAINLY (the driver's form) must start the ranks itself:
+    without a GPU the children fail inside csadp_init with the library's 'no device' error --
+    not with a launcher error -- and the parent reports a non-zero exit code."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--pairs", "2", "--len", "64", "--no-cpu-baseline", "--backend", "gloo"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    err = p.stderr.decode()
+    assert "launch with torch.distributed.run" not in err
+    assert p.returncode != 0
+    assert "no usable gfx950 HIP device" in err or "no HIP device" in err, err[-2000:]

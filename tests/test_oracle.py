@@ -111,3 +111,45 @@ def test_oracle_reproduces_benchmark_pair_digests():
         cons, strs, st = oracle_progressive([a, b], [ra, rb])
         assert (cons, sp_score(strs), "%08x" % fnv1a(strs)) == (g["consensus"], g["sp"], g["fnv1a"])
         assert st.last_score == g["sp"]
+
+
+def test_linear_space_score_equals_the_full_matrix():
+    """odp_pair_score_linear (two rows, no directions) == dpmatrix[nrows][ncols] of the full
+    restatement on fuzzed pairs (sub-regions, rotations, empty sides) ..."""
+    from helpers import oracle_pair_score_linear
+    r = rng(31337)
+    for _ in range(200):
+        fam = random_family(r, 2, r.choice([1, 7, 33, 64, 200, 700]), mut=r.choice([0.0, 0.1, 0.6]), indel=r.choice([0.0, 0.1, 0.3]))
+        fam = [f if f else b"C" for f in fam]
+        rots = [r.randrange(len(f)) for f in fam]
+        starts = [r.randrange(len(f) + 1) if r.random() < 0.3 else 0 for f in fam]
+        ends = [r.randrange(a, len(f) + 1) if r.random() < 0.3 else len(f) for a, f in zip(starts, fam)]
+        rc, strs, st = oracle_progressive(fam, rots, starts, ends)
+        if strs[0] is None:
+            continue                      # both regions empty: the reference returns before any fill (:916)
+        assert oracle_pair_score_linear(fam, rots, starts, ends) == st.last_score == sp_score(strs)
+
+
+def test_linear_space_score_equals_reference_goldens():
+    """... and == the SP score of the COMPILED REFERENCE's strings on whole mitochondrial genomes
+    (real_pairs.json) and on the benchmark workload (config4_pairs.json)."""
+    from helpers import oracle_pair_score_linear, read_fasta, GOLDEN
+    from csa_amd.synth import synth_pair
+    import os
+    for g in load_golden("config4_pairs.json")[:6]:
+        a, b, ra, rb = synth_pair(g["pair"])
+        assert oracle_pair_score_linear([a, b], [ra, rb]) == g["sp"]
+    sets = {}
+    for g in load_golden("real_pairs.json")[::23]:
+        if g["set"] not in sets:
+            sets[g["set"]] = read_fasta(os.path.join(GOLDEN, "data", g["set"] + ".txt"))[1]
+        seqs = sets[g["set"]]
+        assert oracle_pair_score_linear([seqs[g["a"]], seqs[g["b"]]], g["rots"]) == g["sp"]
+
+
+def test_oracle_sp_stats_equal_reference_mode_s():
+    """odp_sp_stats restates tools.c:194-293; sp_stats.json holds what the reference PROGRAM printed
+    in mode S for the same rows (100 alignments incl. all-gap columns and IUPAC letters)."""
+    from helpers import oracle_sp_stats
+    for case in load_golden("sp_stats.json"):
+        assert oracle_sp_stats(case["rows"]) == case["mode_s"]
