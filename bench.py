@@ -148,6 +148,11 @@ def main():
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # invoked plainly: start one child per GPU before anything here has touched a device
+        from csa_amd.dist import spawn_ranks
+        raise SystemExit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
     many_cores = None
     if args.gpus == 1 and not args.no_cpu_baseline:
         from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
@@ -162,7 +167,10 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     dev = 0 if args.share_device else local_rank
-    torch.cuda.set_device(dev)
+    if args.share_device:
+        os.environ["CSADP_SHARE_DEVICE"] = "1"
+    if args.backend == "nccl":
+        torch.cuda.set_device(dev)
     csa_amd.init(device=dev)
     group = cdist.Group(backend=args.backend, device="cuda:%d" % dev)
 

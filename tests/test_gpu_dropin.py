@@ -7,6 +7,7 @@ up to 16 sequences each, stale borders, DeleteGappedColumns, empty regions."""
 import hashlib
 import json
 import os
+import re
 import shutil
 import subprocess
 
@@ -31,6 +32,9 @@ def test_reference_program_with_csadp_dropin(name, tmp_path):
     log = run.stdout.decode(errors="replace")
     assert run.returncode == 0, log[-2000:]
     assert log.count("[(") == gold["dp_calls"]
+    # the stdout tokens of every call -- "[(min-max)", one '.' per fill (:1156), '!' per all-gap column
+    # DeleteGappedColumns met (:689), "->consensus]" -- equal the unmodified program's, so logs diff cleanly
+    assert re.findall(r"\[\([^\]]*\]", log) == gold["dp_log"]
     with open(tmp_path / (name + "-Aligned.fasta"), "rb") as f:
         assert hashlib.md5(f.read()).hexdigest() == gold["aligned_md5"], log[-2000:]
     # the reference's own integrity check (tools.c:123-191) ran on our strings and said OK

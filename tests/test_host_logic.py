@@ -143,3 +143,39 @@ def test_rotated_fasta_wire_format(tmp_path):
         with open(out, "rb") as f:
             assert hashlib.md5(f.read()).hexdigest() == gold[name]["rotated_md5"]
         assert csa_amd.read_rotations(out) == rot[name]
+
+
+def test_progress_tokens_equal_the_reference_log():
+    """csadp_result.progress restates the reference's stdout tokens between "[(min-max)" and "->":
+    one '.' per fill (dynamicprogramming.c:1156) and one '!' per all-gap column DeleteGappedColumns
+    meets (:689).  pipeline.json holds the unmodified program's log lines; the Mammals gaps (42 calls,
+    two '!') run here through the product's host logic, fills from the oracle (test seam)."""
+    import re
+    import csa_amd as C
+    from helpers import GOLDEN, read_fasta
+    gold = load_golden("pipeline.json")["Mammals"]
+    _, seqs = read_fasta(os.path.join(GOLDEN, "data", "Mammals.txt"))
+    rc, segs, _ = C.build_anchor_map(seqs, gold["rotations"])
+    assert rc == 0
+    fill = oracle_filler()
+    n = len(seqs)
+    lines = []
+    for k in range(len(segs) - 1):
+        size, dp, pos = segs[k]
+        if not dp:
+            continue
+        starts = [p + size for p in pos]
+        ends = list(segs[k + 1][2])
+        if max(e - s for s, e in zip(starts, ends)) > 1600:
+            lines.append(None)                    # the large gaps take the Python walk too long; tokens are per gap
+            continue
+        got = C.debug_align_with_filler((seqs, gold["rotations"], starts, ends), fill)
+        assert got["status"] == 0
+        gaps = [e - s for s, e in zip(starts, ends)]
+        lines.append("[(%-4d-%4d)%s->%4d]" % (min(gaps), max(gaps), got["progress"], got["consensus"]))
+    assert len(lines) == len(gold["dp_log"]) == gold["dp_calls"]
+    checked = [(a, b) for a, b in zip(lines, gold["dp_log"]) if a is not None]
+    assert len(checked) >= 30
+    for a, b in checked:
+        assert a == b
+    assert sum(a.count("!") for a, _ in checked) >= 1

@@ -11,7 +11,7 @@ import csa_amd  # noqa: E402
 import helpers as H  # noqa: E402
 
 csa_amd.init(device=0)
-for name in ("Primates", "Mammals"):
+for name in (sys.argv[1:] or ["Primates", "Mammals", "Set3"]):
     _, seqs = H.read_fasta(os.path.join(H.GOLDEN, "data", name + ".txt"))
     for k in range(3):
         t0 = time.perf_counter()
