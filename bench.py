@@ -1,16 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the DP hot path on MI355X.
 
-Metric (BASELINE.json): DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, 1/2/4/8-GPU batch
-scaling.  Workload at every N: each GPU aligns its share of config 4 (1024 synthetic
-circular 16 kbp pairs sharded over 8 GPUs = 128 pairs per GPU, weak scaling); a "step" is
-one pass of the hot path -- matrix fill + direction traceback -- over that batch, inputs
-(packed sequences / profile tables) already resident in HBM.  One process per GPU
-(torch.distributed.run), no data-path collective; barriers and max-over-ranks timing only.
+Metric (BASELINE.json): DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, 1/2/4/8-GPU batch scaling.
+
+Default workload (every N): each GPU aligns its share of config 4 -- 1024 synthetic circular 16 kbp
+pairs over 8 GPUs = 128 pairs per GPU, weak scaling.  A STEP is one pass of the hot path over that
+batch starting from the raw circular letters resident in HBM and ending with the two aligned rows
+of every pair in HBM: nw_pack_planes (CharAt + letter codes) -> nw_fill_bits (the matrix fill) ->
+nw_traceback_replay (the direction walk) -> nw_expand_rows (traceback application + DP score).
+One process per GPU; `python bench.py --gpus N` starts its own ranks when it was not launched by
+torch.distributed.run.  No collective inside the timed region (independent tasks); afterwards the
+16-byte result records of every rank are all-gathered over RCCL and rank 0 checks them.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--len L]
+                    [--mode weak|strong] [--workload config4|config5]
 
-Prints ONE JSON line (rank 0).
+--mode strong: rank 0 owns the whole task list (config 4: 1024 pairs, config 5: 256 mixed-length
+pairs), partitions it by LPT (csadp_partition_lpt), broadcasts the assignment; every rank aligns
+its part; records are gathered and checked.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes
@@ -24,44 +31,26 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-ALG_BYTES_PER_CELL = 0.25             # 2-bit direction per cell, the figure for roofline.achieved
-# The benchmarked path is the bit-parallel pair kernel nw_fill_bits (csadp_bits.hip): a lane
-# advances one row of 32 columns per step on three bit planes.  Default = checkpoint mode
-# (CSADP_BITS_CKPT=1): the fill writes lane-state checkpoints (0.017 B/cell) instead of the
-# direction planes and the traceback (nw_traceback_replay) re-derives the directions of the blocks
-# on the path, so the implementation moves ~7 % of the algorithmic 0.25 B/cell and
-# roofline.achieved (algorithmic bytes / time, as SURVEY 8(d) defines it) can exceed what the HBM
-# could stream.  CSADP_BITS_CKPT=0 writes the direction planes (the kernel is then bound by HBM
-# writes: 5.2 of the 5.9 TB/s a plain store kernel reaches on this chip, tools/hbm_write_probe.hip).
-# Second roofline, VALU issue: ISA count of the compiled steady-state step = 20 v_bitop3 (2.6 issue
-# cycles per wave64 and SIMD when measured alone), 10 DPP / three-operand instructions (4.3) and 2
-# two-operand ones (2.1) per 32 cells -- tools/valu_microbench.hip, profiles/r01_valu_microbench.txt.
-# CSADP_BITS=0 falls back to the packed-16 kernel (nw_fill_tiles_pk, 4 VALU per cell) and
-# CSADP_BITS=0 CSADP_PK16=0 to the 32-bit kernel (6 per cell).
-BITS = os.environ.get("CSADP_BITS", "1") != "0"
-CKPT = os.environ.get("CSADP_BITS_CKPT", "1") != "0"
-PK16 = os.environ.get("CSADP_PK16", "1") != "0"
-if BITS:
-    mix = {"v_bitop3": (20 if CKPT else 21, 2.6), "dpp_or_three_operand": (10, 4.3), "two_operand": (2 if CKPT else 3, 2.1)}
-    VALU_OPS_PER_CELL = round(sum(n for n, _ in mix.values()) / 32, 3)
-    VALU_ISSUE_CYCLES_PER_CELL_WAVE = round(sum(n * c for n, c in mix.values()) / 32, 3)
-    FILL_KERNEL = "nw_fill_bits"
-    DTYPE = "u32 bit planes"
-else:
-    VALU_OPS_PER_CELL = 4 if PK16 else 6
-    VALU_ISSUE_CYCLES_PER_CELL_WAVE = 14 if PK16 else 18
-    FILL_KERNEL = "nw_fill_tiles_pk" if PK16 else "nw_fill_tiles"
-    DTYPE = "int16" if PK16 else "int32"
-VALU_PEAK_CUPS = 256 * 4 * 64 / VALU_ISSUE_CYCLES_PER_CELL_WAVE * 2.4e9
+# Integer VALU peak of the chip: 256 CUs x 4 SIMDs x 32 lanes per clock x 2.4 GHz = 78.6e12 lane
+# operations per second (a wave64 instruction issues in 2 cycles on a SIMD-32: MI355X_MICROARCH.md,
+# "Wave scheduling"; it is the FP32 vector peak of 157.3 TFLOP/s counted without the FMA's factor 2).
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+# VALU instructions of the compiled steady-state step of nw_fill_bits per 32 cells (one lane, one
+# row of 32 columns): ISA count of the shipped code object (tools/count_valu.py); PMC cross-check
+# SQ_INSTS_VALU / cells in profiles/.  The calibrated ceiling prices each instruction kind at the issue
+# cost measured alone on this chip (profiles/r01_valu_microbench.txt): v_bitop3 2.6, DPP /
+# three-operand 4.3, two-operand 2.1 cycles per wave64 and SIMD.
+BITS_STEP_MIX = {"v_bitop3": (20, 2.6), "dpp_or_three_operand": (10, 4.3), "two_operand": (2, 2.1)}
+BITS_VALU_PER_CELL = sum(n for n, _ in BITS_STEP_MIX.values()) / 32.0
+BITS_CYCLES_PER_64_CELLS = sum(n * c for n, c in BITS_STEP_MIX.values()) / 32.0
+ALG_BYTES_PER_CELL = 0.25             # the 2-bit direction of every cell
 
 
-def pmc_traffic_per_launch():
-    """HBM bytes per fill launch from the committed PMC passes (rocprofv3 --pmc WRITE_SIZE /
-    FETCH_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md), or None."""
+def pmc_summary(kernel):
+    """Per-launch PMC figures of `kernel` from this round's committed rocprofv3 passes, or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            k = json.load(f)[FILL_KERNEL]
-        return int(k["hbm_write_bytes_per_launch"] + k["hbm_read_bytes_per_launch_x2_corrected"])
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
+            return json.load(f)[kernel]
     except Exception:
         return None
 
@@ -97,18 +86,15 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
             mismatches += 1
         if secs > seconds_budget:
             break
-    out = {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
-           "sample": "%d of the step's 16 kbp pairs, whole ProgressiveDP (fill+traceback), %.1f s, "
-                     "GPU strings %s" % (n, secs, "identical" if mismatches == 0 else "MISMATCH x%d" % mismatches)}
-    return out
+    return {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": kind,
+            "sample": "%d of the step's 16 kbp pairs, whole ProgressiveDP (fill+traceback), %.1f s, "
+                      "GPU strings %s" % (n, secs, "identical" if mismatches == 0 else "MISMATCH x%d" % mismatches)}
 
 
 def cpu_many_cores(tasks, per_proc=2):
     """The same CPU code in P independent processes (the reference keeps global state, so no
-    threads), `per_proc` pairs each: what a host-only deployment of the reference would reach on a
-    share of this node's cores.  Reported beside the single-core figure, wall clock of the slowest
-    process.  Bounded: ~1.5 s per pair and process.  Runs BEFORE this process touches the GPU, so
-    the forked children never hold a device context."""
+    threads), `per_proc` pairs each.  Runs BEFORE this process touches the GPU, so the forked
+    children never hold a device context."""
     from helpers import have_ref, oracle_progressive, ref_progressive
     run = ref_progressive if have_ref() else (lambda t, r: oracle_progressive(t, r))
     procs = max(1, min(32, (os.cpu_count() or 2) // 2, len(tasks) // per_proc))
@@ -134,6 +120,76 @@ def cpu_many_cores(tasks, per_proc=2):
             "sample": "%d processes x %d pairs, %.1f s wall" % (procs, per_proc, wall)}
 
 
+def streaming_leg(csa_amd, tasks, batches, depth=3):
+    """What a caller of the C-ABI gets from host buffers to host strings, PCIe included: `batches`
+    pair batches, `depth` in flight (create + run + flush of batch n+depth-1 before fetch of batch n).
+    Only C-ABI calls inside the timed loop (the ctypes task arrays are built before it)."""
+    L = csa_amd.lib()
+    ta = csa_amd.TaskArray(tasks)
+    res = [(csa_amd.Result * ta.n)() for _ in range(depth)]
+    cells = sum(len(t[0][0]) * len(t[0][1]) for t in tasks)
+
+    def start():
+        h = ctypes.c_void_p()
+        rc = L.csadp_pairs_create(ta.arr, ta.n, ctypes.byref(h))
+        rc = rc or L.csadp_pairs_run(h) or L.csadp_pairs_flush(h)
+        if rc:
+            raise csa_amd.CsadpError(rc, "streaming leg")
+        return h
+
+    def finish(h, slot):
+        rc = L.csadp_pairs_fetch(h, res[slot])
+        if rc:
+            raise csa_amd.CsadpError(rc, "streaming leg fetch")
+        ok = all(res[slot][i].status == 0 for i in range(ta.n))
+        for i in range(ta.n):
+            L.csadp_free_result(ctypes.byref(res[slot][i]), 2)
+        L.csadp_pairs_destroy(h)
+        return ok
+
+    ok = True
+    wall = 0.0
+    for phase_batches in (depth + 1, batches):       # warm-up (fills the engine's buffer pools), then timed
+        inflight = []
+        t0 = time.perf_counter()
+        for n in range(phase_batches):
+            inflight.append(start())
+            if len(inflight) == depth:
+                ok = finish(inflight.pop(0), n % depth) and ok
+        while inflight:
+            ok = finish(inflight.pop(0), 0) and ok
+        wall = time.perf_counter() - t0
+    return {"gcups": round(cells * batches / wall / 1e9, 1), "ms_per_batch": round(wall * 1e3 / batches, 3),
+            "batches": batches, "in_flight": depth, "ok": ok,
+            "what": "host letters -> H2D -> pack, fill, traceback, expand -> D2H -> malloc'd result strings, "
+                    "several batches in flight through csadp_pairs_create/run/flush/fetch"}
+
+
+def profile_path_leg(csa_amd):
+    """The reference's OWN use of ProgressiveDP (mode N): sequence-vs-profile fills (i up to 18) of the
+    example sets through csadp_msa -- one device batch per set, lock-step rounds.  Best of 3 warm calls."""
+    from helpers import GOLDEN, read_fasta
+    out = {}
+    for name in ("Primates", "Mammals", "Set3"):
+        path = os.path.join(GOLDEN, "data", name + ".txt")
+        if not os.path.exists(path):
+            continue
+        _, seqs = read_fasta(path)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc, rot, rows, st = csa_amd.msa(seqs)
+            wall = time.perf_counter() - t0
+            if rc != 0:
+                best = None
+                break
+            if best is None or st["dp_ms"] < best["dp_ms"]:
+                best = {"dp_ms": round(st["dp_ms"], 2), "total_ms": round(wall * 1e3, 1), "fills": st["fills"],
+                        "gaps": st["dp_gaps"], "cells": st["cells"], "gcups": round(st["cells"] / st["dp_ms"] / 1e6, 1)}
+        out[name] = best
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,10 +197,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
     ap.add_argument("--len", type=int, default=16384, dest="length")
+    ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--workload", default="config4", choices=["config4", "config5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the streaming and profile-path legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for barriers/reductions; 'gloo' + --share-device rehearses the "
-                         "N>1 flow on a one-GPU box")
+                    help="process-group backend; 'gloo' + --share-device rehearses the N>1 flow on a one-GPU box")
     ap.add_argument("--share-device", action="store_true", help="all ranks use HIP device 0 (rehearsal only)")
     args = ap.parse_args()
 
@@ -158,118 +216,166 @@ def main():
         from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
         many_cores = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length))
 
-    import torch
     import csa_amd
     from csa_amd import dist as cdist
-    from csa_amd.synth import config4_tasks
+    from csa_amd.synth import config4_tasks, config5_lengths, synth_pair
 
     rank, local_rank, world = cdist.env_world()
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     dev = 0 if args.share_device else local_rank
     if args.share_device:
         os.environ["CSADP_SHARE_DEVICE"] = "1"
+    torch = None
     if args.backend == "nccl":
+        import torch
         torch.cuda.set_device(dev)
     csa_amd.init(device=dev)
     group = cdist.Group(backend=args.backend, device="cuda:%d" % dev)
 
-    # weak scaling: rank r owns global pairs [r*P, (r+1)*P) of the synthetic batch
-    tasks = config4_tasks(rank * args.pairs, args.pairs, args.length)
+    imbalance = 1.0
+    part = None
+    if args.mode == "weak":
+        # rank r owns global pairs [r*P, (r+1)*P) of the synthetic batch
+        ids = list(range(rank * args.pairs, (rank + 1) * args.pairs))
+        tasks = config4_tasks(rank * args.pairs, args.pairs, args.length)
+        workload = "config 4 share: %d synthetic circular %d bp pairs per GPU (global pairs rank*%d ..)" % (
+            args.pairs, args.length, args.pairs)
+    else:
+        # rank 0 owns the list; cost = DP cells from the nominal lengths; LPT + broadcast
+        if args.workload == "config4":
+            lens = [(args.length, args.length)] * 1024
+
+            def make(p):
+                return synth_pair(p, args.length)
+        else:
+            la, lb = config5_lengths(256)
+            lens = list(zip(la, lb))
+
+            def make(p):
+                return synth_pair(20000 + p, length=int(la[p]))
+        part = cdist.lpt_assignment(group, [a * b for a, b in lens])
+        ids = [t for t, p in enumerate(part) if p == rank]
+        load = [0] * world
+        for t, p in enumerate(part):
+            load[p] += lens[t][0] * lens[t][1]
+        imbalance = max(load) * world / sum(load)
+        tasks = []
+        for p in ids:
+            a, b, ra, rb = make(p)
+            tasks.append(([a, b], [ra, rb], None, None))
+        workload = "%s, all %d pairs partitioned by LPT over the ranks" % (args.workload, len(lens))
+
     t_c0 = time.perf_counter()
-    batch = csa_amd.PairBatch(tasks)            # validate, pack, upload: inputs now resident in HBM
+    batch = csa_amd.PairBatch(tasks)            # argument checks, letters -> pinned memory, H2D started
+    batch.sync()
     create_s = time.perf_counter() - t_c0
 
     def sync():
         batch.sync()
-        torch.cuda.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
 
     elapsed = cdist.timed_steps(group, batch.run, sync, args.steps, args.warmup)
     tm_pipe = batch.timing()                     # HIP events of the launch that held the LAST timed pass
-    # one launch alone (nothing else in flight): the bit-parallel path merges `launch_passes`
-    # consecutive passes into a launch, so request that many
-    for _ in range(max(tm_pipe["launch_passes"], 1)):
+    # one FULL launch alone (nothing else in flight): the bit-parallel path merges up to
+    # `passes_per_launch` consecutive passes into one launch, whatever --steps is
+    full_group = int(os.environ.get("CSADP_BITS_GROUP", "0")) or max(1, min(4, -(-2 * csa_amd.device_info()[1] // max(len(tasks), 1))))
+    for _ in range(full_group):
         batch.run()
     sync()
     tm = batch.timing()
     cells_step = group.sum(tm["cells"])
     t_f0 = time.perf_counter()
-    results = batch.fetch()                      # ops D2H + aligned strings built on the host
+    results = batch.fetch()                      # ONE D2H of the aligned rows + malloc'd result strings
     fetch_s = time.perf_counter() - t_f0
     ok = all(r["status"] == 0 for r in results)
+
+    # the multi-GPU data path: every rank's 16-byte records (task id, score, consensus, FNV-1a) all-gathered
+    recs = group.all_gather_records([(t, r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])) for t, r in zip(ids, results)])
+    by_id = {r[0]: (r[1], r[2], cdist.u32(r[3])) for r in recs}
 
     value = cells_step * args.steps / elapsed / 1e9
     line = None
     if rank == 0:
-        from helpers import degap, rotated, sp_score
+        from helpers import degap, load_golden, rotated, sp_score
         # properties on this rank's first pairs: strings re-spell the inputs, SP == DP score
         for t, r in list(zip(tasks, results))[:4]:
             ok = ok and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
             ok = ok and sp_score(r["aligned"]) == r["score"]
-        launches = max(tm["fill_launches"], 1)
-        lp = max(tm["launch_passes"], 1)                        # passes per launch (1 unless bit-parallel)
-        impl_bytes = tm["dir_bytes"] + tm["border_bytes"]      # what the kernels write per pass (directions or checkpoints, + tile borders)
-        alg_bytes = ALG_BYTES_PER_CELL * tm["cells"] + (tm["border_bytes"] if not tm["bit_parallel"] else 0)
-        # the fill kernel is in flight during the whole timed region (launches rotate over three
-        # streams, the traceback of one hides under the next fill), so its sustained rate is:
-        # work of all timed passes / wall time of the timed region
+        # gathered records: complete, and the ones the compiled reference has digests for agree with it
+        expect = args.pairs * world if args.mode == "weak" else len(part)
+        ok = ok and len(by_id) == expect
+        checked = 0
+        if args.workload == "config4" and args.length == 16384:
+            for g in load_golden("config4_pairs.json"):
+                if g["pair"] in by_id:
+                    ok = ok and by_id[g["pair"]] == (g["sp"], g["consensus"], int(g["fnv1a"], 16))
+                    checked += 1
+        lp = max(tm["launch_passes"], 1)                        # passes carried by the launch timed alone
+        impl_bytes = tm["dir_bytes"] + tm["border_bytes"]      # what the fill writes per pass (checkpoints + marks, or planes)
         rank_cells = tm["cells"]
-        eff_bytes_s = alg_bytes * args.steps / elapsed
-        eff_cups = rank_cells * args.steps / elapsed
+        launch_cells = lp * rank_cells
+        fill_s = tm["fill_ms"] * 1e-3
+        achieved_tops = BITS_VALU_PER_CELL * launch_cells / fill_s / 1e12           # lane operations per second
+        sustained_tops = BITS_VALU_PER_CELL * rank_cells * args.steps / elapsed / 1e12
+        calibrated_peak_gcups = 256 * 4 * 64 / BITS_CYCLES_PER_64_CELLS * 2.4
+        pmc = pmc_summary("nw_fill_bits")
+        traffic = None
+        if pmc and pmc.get("launch_shape") == {"jobs": lp * len(tasks), "len": args.length}:
+            traffic = int(pmc["hbm_write_bytes_per_launch"] + pmc["hbm_read_bytes_per_launch_x2_corrected"])
         line = {
-            "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, fill + traceback, whole job",
+            "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, letters in HBM -> aligned rows in HBM, whole job",
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE,
+            "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
+            "dtype": "u32 bit planes",
             "data": "synthetic", "verified": bool(ok),
             "per_gpu_gcups": round(value / args.gpus, 3),
-            "config": {"workload": "config 4 share: %d synthetic circular %d bp pairs per GPU "
-                                   "(global pairs rank*%d..), linear-gap NW fill + traceback, "
-                                   "bit-exact vs reference" % (args.pairs, args.length, args.pairs),
-                       "pairs_per_gpu": args.pairs, "seq_len": args.length,
-                       "kernel": FILL_KERNEL,
-                       "passes_per_launch": lp,
-                       "parallelism": "tasks sharded over %d GPU(s), no collective" % args.gpus},
-            "kernel_ms": {"fill_launch_pipelined": round(tm_pipe["fill_ms"], 3),
-                          "traceback_launch_pipelined": round(tm_pipe["traceback_ms"], 3),
-                          "fill_launch_alone": round(tm["fill_ms"], 3), "traceback_launch_alone": round(tm["traceback_ms"], 3),
-                          "passes_per_launch": lp,
-                          "fill_launches_per_pass": tm["fill_launches"] / lp, "fill_tiles": tm["fill_tiles"],
-                          "fill_alone_gcups": round(lp * tm["cells"] / tm["fill_ms"] / 1e6, 2)},
-            "host_boundary_ms": {"create_pack_upload": round(create_s * 1e3, 2), "fetch_download_strings": round(fetch_s * 1e3, 2),
-                                 "pcie_inclusive_gcups": round(rank_cells / (create_s + fetch_s + tm["total_ms"] / lp / 1e3) / 1e9, 1),
-                                 "note": "not part of value: one batch from host buffers to host strings, unpipelined"},
-            "roofline": {"bound": "hbm", "kernel": FILL_KERNEL,
-                         "achieved": round(eff_bytes_s / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(eff_bytes_s / 1e9 / HBM_PEAK_GBS, 6),
-                         "traffic": pmc_traffic_per_launch(),
-                         "bytes_per_launch": round(lp * alg_bytes / launches),
-                         "avg_launch_us": round(tm["fill_ms"] * 1e3 / launches, 2),
-                         "per_launch_achieved": round(lp * alg_bytes / (tm["fill_ms"] * 1e-3) / 1e9, 1),
-                         "launch_us_pipelined": round(tm_pipe["fill_ms"] * 1e3 / launches, 2),
-                         "implementation_bytes_per_launch": round(lp * impl_bytes / launches),
-                         "mode": {0: "tiled", 1: "bit-parallel, direction planes in HBM", 2: "bit-parallel, checkpoints + replay traceback"}[tm["bit_parallel"]],
-                         "note": "frac > 1 is not an accounting error: `achieved` counts the ALGORITHMIC bytes SURVEY 8(d) "
-                                 "defines (0.25 B/cell, the 2-bit direction of every cell), but the default checkpoint "
-                                 "mode does not write direction planes -- it writes `implementation_bytes_per_launch` "
-                                 "(lane-state checkpoints + hand-off marks; equal to the PMC `traffic`) and the traceback "
-                                 "replays the blocks on the path. With planes in HBM (CSADP_BITS_CKPT=0) the same metric "
-                                 "reads 0.65 and the kernel sits at 88 % of the measured HBM write ceiling (DESIGN.md 3, 5). "
-                                 "bytes_per_launch = algorithmic bytes of the `passes_per_launch` passes one launch "
-                                 "carries; avg_launch_us = HIP events around ONE such launch alone on its stream (agrees "
-                                 "with rocprofv3 --stats on a single stream, profiles/r01_kernel_stats_solo.csv); "
-                                 "per_launch_achieved = bytes_per_launch / avg_launch_us; achieved = algorithmic bytes of "
-                                 "all timed passes / timed wall time (three launches in flight, so tails and tracebacks "
-                                 "hide under the next fill). The binding resource is VALU issue: roofline_valu"},
-            "roofline_valu": {"bound": "valu-issue", "ops_per_cell": VALU_OPS_PER_CELL,
-                              "issue_cycles_per_64_cells": VALU_ISSUE_CYCLES_PER_CELL_WAVE,
-                              "achieved": round(eff_cups / 1e9, 1), "peak": round(VALU_PEAK_CUPS / 1e9, 1),
-                              "unit": "GCUPS", "frac": round(eff_cups / VALU_PEAK_CUPS, 4),
-                              "note": "peak = 1024 SIMDs x 64 cells / issue cycles x 2.4 GHz with the per-instruction "
-                                      "issue rates measured one kind at a time on this chip "
-                                      "(profiles/r01_valu_microbench.txt) and the instruction count of the compiled kernel"},
+            "config": {"workload": workload + "; linear-gap NW: pack + fill + traceback + row expansion on the device, "
+                                              "bit-exact vs the reference",
+                       "pairs_this_rank": len(tasks), "seq_len": args.length, "kernel": "nw_fill_bits",
+                       "passes_per_launch": max(tm_pipe["launch_passes"], 1), "device_io": tm["device_io"],
+                       "parallelism": "independent tasks over %d GPU(s); no collective in the timed region; result records "
+                                      "all-gathered over %s afterwards" % (args.gpus, "RCCL" if args.backend == "nccl" else "gloo"),
+                       "lpt_imbalance": round(imbalance, 4)},
+            "records": {"gathered": len(by_id), "checked_against_reference_digests": checked},
+            "kernel_ms": {"fill_launch_alone": round(tm["fill_ms"], 3),
+                          "traceback_and_expand_alone": round(tm["traceback_ms"], 3),
+                          "passes_in_that_launch": lp,
+                          "fill_launch_pipelined": round(tm_pipe["fill_ms"], 3),
+                          "fill_alone_gcups": round(launch_cells / tm["fill_ms"] / 1e6, 1),
+                          "recoveries": tm["recoveries"]},
+            "host_boundary": {"create_ms": round(create_s * 1e3, 2), "fetch_ms": round(fetch_s * 1e3, 2),
+                              "note": "not part of value; create = argument checks + letters to pinned memory + H2D, "
+                                      "fetch = one D2H + result strings (Python unpacking included here; the C-ABI "
+                                      "figure is streaming.ms_per_batch)"},
+            "roofline": {"bound": "valu-issue", "kernel": "nw_fill_bits",
+                         "achieved": round(achieved_tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "TOP/s",
+                         "frac": round(achieved_tops / VALU_PEAK_TOPS, 4),
+                         "traffic": traffic,
+                         "what": "integer VALU lane-operations: %.0f wave64 VALU instructions per 2048 cells (ISA count of the "
+                                 "compiled step) x cells of one launch / its HIP-event duration; peak = 256 CUs x 4 SIMDs x "
+                                 "32 lanes/clk x 2.4 GHz (nominal 2 issue cycles per wave64 instruction)" % (BITS_VALU_PER_CELL * 32),
+                         "cells_per_launch": launch_cells, "avg_launch_us": round(tm["fill_ms"] * 1e3, 1),
+                         "sustained_frac": round(sustained_tops / VALU_PEAK_TOPS, 4),
+                         "calibrated": {"peak_gcups": round(calibrated_peak_gcups, 1),
+                                        "frac_alone": round(launch_cells / fill_s / 1e9 / calibrated_peak_gcups, 4),
+                                        "frac_sustained": round(value / args.gpus / calibrated_peak_gcups, 4),
+                                        "what": "ceiling with every instruction kind at the issue cost measured alone on this "
+                                                "chip (profiles/r01_valu_microbench.txt): %.1f cycles per 64 cells" % BITS_CYCLES_PER_64_CELLS}},
+            "roofline_hbm": {"bound": "hbm", "achieved": round(lp * impl_bytes / fill_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(lp * impl_bytes / fill_s / 1e9 / HBM_PEAK_GBS, 4),
+                             "bytes_per_launch": int(lp * impl_bytes),
+                             "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_CELL * launch_cells),
+                             "what": "bytes the fill actually writes (lane-state checkpoints + hand-off marks; no direction "
+                                     "planes in checkpoint mode) / launch duration.  SURVEY 8(d)'s algorithmic 0.25 B/cell is "
+                                     "listed for reference only: the kernel does not move those bytes, so it is not priced "
+                                     "against HBM"},
         }
+        if args.gpus == 1 and not args.no_extra_legs:
+            line["streaming"] = streaming_leg(csa_amd, tasks, batches=12)
+            line["profile_path"] = profile_path_leg(csa_amd)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)
             line["cpu_baseline"]["many_cores"] = many_cores

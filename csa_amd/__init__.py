@@ -69,7 +69,8 @@ class Timing(ctypes.Structure):
                 ("fill_tiles", ctypes.c_longlong), ("fill_ms", ctypes.c_float),
                 ("traceback_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("dir_bytes", ctypes.c_longlong), ("border_bytes", ctypes.c_longlong),
-                ("launch_passes", ctypes.c_int), ("bit_parallel", ctypes.c_int)]
+                ("launch_passes", ctypes.c_int), ("bit_parallel", ctypes.c_int),
+                ("recoveries", ctypes.c_int), ("device_io", ctypes.c_int)]
 
 
 # symbols declared in include/csadp.h and include/csadp_debug.h
@@ -77,7 +78,7 @@ EXPORTS = [
     "csadp_init", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
     "csadp_align_batch", "csadp_free_result", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
     "csadp_align_batch_multi", "csadp_pairs_create_on",
-    "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_fetch",
+    "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_flush", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
     "csadp_partition_lpt", "csadp_fnv1a", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
@@ -108,7 +109,7 @@ def lib():
         L.csadp_align_batch.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(Result)]
         L.csadp_free_result.argtypes = [ctypes.POINTER(Result), ctypes.c_int]
         L.csadp_pairs_create.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
-        for name in ("csadp_pairs_run", "csadp_pairs_sync"):
+        for name in ("csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_flush"):
             getattr(L, name).argtypes = [ctypes.c_void_p]
         L.csadp_pairs_destroy.argtypes = [ctypes.c_void_p]
         L.csadp_pairs_destroy.restype = None
@@ -256,6 +257,9 @@ class PairBatch:
 
     def sync(self):
         _check(lib().csadp_pairs_sync(self.h), "csadp_pairs_sync")
+
+    def flush(self):
+        _check(lib().csadp_pairs_flush(self.h), "csadp_pairs_flush")
 
     def timing(self):
         t = Timing()

@@ -98,6 +98,12 @@ private:
 	unsigned long long epoch_ = 0;
 };
 
+bool env_on(const char *name, bool dflt)
+{
+	const char *v = getenv(name);
+	return (v && *v) ? atoi(v) != 0 : dflt;
+}
+
 template <class F>
 void parallel_for(int n, F &&fn)
 {
@@ -236,6 +242,12 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 
 }  // namespace
 
+/* geometry of a 2-sequence task on the device-I/O path: which sequence is the column one */
+struct PairGeom {
+	int col = 0;                 /* index (0/1) of the sequence that seeds the profile = the columns (:290-307) */
+	int nrows = 0, ncols = 0;
+};
+
 struct csadp_pairbatch {
 	explicit csadp_pairbatch(Engine *e) : fb(e) {}
 	std::vector<Progressive> tasks;
@@ -243,13 +255,30 @@ struct csadp_pairbatch {
 	std::vector<int> active;     /* tasks that own a job of the batch */
 	FillBatch fb;
 	bool ran = false, fetched = false;
+	/* device-I/O path (csadp_pairio.hip): the letters are copied into the batch at create(), nothing of the
+	 * caller's memory is referenced afterwards; tasks with an empty region never reach the device and are
+	 * finished by the host logic (`tasks`, indexed like the batch) */
+	bool device_io = false;
+	std::vector<PairGeom> geom;
 };
+
+static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntasks, bool pipelined, bool strings);
 
 namespace {
 
 /* csadp_align_batch on one engine: lock-step rounds over the engine's cached arena */
 int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result *results)
 {
+	/* a batch of 2-sequence tasks takes the device-I/O pair path: letters up, rows down */
+	bool all_pairs = ntasks > 0 && env_on("CSADP_BITS", true) && env_on("CSADP_DEVICE_IO", true);
+	for (int t = 0; t < ntasks && all_pairs; ++t) all_pairs = tasks[t].nseq == 2;
+	if (all_pairs) {
+		csadp_pairbatch b(E);
+		int rc = pairs_create_io(&b, tasks, ntasks, false, true);
+		if (rc == CSADP_OK) rc = csadp_pairs_run(&b);
+		if (rc == CSADP_OK) rc = csadp_pairs_fetch(&b, results);
+		return rc;
+	}
 	std::vector<Progressive> prog((size_t)ntasks);
 	std::vector<int> status((size_t)ntasks, CSADP_OK);
 	parallel_for(ntasks, [&](int t) {
@@ -396,12 +425,89 @@ int csadp_pairs_create_on(int device, const csadp_task *tasks, int ntasks, csadp
 	return pairs_create(E, tasks, ntasks, out, false);
 }
 
+namespace {
+
+/* the argument checks of Progressive::init for one sequence of a task, without reading its letters */
+int check_region(const csadp_task &t, int s)
+{
+	if (!t.texts[s] || t.textsizes[s] < 0) return CSADP_ERR_ARG;
+	if (t.starts[s] < 0 || t.ends[s] < t.starts[s] || t.ends[s] > t.textsizes[s]) return CSADP_ERR_ARG;
+	if (t.ends[s] > t.starts[s] && (t.rotations[s] < 0 || t.rotations[s] >= t.textsizes[s])) return CSADP_ERR_ARG;
+	return CSADP_OK;
+}
+
+}  // namespace
+
+/*
+ * Device-I/O form of a pair batch: raw letters up, aligned rows down.  The host only checks the
+ * arguments, decides which sequence is the column one (SortSequencesForDP: the first strict minimum,
+ * :290-307), copies every distinct text into the pinned staging area once, and starts ONE H2D copy.
+ * CharAt / CharCodeFromSeq / the alphabet check run in nw_pack_planes, the traceback application of
+ * :1066-1138 in nw_expand_rows.  Nothing waits here: run()/flush() may follow at once.
+ */
+static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntasks, bool pipelined, bool strings)
+{
+	b->device_io = true;
+	b->geom.assign((size_t)ntasks, PairGeom());
+	b->tasks = std::vector<Progressive>((size_t)ntasks);
+	b->status.assign((size_t)ntasks, CSADP_OK);
+	FillBatch &fb = b->fb;
+	fb.set_pipelined(pipelined);
+	fb.allow_bits(true);
+	fb.want_strings(strings);
+	for (int t = 0; t < ntasks; ++t) {
+		const csadp_task &T = tasks[t];
+		if (!T.texts || !T.textsizes || !T.rotations || !T.starts || !T.ends) { b->status[(size_t)t] = CSADP_ERR_ARG; continue; }
+		int rc = check_region(T, 0);
+		if (rc == CSADP_OK) rc = check_region(T, 1);
+		if (rc != CSADP_OK) { b->status[(size_t)t] = rc; continue; }
+		const int len0 = T.ends[0] - T.starts[0], len1 = T.ends[1] - T.starts[1];
+		if (len0 == 0 || len1 == 0) {
+			/* no matrix: the host logic finishes the task (:916 early return, :950-956, or a walk that never starts) */
+			rc = b->tasks[(size_t)t].init(T);
+			if (rc == CSADP_OK) (void)advance(b->tasks[(size_t)t]);
+			b->status[(size_t)t] = rc;
+			b->geom[(size_t)t].nrows = -1;
+			continue;
+		}
+		PairGeom &G = b->geom[(size_t)t];
+		G.col = (len1 < len0) ? 1 : 0;
+		G.ncols = G.col ? len1 : len0;
+		G.nrows = G.col ? len0 : len1;
+		const int j = fb.add(G.nrows, G.ncols, 1, 1);
+		int tid[2], first[2];
+		for (int w = 0; w < 2; ++w) {
+			const int sq = w == 0 ? G.col : 1 - G.col;
+			tid[w] = fb.add_text(T.texts[sq], T.textsizes[sq]);
+			int f = T.rotations[sq] + T.starts[sq];          /* CharAt, alignment.c:16-20 */
+			if (f >= T.textsizes[sq]) f -= T.textsizes[sq];
+			first[w] = f;
+		}
+		fb.set_pair_io(j, tid[0], first[0], tid[1], first[1]);
+		b->active.push_back(t);
+	}
+	if (b->active.empty()) return CSADP_OK;
+	int rc = fb.layout();
+	if (rc != CSADP_OK) return rc;
+	if (!fb.device_io()) return CSADP_ERR_STATE;
+	parallel_for(fb.ntexts(), [&](int i) { memcpy(fb.text_staging(i), fb.text_source(i), (size_t)fb.text_size(i)); });
+	return fb.upload_async();
+}
+
 /* device_scores: the caller only wants DP scores -- where the traceback kernel can sum its path
  * itself it does, and the host never walks the traces */
 static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores)
 {
 	std::unique_ptr<csadp_pairbatch> b(new (std::nothrow) csadp_pairbatch(E));
 	if (!b) return CSADP_ERR_NOMEM;
+	for (int t = 0; t < ntasks; ++t)
+		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
+	if (env_on("CSADP_BITS", true) && env_on("CSADP_DEVICE_IO", true)) {
+		const int rc = pairs_create_io(b.get(), tasks, ntasks, true, !device_scores);
+		if (rc != CSADP_OK) return rc;
+		*out = b.release();
+		return CSADP_OK;
+	}
 	b->tasks = std::vector<Progressive>((size_t)ntasks);
 	b->status.assign((size_t)ntasks, CSADP_OK);
 	for (int t = 0; t < ntasks; ++t)
@@ -460,6 +566,12 @@ int csadp_pairs_run(csadp_pairbatch *b)
 	return b->fb.run();
 }
 
+int csadp_pairs_flush(csadp_pairbatch *b)
+{
+	if (!b) return CSADP_ERR_ARG;
+	return b->active.empty() ? CSADP_OK : b->fb.flush();
+}
+
 int csadp_pairs_sync(csadp_pairbatch *b)
 {
 	if (!b) return CSADP_ERR_ARG;
@@ -485,6 +597,52 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 		fprintf(stderr, "csadp_pairs_fetch:  %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tick).count());
 		tick = now;
 	};
+	if (b->device_io) {
+		if (!b->active.empty()) {
+			const int rc = b->fb.download();
+			if (rc != CSADP_OK) return rc;
+		}
+		lap("download");
+		std::vector<int> job_of((size_t)b->tasks.size(), -1);
+		for (size_t j = 0; j < b->active.size(); ++j) job_of[(size_t)b->active[j]] = (int)j;
+		parallel_for((int)b->tasks.size(), [&](int t) {
+			csadp_result &R = results[t];
+			memset(&R, 0, sizeof(R));
+			int st = b->status[(size_t)t];
+			const int j = job_of[(size_t)t];
+			if (st == CSADP_OK && j < 0) st = b->tasks[(size_t)t].finish(&R);      /* a task without a matrix */
+			if (st == CSADP_OK && j >= 0) {
+				const PairGeom &G = b->geom[(size_t)t];
+				const int32_t *sm = b->fb.summary(j);
+				if (sm[4] & 1) st = CSADP_ERR_ALPHABET;
+				else if (sm[4] != 0) st = CSADP_ERR_HIP;
+				else {
+					R.consensus = sm[0] + sm[1] + sm[2];
+					R.score = sm[3];
+					R.fills = 1;
+					R.cells = (long long)G.nrows * G.ncols;
+					R.aligned = (char **)calloc(2, sizeof(char *));
+					R.progress = strdup(".");
+					char *a = (char *)malloc((size_t)R.consensus + 1), *c = (char *)malloc((size_t)R.consensus + 1);
+					if (!R.aligned || !R.progress || !a || !c) {
+						free(a); free(c); free(R.aligned); free(R.progress);
+						R.aligned = NULL; R.progress = NULL;
+						st = CSADP_ERR_NOMEM;
+					} else {
+						memcpy(a, b->fb.out_row(j, 0), (size_t)R.consensus + 1);
+						memcpy(c, b->fb.out_row(j, 1), (size_t)R.consensus + 1);
+						R.aligned[G.col] = a;                /* original index order (:1160) */
+						R.aligned[1 - G.col] = c;
+					}
+				}
+			}
+			b->status[(size_t)t] = st;
+			R.status = st;
+		});
+		lap("result strings");
+		b->fetched = true;
+		return CSADP_OK;
+	}
 	if (!b->active.empty()) {
 		const int rc = b->fb.download();
 		if (rc != CSADP_OK) return rc;
@@ -524,6 +682,12 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 	parallel_for((int)b->active.size(), [&](int j) {
 		const int32_t *sm = b->fb.summary(j);
 		const size_t t = (size_t)b->active[(size_t)j];
+		if (b->device_io) {                                /* nw_expand_rows summed the path */
+			if (sm[4] & 1) b->status[t] = CSADP_ERR_ALPHABET;
+			else if (sm[4] != 0) b->status[t] = CSADP_ERR_HIP;
+			else scores[t] = sm[3];
+			return;
+		}
 		if (b->fb.device_scores()) {                     /* the traceback kernel has already summed its path */
 			scores[t] = sm[3];
 			return;
@@ -533,7 +697,8 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 	});
 	/* tasks without a matrix (an empty region): the score is the border cell the host already knows */
 	for (int t = 0; t < ntasks; ++t) {
-		if (b->status[(size_t)t] == CSADP_OK && !b->tasks[(size_t)t].next_fill()) {
+		const bool no_matrix = b->device_io ? b->geom[(size_t)t].nrows < 0 : !b->tasks[(size_t)t].next_fill();
+		if (b->status[(size_t)t] == CSADP_OK && no_matrix) {
 			csadp_result r;
 			memset(&r, 0, sizeof(r));
 			if (b->tasks[(size_t)t].finish(&r) == CSADP_OK) { scores[t] = r.score; csadp_free_result(&r, 2); }

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
-	__shared__ uint32_t scrap[kBitMaxStrips][kBitBlock];
+	__shared__ uint32_t scrap[kBitMaxStrips][kLanes + kBitBlock];   /* lane l, step t -> word l + t: 64 different banks per store */
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	const BitJob &J = jobs[blockIdx.x];
 	const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[s][lane] = word;
-		uint32_t *lanebuf = !writes ? &scrap[s][0] : (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
+		uint32_t *lanebuf = !writes ? &scrap[s][lane] : (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
 	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
-	__shared__ uint32_t scrap[kBitMaxStrips][kBitBlock];
+	__shared__ uint32_t scrap[kBitMaxStrips][kLanes + kBitBlock];   /* lane l, step t -> word l + t: 64 different banks per store */
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	const TileRef item = work[blockIdx.x];                      /* x: the work list of one pass, y: the pass */
 	const BitJob &J = jobs[(size_t)blockIdx.y * njobs + item.job];
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[wv][lane] = word;
-		uint32_t *lanebuf = !writes ? &scrap[wv][0] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
+		uint32_t *lanebuf = !writes ? &scrap[wv][lane] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */

@@ -137,6 +137,15 @@ struct BitJob {
 	int32_t steps_pad;        /* local steps per strip, multiple of kBitBlock, >= nrows + 64                               */
 	int32_t nwords_pad;       /* 64 * nstrips                                                                              */
 	int32_t rowwords;         /* steps_pad / 32                                                                            */
+	/* device-side input packing / output expansion of 2-sequence tasks (nw_pack_planes, nw_expand_rows): the batch
+	 * holds the raw circular texts; [0] = the column sequence (the shorter region, dynamicprogramming.c:290-307),
+	 * [1] = the row sequence.  text = 0 (no arena offset is 0: the job table sits there) marks a job whose planes
+	 * the host wrote.                                                                                            */
+	uint64_t text[2];         /* u8 [size] the sequence as loaded (un-rotated)                                             */
+	uint64_t out[2];          /* u8 [nrows + ncols + 1] the aligned row of that sequence, NUL-terminated (per slot)        */
+	uint64_t istatus;         /* i32 input status: bit 0 = a letter other than A,C,G,T inside a region (survey Q4)         */
+	int32_t size[2];          /* textsizes                                                                                 */
+	int32_t first[2];         /* rotation + start, wrapped once: text index of the region's first letter (CharAt)          */
 };
 
 }  // namespace csadp

@@ -133,30 +133,71 @@ int Engine::init(int dev, const csadp_config *cfg)
 	return CSADP_OK;
 }
 
+/* Pools of released HBM arenas and pinned staging buffers: consecutive batches of similar size
+ * (bench steps, the drop-in's ~50 calls, a streaming caller with several pair batches in flight) skip
+ * hipMalloc / hipHostMalloc, which cost 0.1 .. 1 ms each.  Best fit; a full pool drops its smallest entry. */
+namespace {
+constexpr size_t kPoolEntries = 6;
+
+uint8_t *pool_take(std::vector<std::pair<uint8_t *, size_t>> &pool, size_t need, size_t *got)
+{
+	int best = -1;
+	for (size_t i = 0; i < pool.size(); ++i)
+		if (pool[i].second >= need && (best < 0 || pool[i].second < pool[(size_t)best].second)) best = (int)i;
+	if (best < 0) return nullptr;
+	uint8_t *p = pool[(size_t)best].first;
+	*got = pool[(size_t)best].second;
+	pool.erase(pool.begin() + best);
+	return p;
+}
+
+/* returns the buffer the pool lets go of (to be freed by the caller), or nullptr */
+uint8_t *pool_give(std::vector<std::pair<uint8_t *, size_t>> &pool, uint8_t *ptr, size_t bytes)
+{
+	pool.emplace_back(ptr, bytes);
+	if (pool.size() <= kPoolEntries) return nullptr;
+	size_t smallest = 0;
+	for (size_t i = 1; i < pool.size(); ++i)
+		if (pool[i].second < pool[smallest].second) smallest = i;
+	uint8_t *drop = pool[smallest].first;
+	pool.erase(pool.begin() + (long)smallest);
+	return drop;
+}
+}  // namespace
+
 void Engine::give_arena(uint8_t *ptr, size_t bytes)
 {
 	if (!ptr) return;
-	if (!ready_ || bytes <= cached_bytes_) { (void)hipFree(ptr); return; }
-	if (cached_arena_) (void)hipFree(cached_arena_);
-	cached_arena_ = ptr;
-	cached_bytes_ = bytes;
+	std::lock_guard<std::mutex> lock(pool_mutex_);
+	uint8_t *drop = ready_ ? pool_give(arena_pool_, ptr, bytes) : ptr;
+	if (drop) (void)hipFree(drop);
 }
 
 uint8_t *Engine::take_arena(size_t need, size_t *got)
 {
-	if (!cached_arena_ || cached_bytes_ < need) return nullptr;
-	uint8_t *p = cached_arena_;
-	*got = cached_bytes_;
-	cached_arena_ = nullptr;
-	cached_bytes_ = 0;
-	return p;
+	std::lock_guard<std::mutex> lock(pool_mutex_);
+	return pool_take(arena_pool_, need, got);
+}
+
+void Engine::give_pinned(uint8_t *ptr, size_t bytes)
+{
+	if (!ptr) return;
+	std::lock_guard<std::mutex> lock(pool_mutex_);
+	uint8_t *drop = ready_ ? pool_give(pinned_pool_, ptr, bytes) : ptr;
+	if (drop) (void)hipHostFree(drop);
+}
+
+uint8_t *Engine::take_pinned(size_t need, size_t *got)
+{
+	std::lock_guard<std::mutex> lock(pool_mutex_);
+	return pool_take(pinned_pool_, need, got);
 }
 
 void Engine::drop_arena_cache()
 {
-	if (cached_arena_) (void)hipFree(cached_arena_);
-	cached_arena_ = nullptr;
-	cached_bytes_ = 0;
+	std::lock_guard<std::mutex> lock(pool_mutex_);
+	for (auto &e : arena_pool_) (void)hipFree(e.first);
+	arena_pool_.clear();
 }
 
 void Engine::shutdown()
@@ -169,6 +210,11 @@ void Engine::shutdown()
 		cached_batch = nullptr;
 	}
 	drop_arena_cache();
+	{
+		std::lock_guard<std::mutex> lock(pool_mutex_);
+		for (auto &e : pinned_pool_) (void)hipHostFree(e.first);
+		pinned_pool_.clear();
+	}
 	for (int i = 0; i < std::max(slots_, 2); ++i) {
 		(void)hipStreamSynchronize(streams_[i]);
 		(void)hipStreamDestroy(streams_[i]);
@@ -182,10 +228,14 @@ void Engine::shutdown()
 FillBatch::~FillBatch()
 {
 	(void)E_->bind();
+	/* the arena and the pinned mirrors go back to the engine's pools: nothing may still be using them */
+	if (laid_out_)
+		for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl) (void)hipStreamSynchronize(E_->stream(sl));
 	if (arena_) E_->give_arena(arena_, arena_cap_);
-	if (h_in_) (void)hipHostFree(h_in_);
-	if (h_res_) (void)hipHostFree(h_res_);
+	if (h_in_) E_->give_pinned(h_in_, h_in_cap_);
+	if (h_res_) E_->give_pinned(h_res_, h_res_cap_);
 	if (h_abort_) (void)hipHostFree(h_abort_);
+	if (ev_up_) (void)hipEventDestroy(ev_up_);
 	for (auto &slot : ev_)
 		for (auto &e : slot)
 			if (e) (void)hipEventDestroy(e);
@@ -205,9 +255,30 @@ void FillBatch::clear()
 	bits_ = false;
 	bjobs_.clear();
 	bextra_.clear();
+	texts_.clear();
+	pairio_.clear();
+	io_ = false;
 	laid_out_ = false;
 	ran_ = false;
 }
+
+int FillBatch::add_text(const char *text, int size)
+{
+	for (size_t i = 0; i < texts_.size(); ++i)
+		if (texts_[i].ptr == text && texts_[i].size == size) return (int)i;
+	texts_.push_back(TextRef{text, size, 0});
+	return (int)texts_.size() - 1;
+}
+
+void FillBatch::set_pair_io(int j, int text_col, int first_col, int text_row, int first_row)
+{
+	if ((int)pairio_.size() <= j) pairio_.resize((size_t)j + 1, PairIo{{-1, -1}, {0, 0}});
+	pairio_[(size_t)j] = PairIo{{text_col, text_row}, {first_col, first_row}};
+}
+
+uint8_t *FillBatch::text_staging(int id) { return h_in_ + texts_[(size_t)id].off; }
+
+const uint8_t *FillBatch::out_row(int j, int which) const { return h_res_ + bextra_[(size_t)j].res_out[which]; }
 
 int FillBatch::add(int nrows, int ncols, int nprev, int left_i)
 {
@@ -354,34 +425,7 @@ int FillBatch::layout()
 	}
 	total_bytes_ = off;
 
-	if (total_bytes_ > arena_cap_) {
-		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
-		arena_ = E.take_arena(total_bytes_, &arena_cap_);
-	}
-	if (total_bytes_ > arena_cap_) {
-		E.drop_arena_cache();
-		size_t free_b = 0, total_b = 0;
-		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		if (total_bytes_ + (256u << 20) > free_b) {
-			fprintf(stderr, "csadp: batch needs %.1f GiB of HBM, %.1f GiB free\n",
-			        total_bytes_ / 1073741824.0, free_b / 1073741824.0);
-			return CSADP_ERR_RANGE;
-		}
-		HIP_TRY(hipMalloc((void **)&arena_, total_bytes_));
-		arena_cap_ = total_bytes_;
-	}
-	if (in_bytes_ > h_in_cap_) {
-		if (h_in_) (void)hipHostFree(h_in_);
-		h_in_ = nullptr;
-		HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
-		h_in_cap_ = in_bytes_;
-	}
-	if (res_bytes_ > h_res_cap_) {
-		if (h_res_) (void)hipHostFree(h_res_);
-		h_res_ = nullptr;
-		HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
-		h_res_cap_ = res_bytes_;
-	}
+	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
 	for (int sl = 0; sl < nslots_; ++sl)
 		for (auto &e : ev_[sl])
 			if (!e) HIP_TRY(hipEventCreate(&e));
@@ -571,34 +615,7 @@ int FillBatch::layout_pk()
 	}
 	total_bytes_ = off;
 
-	if (total_bytes_ > arena_cap_) {
-		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
-		arena_ = E.take_arena(total_bytes_, &arena_cap_);
-	}
-	if (total_bytes_ > arena_cap_) {
-		E.drop_arena_cache();
-		size_t free_b = 0, total_b = 0;
-		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-		if (total_bytes_ + (256u << 20) > free_b) {
-			fprintf(stderr, "csadp: batch needs %.1f GiB of HBM, %.1f GiB free\n",
-			        total_bytes_ / 1073741824.0, free_b / 1073741824.0);
-			return CSADP_ERR_RANGE;
-		}
-		HIP_TRY(hipMalloc((void **)&arena_, total_bytes_));
-		arena_cap_ = total_bytes_;
-	}
-	if (in_bytes_ > h_in_cap_) {
-		if (h_in_) (void)hipHostFree(h_in_);
-		h_in_ = nullptr;
-		HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
-		h_in_cap_ = in_bytes_;
-	}
-	if (res_bytes_ > h_res_cap_) {
-		if (h_res_) (void)hipHostFree(h_res_);
-		h_res_ = nullptr;
-		HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
-		h_res_cap_ = res_bytes_;
-	}
+	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
 	for (int sl = 0; sl < nslots_; ++sl)
 		for (auto &e : ev_[sl])
 			if (!e) HIP_TRY(hipEventCreate(&e));
@@ -664,6 +681,10 @@ int FillBatch::layout_bits()
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)J.nrows * words * 8;
 	}
+	/* device-side I/O: every job has its two texts registered */
+	io_ = (int)pairio_.size() == nj && nj > 0;
+	for (const PairIo &P : pairio_)
+		if (P.text[0] < 0 || P.text[1] < 0) io_ = false;
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	if (bits_ckpt_) {                              /* no direction planes: lane state per block + hand-off words */
 		dir_bytes_ = 0;
@@ -696,7 +717,10 @@ int FillBatch::layout_bits()
 		off += (size_t)nj * sizeof(BitJob);
 	}
 	off = align_up(off, 256);
+	abort_off_ = off;                             /* one abort word for every launch of the batch, zeroed by upload() */
+	off += 256;
 	tiles_off_ = off;
+	chunk_first_.clear();
 	if (bits_wide_) {
 		/* work list of the chunked kernel: (job, chunk of 16 strips), the longest jobs first -- they
 		 * are the critical path of a mixed batch -- and a job's chunks in ascending order, so that the
@@ -716,29 +740,92 @@ int FillBatch::layout_bits()
 				tiles_.push_back(t);
 			}
 		off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
+		/* the same items once more, grouped by chunk index: the serial fallback launches one group at a
+		 * time, so no workgroup ever waits for another (recover_bits) */
+		serial_off_ = off;
+		std::vector<TileRef> serial(tiles_);
+		std::stable_sort(serial.begin(), serial.end(), [](const TileRef &a, const TileRef &b) { return a.a < b.a; });
+		for (size_t i = 0; i < serial.size(); ++i)
+			if (i == 0 || serial[i].a != serial[i - 1].a) chunk_first_.push_back(i);
+		chunk_first_.push_back(serial.size());
+		serial_tiles_.swap(serial);
+		off = align_up(off + serial_tiles_.size() * sizeof(TileRef), 256);
 	}
-	for (int j = 0; j < nj; ++j) {
-		BitJob &B = bjobs_[(size_t)j];
-		bextra_[(size_t)j].in_cols = B.colplanes = off;
-		off = align_up(off + (size_t)2 * B.nwords_pad * 4, 256);
-		bextra_[(size_t)j].in_rows = B.rowplanes = off;
-		off = align_up(off + (size_t)2 * B.rowwords * 4, 256);
+	if (io_) {
+		/* inputs = the raw texts (each once) + one status word per job; the planes are per-slot scratch
+		 * written by nw_pack_planes */
+		for (TextRef &T : texts_) {
+			T.off = off;
+			off = align_up(off + (size_t)T.size + 16, 256);
+		}
+		for (int j = 0; j < nj; ++j) {
+			BitJob &B = bjobs_[(size_t)j];
+			const PairIo &P = pairio_[(size_t)j];
+			for (int w = 0; w < 2; ++w) {
+				B.text[w] = texts_[(size_t)P.text[w]].off;
+				B.size[w] = texts_[(size_t)P.text[w]].size;
+				B.first[w] = P.first[w];
+			}
+			B.istatus = off;
+			off += 4;
+		}
+		off = align_up(off, 256);
+	} else {
+		for (int j = 0; j < nj; ++j) {
+			BitJob &B = bjobs_[(size_t)j];
+			bextra_[(size_t)j].in_cols = B.colplanes = off;
+			off = align_up(off + (size_t)2 * B.nwords_pad * 4, 256);
+			bextra_[(size_t)j].in_rows = B.rowplanes = off;
+			off = align_up(off + (size_t)2 * B.rowwords * 4, 256);
+		}
 	}
 	in_bytes_ = off;
 	std::vector<std::vector<BitJob>> slot_jobs((size_t)nslots_, bjobs_);
 	for (int sl = 0; sl < nslots_; ++sl) {
 		res_off_[sl] = off;
-		for (int j = 0; j < nj; ++j) {
-			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
-			Extra &X = extra_[(size_t)j];
-			B.summary = off;
-			X.res_summary = off - res_off_[sl];
-			off += 64;
-			B.ops = off;
-			X.res_ops = off - res_off_[sl];
-			off = align_up(off + (size_t)B.nrows + B.ncols + 64, 256);
+		if (io_) {
+			/* results = [summaries][aligned rows]: the host never sees the op lists */
+			for (int j = 0; j < nj; ++j) {
+				slot_jobs[(size_t)sl][(size_t)j].summary = off;
+				extra_[(size_t)j].res_summary = off - res_off_[sl];
+				off += 64;
+			}
+			off = align_up(off, 256);
+			sum_bytes_ = off - res_off_[sl];
+			for (int j = 0; j < nj; ++j) {
+				BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+				for (int w = 0; w < 2; ++w) {
+					B.out[w] = off;
+					bextra_[(size_t)j].res_out[w] = off - res_off_[sl];
+					off = align_up(off + (size_t)B.nrows + B.ncols + 1, 16);
+				}
+			}
+			off = align_up(off, 256);
+		} else {
+			for (int j = 0; j < nj; ++j) {
+				BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+				Extra &X = extra_[(size_t)j];
+				B.summary = off;
+				X.res_summary = off - res_off_[sl];
+				off += 64;
+				B.ops = off;
+				X.res_ops = off - res_off_[sl];
+				off = align_up(off + (size_t)B.nrows + B.ncols + 64, 256);
+			}
+			sum_bytes_ = off - res_off_[sl];
 		}
 		res_bytes_ = off - res_off_[sl];
+		if (io_) {
+			for (int j = 0; j < nj; ++j) {               /* scratch of this slot: op list and bit planes */
+				BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+				B.ops = off;
+				off = align_up(off + (size_t)B.nrows + B.ncols + 64, 256);
+				B.colplanes = off;
+				off = align_up(off + (size_t)2 * B.nwords_pad * 4, 256);
+				B.rowplanes = off;
+				off = align_up(off + (size_t)2 * B.rowwords * 4, 256);
+			}
+		}
 		flags_off_[sl] = off;                     /* abort word | progress counters of wide jobs: zeroed before every launch */
 		off += 256;
 		for (int j = 0; j < nj; ++j) {
@@ -763,14 +850,22 @@ int FillBatch::layout_bits()
 	if (rc != CSADP_OK) return rc;
 	for (int sl = 0; sl < nslots_; ++sl)
 		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(BitJob));
-	if (!tiles_.empty()) memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
+	if (!tiles_.empty()) {
+		memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
+		memcpy(h_in_ + serial_off_, serial_tiles_.data(), serial_tiles_.size() * sizeof(TileRef));
+	}
+	next_stream_ = 0;
+	/* batches of one engine start on different streams, so that a streaming caller's batches (each one
+	 * pass, several in flight) overlap instead of queueing behind each other */
+	base_stream_ = E.rotate_stream() % std::max(E.slots(), 2);
+	used_streams_ = 0;
 	bjobs_ = slot_jobs[0];
 	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
 	return CSADP_OK;
 }
 
-/* HBM arena, pinned staging mirrors (zeroed inputs), events */
-int FillBatch::finish_layout()
+/* HBM arena and pinned staging mirrors, grow-only, taken from / returned to the engine's pools */
+int FillBatch::alloc_buffers()
 {
 	Engine &E = *E_;
 	if (total_bytes_ > arena_cap_) {
@@ -778,9 +873,12 @@ int FillBatch::finish_layout()
 		arena_ = E.take_arena(total_bytes_, &arena_cap_);
 	}
 	if (total_bytes_ > arena_cap_) {
-		E.drop_arena_cache();
 		size_t free_b = 0, total_b = 0;
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		if (total_bytes_ + (256u << 20) > free_b) {
+			E.drop_arena_cache();
+			HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		}
 		if (total_bytes_ + (256u << 20) > free_b) {
 			fprintf(stderr, "csadp: batch needs %.1f GiB of HBM, %.1f GiB free\n",
 			        total_bytes_ / 1073741824.0, free_b / 1073741824.0);
@@ -790,17 +888,28 @@ int FillBatch::finish_layout()
 		arena_cap_ = total_bytes_;
 	}
 	if (in_bytes_ > h_in_cap_) {
-		if (h_in_) (void)hipHostFree(h_in_);
-		h_in_ = nullptr;
-		HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
-		h_in_cap_ = in_bytes_;
+		if (h_in_) E.give_pinned(h_in_, h_in_cap_);
+		h_in_ = E.take_pinned(in_bytes_, &h_in_cap_);
+		if (!h_in_) {
+			HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
+			h_in_cap_ = in_bytes_;
+		}
 	}
 	if (res_bytes_ > h_res_cap_) {
-		if (h_res_) (void)hipHostFree(h_res_);
-		h_res_ = nullptr;
-		HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
-		h_res_cap_ = res_bytes_;
+		if (h_res_) E.give_pinned(h_res_, h_res_cap_);
+		h_res_ = E.take_pinned(res_bytes_, &h_res_cap_);
+		if (!h_res_) {
+			HIP_TRY(hipHostMalloc((void **)&h_res_, res_bytes_, hipHostMallocDefault));
+			h_res_cap_ = res_bytes_;
+		}
 	}
+	return CSADP_OK;
+}
+
+/* buffers, zeroed inputs, events */
+int FillBatch::finish_layout()
+{
+	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
 	for (int sl = 0; sl < nslots_; ++sl)
 		for (auto &e : ev_[sl])
 			if (!e) HIP_TRY(hipEventCreate(&e));
@@ -825,6 +934,24 @@ int FillBatch::upload()
 	 * timed path; run() calls may follow on any stream) */
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, E_->stream(0)));
 	HIP_TRY(hipStreamSynchronize(E_->stream(0)));
+	return CSADP_OK;
+}
+
+/* inputs -> HBM without waiting.  The copy runs on the engine's stream 0 and an event makes every other
+ * stream of the engine wait for it, so passes may be enqueued right away (device-I/O pair batches: the
+ * host never blocks between create and fetch). */
+int FillBatch::upload_async()
+{
+	if (!laid_out_) return CSADP_ERR_STATE;
+	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
+	const int nst = std::max(E_->slots(), 2);
+	hipStream_t s0 = E_->stream(bits_ ? base_stream_ : 0);
+	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, s0));
+	if (!ev_up_) HIP_TRY(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
+	HIP_TRY(hipEventRecord(ev_up_, s0));
+	for (int sl = 0; sl < nst; ++sl)
+		if (E_->stream(sl) != s0) HIP_TRY(hipStreamWaitEvent(E_->stream(sl), ev_up_, 0));
+	used_streams_ |= 1u << (bits_ ? base_stream_ : 0);
 	return CSADP_OK;
 }
 
@@ -856,39 +983,90 @@ int FillBatch::flush()
 	return CSADP_OK;
 }
 
-/* Bit-parallel mode: enqueue k passes as merged launches of up to bits_group_ consecutive slots.
- * Slots [0, group) always run on stream 0 and slots [group, 2*group) on stream 1, so a slot is
- * reused in stream order. */
+/* Bit-parallel mode: enqueue k passes as merged launches of up to bits_group_ passes.  Launches
+ * rotate over bits_streams_ streams; stream q owns slots [q * group, (q + 1) * group) and every launch
+ * starts at its stream's first slot, so the passes per launch never depend on how many passes earlier
+ * flushes carried (a slot is reused in stream order). */
 int FillBatch::flush_bits(int k)
 {
 	Engine &E = *E_;
 	const int nj = (int)bjobs_.size();
 	while (k > 0) {
-		const int first = next_slot_;
-		const int half_end = (first / bits_group_ + 1) * bits_group_;          /* end of this stream's slot range */
-		const int g = std::min(k, std::min(half_end, nslots_) - first);
-		hipStream_t st = E.stream(nslots_ > 1 ? (first / bits_group_) % bits_streams_ : 0);
-		hipEvent_t *ev = ev_[first + g - 1];
-		const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
-		HIP_TRY(hipEventRecord(ev[0], st));
-		for (int sl = first; sl < first + g; ++sl)         /* abort word (of the first slot) and every slot's progress counters */
-			HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
-		if (bits_wide_)
-			HIP_TRY(launch_fill_bits_wide(arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(),
-			                              reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
-		else
-			HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, reinterpret_cast<int *>(arena_ + flags_off_[first]), st));
-		HIP_TRY(hipEventRecord(ev[1], st));
-		HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, st));
-		HIP_TRY(hipEventRecord(ev[2], st));
-		for (int sl = first; sl < first + g; ++sl) {
-			slot_used_[sl] = true;
-			flag_slot_[sl] = first;
-		}
+		const int qi = nslots_ > 1 ? next_stream_ : 0;                 /* slot range of this launch */
+		const int q = (base_stream_ + qi) % std::max(E.slots(), 2);   /* its stream */
+		const int first = qi * bits_group_;
+		const int g = std::min(k, bits_group_);
+		const int rc = launch_bits_pass(first, g, E.stream(q), false);
+		used_streams_ |= 1u << q;
+		last_stream_ = q;
+		if (rc != CSADP_OK) return rc;
+		for (int sl = first; sl < first + g; ++sl) slot_used_[sl] = true;
 		last_slot_ = first + g - 1;
 		last_group_ = g;
-		next_slot_ = (first + g) % nslots_;
+		next_stream_ = (next_stream_ + 1) % bits_streams_;
 		k -= g;
+	}
+	(void)nj;
+	return CSADP_OK;
+}
+
+/* g merged passes (slots first .. first+g-1) on stream st: [pack planes] fill, traceback, [expand rows].
+ * serial = the wait-free form of the chunked fill: one launch per chunk index (recover_bits). */
+int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, bool serial)
+{
+	const int nj = (int)bjobs_.size();
+	hipEvent_t *ev = ev_[first + g - 1];
+	const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
+	int *abort_word = reinterpret_cast<int *>(arena_ + abort_off_);
+	HIP_TRY(hipEventRecord(ev[0], st));
+	if (io_) HIP_TRY(launch_pack_planes(arena_, bj, g * nj, st));
+	if (bits_wide_) {
+		for (int sl = first; sl < first + g; ++sl)         /* progress counters of the chunked jobs */
+			HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
+		if (!serial) {
+			HIP_TRY(launch_fill_bits_wide(arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), abort_word, st));
+		} else {
+			for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
+				HIP_TRY(launch_fill_bits_wide(arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
+				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), abort_word, st));
+		}
+	} else {
+		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, abort_word, st));
+	}
+	HIP_TRY(hipEventRecord(ev[1], st));
+	HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, st));
+	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, st));
+	HIP_TRY(hipEventRecord(ev[2], st));
+	return CSADP_OK;
+}
+
+/* Did a bounded wait inside a bit-parallel fill run out (the word is shared by every launch since
+ * upload())?  Then no pass since then can be trusted: repeat the LAST pass -- the one whose results
+ * fetch() hands out -- on the wait-free path.  Chunked fills (nw_fill_bits_wide) wait across
+ * workgroups and rely on dispatch order for speed, never for results: launched chunk by chunk the
+ * producer of every hand-off has finished before its consumer starts. */
+int FillBatch::check_abort()
+{
+	if (!bits_ || !h_abort_) return CSADP_OK;
+	hipStream_t st = E_->stream(last_stream_);
+	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (*h_abort_ == 0) return CSADP_OK;
+	if (!bits_wide_) {
+		fprintf(stderr, "csadp: a wait inside the bit-parallel fill kernel timed out\n");
+		return CSADP_ERR_HIP;
+	}
+	fprintf(stderr, "csadp: a cross-workgroup wait of the chunked fill timed out; repeating the pass chunk by chunk\n");
+	++recoveries_;
+	HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 0, 4, st));
+	const int first = (last_slot_ / bits_group_) * bits_group_;
+	const int rc = launch_bits_pass(first, last_slot_ - first + 1, st, true);
+	if (rc != CSADP_OK) return rc;
+	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(hipStreamSynchronize(st));
+	if (*h_abort_ != 0) {
+		fprintf(stderr, "csadp: the chunk-by-chunk repeat timed out as well\n");
+		return CSADP_ERR_HIP;
 	}
 	return CSADP_OK;
 }
@@ -936,8 +1114,10 @@ int FillBatch::sync()
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	const int rc = flush();
 	if (rc != CSADP_OK) return rc;
-	for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
-	return CSADP_OK;
+	/* bit-parallel batches wait for the streams THEY used: other batches of the engine keep running */
+	for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl)
+		if (!bits_ || (used_streams_ >> sl) & 1u) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
+	return ran_ ? check_abort() : CSADP_OK;
 }
 
 int FillBatch::download()
@@ -948,15 +1128,7 @@ int FillBatch::download()
 		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
 		if (rc != CSADP_OK) return rc;
 	}
-	hipStream_t st = E_->stream(bits_ ? (nslots_ > 1 ? (last_slot_ / bits_group_) % bits_streams_ : 0) : last_slot_);
-	if (bits_) {
-		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + flags_off_[flag_slot_[last_slot_]], 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		if (*h_abort_ != 0) {
-			fprintf(stderr, "csadp: a wait inside the bit-parallel fill kernel timed out\n");
-			return CSADP_ERR_HIP;
-		}
-	}
+	hipStream_t st = E_->stream(bits_ ? last_stream_ : last_slot_);
 	if (pk_ && persist_) {
 		/* did a bounded spin of the persistent kernel run out?  Then its directions are
 		 * incomplete: repeat the pass with the launch-per-diagonal kernels (no in-kernel waits) */
@@ -969,7 +1141,8 @@ int FillBatch::download()
 			if (rc != CSADP_OK) return rc;
 		}
 	}
-	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], res_bytes_, hipMemcpyDeviceToHost, st));
+	const size_t want = (io_ && !want_strings_) ? sum_bytes_ : res_bytes_;
+	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], want, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	return CSADP_OK;
 }
@@ -988,10 +1161,18 @@ int FillBatch::timing(csadp_timing *t)
 	memset(t, 0, sizeof(*t));
 	hipEvent_t *ev = ev_[last_slot_];
 	HIP_TRY(hipEventSynchronize(ev[2]));
+	{
+		const int before = recoveries_;
+		const int rc = check_abort();                 /* a launch that gave up early must not be timed as if it had run */
+		if (rc != CSADP_OK) return rc;
+		if (recoveries_ != before) HIP_TRY(hipEventSynchronize(ev[2]));
+	}
 	HIP_TRY(hipEventElapsedTime(&t->fill_ms, ev[0], ev[1]));
 	HIP_TRY(hipEventElapsedTime(&t->traceback_ms, ev[1], ev[2]));
 	HIP_TRY(hipEventElapsedTime(&t->total_ms, ev[0], ev[2]));
 	t->launch_passes = bits_ ? last_group_ : 1;
+	t->recoveries = recoveries_;
+	t->device_io = io_ ? 1 : 0;
 	t->bit_parallel = bits_ ? (bits_ckpt_ ? 2 : 1) : 0;
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;

@@ -8,7 +8,9 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "csadp.h"
@@ -34,6 +36,7 @@ public:
 	static Engine *primary_if_ready();
 	static void shutdown_all();
 	int bind() const;                /* hipSetDevice(device_) on the calling thread */
+	int rotate_stream() { return stream_rr_.fetch_add(1); }
 	bool ready() const { return ready_; }
 	static constexpr int kMaxSlots = 16;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
@@ -45,10 +48,11 @@ public:
 	const char *name() const { return name_; }
 	int compute_units() const { return cus_; }
 	bool verbose() const { return verbose_; }
-	/* one-entry cache of the last released HBM arena: consecutive batches of similar size
-	 * (bench steps, csa_pairs runs, the drop-in's ~50 calls) skip hipMalloc/hipFree */
+	/* pools of released HBM arenas / pinned staging buffers (csadp_engine.cpp) */
 	void give_arena(uint8_t *ptr, size_t bytes);
 	uint8_t *take_arena(size_t need, size_t *got);
+	void give_pinned(uint8_t *ptr, size_t bytes);
+	uint8_t *take_pinned(size_t need, size_t *got);
 	void drop_arena_cache();
 
 	/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) per device alive
@@ -67,8 +71,9 @@ private:
 	char name_[256] = {0};
 	int slots_ = 2;
 	hipStream_t streams_[kMaxSlots] = {};
-	uint8_t *cached_arena_ = nullptr;
-	size_t cached_bytes_ = 0;
+	std::atomic<int> stream_rr_{0};
+	std::mutex pool_mutex_;
+	std::vector<std::pair<uint8_t *, size_t>> arena_pool_, pinned_pool_;
 };
 
 /*
@@ -120,10 +125,25 @@ public:
 	int bit_nwords(int j) const;
 	uint32_t *bit_rows(int j);         /* [2][bit_rowwords(j)] */
 	int bit_rowwords(int j) const;
+	/* Device-side I/O of 2-sequence tasks (bit-parallel mode only; csadp_pairio.hip): the batch holds the
+	 * raw texts, the planes are packed and the aligned rows written on the device.  add_text() registers a
+	 * text once per (pointer, size); set_pair_io() names the column / row sequence of job j and the text
+	 * index of each region's first letter.  After layout(): copy the letters to text_staging(id). */
+	int add_text(const char *text, int size);
+	void set_pair_io(int j, int text_col, int first_col, int text_row, int first_row);
+	bool device_io() const { return io_; }
+	int ntexts() const { return (int)texts_.size(); }
+	uint8_t *text_staging(int id);
+	const char *text_source(int id) const { return texts_[(size_t)id].ptr; }
+	int text_size(int id) const { return texts_[(size_t)id].size; }
+	/* results of the last pass in device-I/O mode: the aligned row of the column (0) / row (1) sequence */
+	const uint8_t *out_row(int j, int which) const;
+	void want_strings(bool on) { want_strings_ = on; }   /* false: download() fetches the summaries only */
 	uint8_t *rowshift(int j);        /* points at row 1 (index padl) */
 	int32_t *top(int j);
 	int ncols_pad(int j) const;
-	int upload();                    /* inputs -> HBM (async on the engine stream) */
+	int upload();                    /* inputs -> HBM, waits for the copy */
+	int upload_async();              /* the same without waiting: later work of every engine stream is ordered behind it */
 	/* Request one more pass.  Passes are enqueued at the next sync()/timing()/download(): tiled
 	 * kernels: pass i on slot i % slots and that slot's stream; bit-parallel kernels: consecutive
 	 * passes merged into launches that rotate over 2-3 streams (flush_bits). */
@@ -142,13 +162,26 @@ private:
 	Engine *E_;
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
 	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
-	struct BitExtra { size_t in_cols, in_rows; };
+	struct BitExtra { size_t in_cols, in_rows; size_t res_out[2]; };
+	struct TextRef { const char *ptr; int size; size_t off; };
+	struct PairIo { int text[2], first[2]; };
+	std::vector<TextRef> texts_;
+	std::vector<PairIo> pairio_;
+	bool io_ = false, want_strings_ = true;
+	size_t sum_bytes_ = 0;             /* leading part of a slot's result region that holds the summaries */
 	int layout_pk();
 	int layout_bits();
 	int flush_bits(int k);
-	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2;
-	int flag_slot_[Engine::kMaxSlots] = {};
-	int finish_layout();             /* arena / staging allocation shared by the layouts */
+	int launch_bits_pass(int first, int g, hipStream_t st, bool serial);
+	int check_abort();
+	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0;
+	int base_stream_ = 0, last_stream_ = 0;
+	unsigned used_streams_ = 0;
+	size_t abort_off_ = 0, serial_off_ = 0;
+	std::vector<TileRef> serial_tiles_;
+	std::vector<size_t> chunk_first_;
+	int alloc_buffers();             /* arena / staging allocation shared by the layouts */
+	int finish_layout();
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
 	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false, want_scores_ = false;
@@ -180,6 +213,7 @@ private:
 	uint8_t *h_res_ = nullptr;       /* pinned mirror of the result region */
 	size_t h_res_cap_ = 0;
 	hipEvent_t ev_[Engine::kMaxSlots][3] = {};
+	hipEvent_t ev_up_ = nullptr;
 	bool laid_out_ = false, ran_ = false, pipelined_ = false, wide_ = false;
 	long long cells_ = 0, dir_bytes_ = 0, border_bytes_ = 0;
 };

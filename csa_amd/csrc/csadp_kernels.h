@@ -38,6 +38,10 @@ hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, 
                                  int *abort_word, hipStream_t st);
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
 hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st);
+/* csadp_pairio.hip: 2-sequence tasks whose letters live in the arena (BitJob::text): bit planes from
+ * the raw circular texts, and the two aligned rows + the DP score from the traceback's op list */
+hipError_t launch_pack_planes(uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st);
+hipError_t launch_expand_rows(uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st);
 /* once per device (function attributes), with that device current */
 hipError_t configure_kernels();
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st);

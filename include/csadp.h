@@ -142,18 +142,25 @@ CSADP_API int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp
 /* ---- device-resident pair batches (the benchmarked path) --------------------------- */
 
 /*
- * A batch of 2-sequence tasks whose inputs live in HBM: create() validates, packs and
- * uploads; run() requests one pass (fill + traceback of the whole batch) and returns
- * immediately; sync() enqueues every requested pass and waits; fetch() downloads the traceback
- * of the LAST pass and builds the aligned strings.  run() may be called repeatedly before a
- * sync() (benchmark steps, streaming use): consecutive passes rotate over independent
- * result/scratch slots on separate HIP streams so that they overlap on the device.
+ * A batch of 2-sequence tasks whose inputs live in HBM.  create() checks the arguments, copies the
+ * letters of every distinct text into pinned memory and STARTS one H2D copy (it does not wait and does
+ * not reference the caller's texts afterwards); run() requests one pass and returns immediately;
+ * flush() enqueues the requested passes, sync() also waits; fetch() downloads the LAST pass' results
+ * in one D2H copy.  A pass = nw_pack_planes (CharAt + letter codes + alphabet check of both regions,
+ * from the raw circular texts) -> fill -> traceback -> nw_expand_rows (the two aligned rows and the DP
+ * score), all on the device: the host never touches a letter between create and fetch.  run() may be
+ * called repeatedly before a sync() (benchmark steps, streaming use): consecutive passes are merged
+ * into launches that rotate over independent result/scratch slots on separate HIP streams.  A
+ * streaming caller keeps several batches in flight: create + run + flush of batch n+1 before fetch
+ * of batch n.  (CSADP_DEVICE_IO=0 or CSADP_BITS=0: the host packs tables and applies traces, as for
+ * N-sequence tasks.)
  */
 typedef struct csadp_pairbatch csadp_pairbatch;
 
 CSADP_API int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
 CSADP_API int csadp_pairs_create_on(int device, const csadp_task *tasks, int ntasks, csadp_pairbatch **out);
 CSADP_API int csadp_pairs_run(csadp_pairbatch *b);
+CSADP_API int csadp_pairs_flush(csadp_pairbatch *b);    /* enqueue every requested pass, do not wait */
 CSADP_API int csadp_pairs_sync(csadp_pairbatch *b);
 CSADP_API int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results);
 CSADP_API void csadp_pairs_destroy(csadp_pairbatch *b);
@@ -181,6 +188,10 @@ typedef struct csadp_timing {
 	int bit_parallel;       /* 0 = tiled kernels, 1 = bit-parallel kernels (nw_fill_bits) with  */
 	                        /* direction planes in HBM, 2 = bit-parallel with checkpoints and    */
 	                        /* replay traceback (default)                                        */
+	int recoveries;         /* passes repeated on the wait-free path after a bounded wait of the  */
+	                        /* chunked fill ran out (0 in any healthy run)                        */
+	int device_io;          /* 1 = a pass starts from the raw letters in HBM and ends with the    */
+	                        /* aligned rows in HBM (nw_pack_planes / nw_expand_rows in the pass)  */
 } csadp_timing;
 
 CSADP_API int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);

@@ -22,10 +22,14 @@ def device():
 # First fills (every pairwise task, and step 1 of every progressive task) run the bit-parallel
 # kernels by default (csadp_bits.hip); CSADP_BITS=0 sends them to the packed-16 pair kernel and
 # CSADP_BITS=0 CSADP_PK16=0 to the 32-bit profile kernel.  The environment is read at every batch
-# layout, so the tests below that take `fill_mode` cover all three.
-@pytest.fixture(params=["bits", "packed16", "int32"])
+# layout, so the tests below that take `fill_mode` cover all three.  Batches of 2-sequence tasks in
+# bit-parallel mode also pack their inputs and build their rows on the device (csadp_pairio.hip);
+# "bits-hostio" switches that off: tables written and traces applied by the host, as for N sequences.
+@pytest.fixture(params=["bits", "bits-hostio", "packed16", "int32"])
 def fill_mode(request, monkeypatch):
-    if request.param != "bits":
+    if request.param == "bits-hostio":
+        monkeypatch.setenv("CSADP_DEVICE_IO", "0")
+    elif request.param != "bits":
         monkeypatch.setenv("CSADP_BITS", "0")
     if request.param == "int32":
         monkeypatch.setenv("CSADP_PK16", "0")
@@ -112,6 +116,41 @@ def test_families_vs_oracle_medium():
         assert g["aligned"] == strs
         assert g["score"] == st.last_score
         assert g["cells"] == st.cells and g["fills"] == st.fills
+
+
+def test_device_io_alphabet_regions_and_rotations():
+    """The device-side input path (nw_pack_planes): CharAt's single wrap at every rotation/start
+    combination, sub-regions, shared texts (one upload per distinct text), letters outside A,C,G,T
+    inside and outside the regions (CSADP_ERR_ALPHABET only when inside, per task), empty regions
+    beside full ones in one batch -- against the oracle string for string."""
+    r = rng(99)
+    base = [bytes(r.choice(b"ACGT") for _ in range(n)) for n in (1, 2, 63, 64, 65, 700, 2049)]
+    tasks = []
+    for _ in range(120):
+        a, b = r.choice(base), r.choice(base)
+        ra, rb = r.randrange(len(a)), r.randrange(len(b))
+        sa = r.randrange(len(a) + 1) if r.random() < 0.5 else 0
+        sb = r.randrange(len(b) + 1) if r.random() < 0.5 else 0
+        ea = r.randrange(sa, len(a) + 1) if r.random() < 0.5 else len(a)
+        eb = r.randrange(sb, len(b) + 1) if r.random() < 0.5 else len(b)
+        tasks.append(([a, b], [ra, rb], [sa, sb], [ea, eb]))
+    # an N inside the region of one task, outside the region of another
+    dirty = bytearray(base[5]); dirty[100] = ord("N"); dirty = bytes(dirty)
+    tasks.append(([dirty, base[5]], [0, 0], [0, 0], [700, 700]))          # N at rotated position 100: inside
+    tasks.append(([dirty, base[5]], [0, 0], [101, 0], [700, 700]))        # region starts behind it: fine
+    tasks.append(([dirty, base[5]], [650, 0], [0, 0], [100, 700]))        # rotated positions 0..99 = text 650..699, 0..49: fine
+    tasks.append(([dirty, base[5]], [650, 0], [0, 0], [151, 700]))        # ... 0..100: inside
+    got = csa_amd.align_batch(tasks)
+    assert [g["status"] for g in got[-4:]] == [csa_amd.ERR_ALPHABET, 0, 0, csa_amd.ERR_ALPHABET]
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(*t)
+        if cons < 0:
+            assert g["status"] == csa_amd.ERR_ALPHABET and g["aligned"] is None
+            continue
+        assert g["status"] == 0 and g["consensus"] == cons
+        assert g["aligned"] == (strs if strs[0] is not None else None)
+        if strs[0] is not None:
+            assert g["score"] == st.last_score and g["progress"] == ("." if st.fills else "")
 
 
 def test_errors():
