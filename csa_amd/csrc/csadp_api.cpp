@@ -98,6 +98,8 @@ private:
 	unsigned long long epoch_ = 0;
 };
 
+constexpr int kNoDeviceIo = 1;    /* pairs_create_io: use the host-I/O path instead (never leaves this file) */
+
 bool env_on(const char *name, bool dflt)
 {
 	const char *v = getenv(name);
@@ -277,7 +279,7 @@ int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result 
 		int rc = pairs_create_io(&b, tasks, ntasks, false, true);
 		if (rc == CSADP_OK) rc = csadp_pairs_run(&b);
 		if (rc == CSADP_OK) rc = csadp_pairs_fetch(&b, results);
-		return rc;
+		if (rc != kNoDeviceIo) return rc;
 	}
 	std::vector<Progressive> prog((size_t)ntasks);
 	std::vector<int> status((size_t)ntasks, CSADP_OK);
@@ -489,7 +491,7 @@ static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntas
 	if (b->active.empty()) return CSADP_OK;
 	int rc = fb.layout();
 	if (rc != CSADP_OK) return rc;
-	if (!fb.device_io()) return CSADP_ERR_STATE;
+	if (!fb.device_io()) return kNoDeviceIo;      /* the batch did not qualify for the bit-parallel kernels */
 	parallel_for(fb.ntexts(), [&](int i) { memcpy(fb.text_staging(i), fb.text_source(i), (size_t)fb.text_size(i)); });
 	return fb.upload_async();
 }
@@ -504,9 +506,13 @@ static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pa
 		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
 	if (env_on("CSADP_BITS", true) && env_on("CSADP_DEVICE_IO", true)) {
 		const int rc = pairs_create_io(b.get(), tasks, ntasks, true, !device_scores);
-		if (rc != CSADP_OK) return rc;
-		*out = b.release();
-		return CSADP_OK;
+		if (rc == CSADP_OK) {
+			*out = b.release();
+			return CSADP_OK;
+		}
+		if (rc != kNoDeviceIo) return rc;
+		b.reset(new (std::nothrow) csadp_pairbatch(E));   /* e.g. direction planes in HBM and a job wider than one workgroup */
+		if (!b) return CSADP_ERR_NOMEM;
 	}
 	b->tasks = std::vector<Progressive>((size_t)ntasks);
 	b->status.assign((size_t)ntasks, CSADP_OK);
