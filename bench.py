@@ -374,7 +374,12 @@ def main():
                                      "against HBM"},
         }
         if args.gpus == 1 and not args.no_extra_legs:
-            line["streaming"] = streaming_leg(csa_amd, tasks, batches=12)
+            # a throughput caller sizes its batches to fill the chip: 4 x the step's batch = one 512-workgroup
+            # fill launch per batch (what the timed region reaches by merging 4 passes of 128 pairs)
+            big = tasks if args.mode != "weak" else tasks + config4_tasks((world + 1) * args.pairs, 3 * args.pairs, args.length)
+            line["streaming"] = streaming_leg(csa_amd, big, batches=8)
+            line["streaming"]["pairs_per_batch"] = len(big)
+            line["streaming"]["vs_value"] = round(line["streaming"]["gcups"] / (value / args.gpus), 3)
             line["profile_path"] = profile_path_leg(csa_amd)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)

@@ -230,7 +230,8 @@ FillBatch::~FillBatch()
 	(void)E_->bind();
 	/* the arena and the pinned mirrors go back to the engine's pools: nothing may still be using them */
 	if (laid_out_)
-		for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl) (void)hipStreamSynchronize(E_->stream(sl));
+		for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl)
+			if (!bits_ || (used_streams_ >> sl) & 1u) (void)hipStreamSynchronize(E_->stream(sl));
 	if (arena_) E_->give_arena(arena_, arena_cap_);
 	if (h_in_) E_->give_pinned(h_in_, h_in_cap_);
 	if (h_res_) E_->give_pinned(h_res_, h_res_cap_);

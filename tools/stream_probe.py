@@ -39,3 +39,6 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 for depth in (1, 2, 3, 4, 6):
     print(depth, bench.streaming_leg(csa_amd, tasks, 16, depth=depth), flush=True)
+big = config4_tasks(0, 512, 16384)
+for depth in (1, 2, 3):
+    print("512 pairs", depth, bench.streaming_leg(csa_amd, big, 8, depth=depth), flush=True)
