@@ -259,6 +259,8 @@ void FillBatch::clear()
 	texts_.clear();
 	pairio_.clear();
 	io_ = false;
+	cells_mode_ = false;
+	cjobs_.clear();
 	laid_out_ = false;
 	ran_ = false;
 }
@@ -306,6 +308,7 @@ int FillBatch::layout()
 	wide_ = false;
 	pk_ = false;
 	bits_ = false;
+	cells_mode_ = false;
 	if (bits_allowed_ && nj >= 1 && env_int("CSADP_BITS", 1) != 0) {
 		bits_ = true;
 		bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
@@ -323,6 +326,9 @@ int FillBatch::layout()
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) pk_ = false;
 	}
 	if (pk_) return layout_pk();
+	/* every other fill (profile steps, stale borders, pairs with the bit-parallel path switched off):
+	 * the persistent cell-per-lane wavefront; CSADP_CELLS=0 keeps the tiled 32-bit kernel */
+	if (env_int("CSADP_CELLS", 1) != 0) return layout_cells();
 
 	/* geometry + tile schedule */
 	int ndiag = 0;
@@ -447,6 +453,134 @@ int32_t *FillBatch::leftc(int j) { return reinterpret_cast<int32_t *>(h_in_ + ex
 uint8_t *FillBatch::rowshift(int j) { return h_in_ + extra_[j].in_rowshift + jobs_[j].padl; }
 int32_t *FillBatch::top(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_top); }
 int FillBatch::ncols_pad(int j) const { return pk_ ? pextra_[(size_t)pair_of_[(size_t)j]].ncols_pad : extra_[j].ncols_pad; }
+
+/* Cell-per-lane mode (csadp_cells.hip): one CellJob per fill, a work list of (job, chunk of kCellWaves
+ * strips) -- the longest jobs first, a job's chunks in ascending order -- one launch per pass. */
+int FillBatch::layout_cells()
+{
+	Engine &E = *E_;
+	const int nj = (int)jobs_.size();
+	cells_mode_ = true;
+	cjobs_.assign((size_t)nj, CellJob());
+	tiles_.clear();
+	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
+	for (int j = 0; j < nj; ++j) {
+		FillJob &J = jobs_[(size_t)j];
+		if (J.nrows <= 0 || J.ncols <= 0) return CSADP_ERR_ARG;
+		const long long nprev = J.nprev;
+		if (nprev < 1 || nprev > 63) return CSADP_ERR_ARG;
+		if (nprev * (2LL * J.nrows + J.ncols) * 4 + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
+		if (nprev > 31) wide_ = true;
+		CellJob &C = cjobs_[(size_t)j];
+		memset(&C, 0, sizeof(C));
+		C.nrows = J.nrows;
+		C.ncols = J.ncols;
+		C.nprev = J.nprev;
+		C.leftmul = J.leftmul;
+		C.nstrips = (J.ncols + kLanes - 1) / kLanes;
+		C.nchunks = (C.nstrips + kCellWaves - 1) / kCellWaves;
+		C.steps_pad = (int)align_up((size_t)J.nrows + 64, kCellBlock);
+		J.nstrips = C.nstrips;
+		J.steps_pad = C.steps_pad;
+		J.padl = 0;
+		extra_[(size_t)j].ncols_pad = C.nstrips * kLanes;
+		cells_ += (long long)J.nrows * J.ncols;
+		dir_bytes_ += (long long)C.nstrips * (C.steps_pad / 16) * kLanes * 4;
+		border_bytes_ += (long long)std::max(C.nchunks - 1, 0) * C.steps_pad * 8 * 2;      /* written once, read once */
+	}
+	{
+		std::vector<int> order((size_t)nj);
+		for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+			const CellJob &A = cjobs_[(size_t)a], &B = cjobs_[(size_t)b];
+			return (long long)A.steps_pad + 64LL * A.nstrips > (long long)B.steps_pad + 64LL * B.nstrips;   /* wavefront length */
+		});
+		for (int j : order)
+			for (int c = 0; c < cjobs_[(size_t)j].nchunks; ++c) {
+				TileRef t;
+				t.job = j;
+				t.a = c;
+				t.s = 0;
+				t.first = 0;
+				tiles_.push_back(t);
+			}
+		serial_tiles_ = tiles_;
+		std::stable_sort(serial_tiles_.begin(), serial_tiles_.end(), [](const TileRef &a, const TileRef &b) { return a.a < b.a; });
+		chunk_first_.clear();
+		for (size_t i = 0; i < serial_tiles_.size(); ++i)
+			if (i == 0 || serial_tiles_[i].a != serial_tiles_[i - 1].a) chunk_first_.push_back(i);
+		chunk_first_.push_back(serial_tiles_.size());
+	}
+
+	nslots_ = pipelined_ ? E.slots() : 1;
+	next_slot_ = 0;
+	size_t off = 0;
+	for (int sl = 0; sl < nslots_; ++sl) {
+		jobs_off_[sl] = off;
+		off += (size_t)nj * sizeof(CellJob);
+	}
+	off = align_up(off, 256);
+	abort_off_ = off;
+	off += 256;
+	tiles_off_ = off;
+	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
+	serial_off_ = off;
+	off = align_up(off + serial_tiles_.size() * sizeof(TileRef), 256);
+	for (int j = 0; j < nj; ++j) {
+		CellJob &C = cjobs_[(size_t)j];
+		Extra &X = extra_[(size_t)j];
+		X.in_coltab = C.coltab = off;
+		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
+		X.in_leftc = C.leftc = off;
+		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
+		X.in_rowshift = C.rowshift = off;
+		off = align_up(off + (size_t)C.steps_pad + 64, 256);
+		X.in_top = C.top = off;
+		off = align_up(off + ((size_t)X.ncols_pad + 1) * 4, 256);
+	}
+	in_bytes_ = off;
+	std::vector<std::vector<CellJob>> slot_jobs((size_t)nslots_, cjobs_);
+	for (int sl = 0; sl < nslots_; ++sl) {
+		res_off_[sl] = off;
+		for (int j = 0; j < nj; ++j) {
+			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
+			Extra &X = extra_[(size_t)j];
+			C.summary = off;
+			X.res_summary = off - res_off_[sl];
+			off += 64;
+			C.ops = off;
+			X.res_ops = off - res_off_[sl];
+			off = align_up(off + (size_t)C.nrows + C.ncols + 64, 256);
+		}
+		res_bytes_ = off - res_off_[sl];
+		sum_bytes_ = res_bytes_;
+		flags_off_[sl] = off;                     /* progress counters of the chunked jobs: zeroed before every pass */
+		for (int j = 0; j < nj; ++j) {
+			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
+			C.progress = off;
+			off += (size_t)C.nchunks * 4;
+		}
+		off = align_up(off, 256);
+		flags_bytes_ = off - flags_off_[sl];
+		for (int j = 0; j < nj; ++j) {
+			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
+			C.dirs = off;
+			off = align_up(off + (size_t)C.nstrips * (C.steps_pad / 16) * kLanes * 4, 256);
+			C.hand = off;
+			off = align_up(off + (size_t)C.nchunks * C.steps_pad * 8, 256);
+		}
+	}
+	total_bytes_ = off;
+	const int rc = finish_layout();
+	if (rc != CSADP_OK) return rc;
+	for (int sl = 0; sl < nslots_; ++sl)
+		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(CellJob));
+	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
+	memcpy(h_in_ + serial_off_, serial_tiles_.data(), serial_tiles_.size() * sizeof(TileRef));
+	cjobs_ = slot_jobs[0];
+	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
+	return CSADP_OK;
+}
 
 /* Packed-16 pair mode: jobs sorted by size are paired (A = low half word, B = high half word);
  * the pair uses the geometry of the larger matrix.  Same arena structure as layout(). */
@@ -1048,7 +1182,25 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, bool serial)
  * producer of every hand-off has finished before its consumer starts. */
 int FillBatch::check_abort()
 {
-	if (!bits_ || !h_abort_) return CSADP_OK;
+	if ((!bits_ && !cells_mode_) || !h_abort_) return CSADP_OK;
+	if (cells_mode_) {
+		hipStream_t st = E_->stream(last_slot_);
+		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (*h_abort_ == 0) return CSADP_OK;
+		fprintf(stderr, "csadp: a wait of the cell-per-lane fill timed out; repeating the pass chunk by chunk\n");
+		++recoveries_;
+		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 0, 4, st));
+		const int rc = run_slot_cells(last_slot_, true);
+		if (rc != CSADP_OK) return rc;
+		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (*h_abort_ != 0) {
+			fprintf(stderr, "csadp: the chunk-by-chunk repeat timed out as well\n");
+			return CSADP_ERR_HIP;
+		}
+		return CSADP_OK;
+	}
 	hipStream_t st = E_->stream(last_stream_);
 	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1073,9 +1225,35 @@ int FillBatch::check_abort()
 }
 
 /* Enqueue ONE pass (fill + traceback) of slot sl on stream sl. */
+/* one pass of the cell-per-lane kernels on slot sl: progress counters, fill (one launch, or one per
+ * chunk index on the wait-free path), traceback */
+int FillBatch::run_slot_cells(int sl, bool serial)
+{
+	hipStream_t st = E_->stream(sl);
+	hipEvent_t *ev = ev_[sl];
+	const CellJob *cj = reinterpret_cast<const CellJob *>(arena_ + jobs_off_[sl]);
+	int *abort_word = reinterpret_cast<int *>(arena_ + abort_off_);
+	if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));
+	HIP_TRY(hipEventRecord(ev[0], st));
+	if (flags_bytes_ > 0) HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
+	if (!serial) {
+		HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), abort_word, st));
+	} else {
+		for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
+			HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
+			                          (int)(chunk_first_[c + 1] - chunk_first_[c]), abort_word, st));
+	}
+	HIP_TRY(hipEventRecord(ev[1], st));
+	HIP_TRY(launch_traceback_cells(arena_, cj, (int)cjobs_.size(), st));
+	HIP_TRY(hipEventRecord(ev[2], st));
+	slot_used_[sl] = true;
+	return CSADP_OK;
+}
+
 int FillBatch::run_slot(int sl, bool persistent)
 {
 	Engine &E = *E_;
+	if (cells_mode_) return run_slot_cells(sl, false);
 	hipStream_t st = E.stream(sl);
 	hipEvent_t *ev = ev_[sl];
 	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);

@@ -171,6 +171,10 @@ private:
 	size_t sum_bytes_ = 0;             /* leading part of a slot's result region that holds the summaries */
 	int layout_pk();
 	int layout_bits();
+	int layout_cells();
+	int run_slot_cells(int sl, bool serial);
+	std::vector<CellJob> cjobs_;
+	bool cells_mode_ = false;
 	int flush_bits(int k);
 	int launch_bits_pass(int first, int g, hipStream_t st, bool serial);
 	int check_abort();

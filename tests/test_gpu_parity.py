@@ -25,14 +25,25 @@ def device():
 # layout, so the tests below that take `fill_mode` cover all three.  Batches of 2-sequence tasks in
 # bit-parallel mode also pack their inputs and build their rows on the device (csadp_pairio.hip);
 # "bits-hostio" switches that off: tables written and traces applied by the host, as for N sequences.
-@pytest.fixture(params=["bits", "bits-hostio", "packed16", "int32"])
+@pytest.fixture(params=["bits", "bits-hostio", "packed16", "cells", "tiles32"])
 def fill_mode(request, monkeypatch):
     if request.param == "bits-hostio":
         monkeypatch.setenv("CSADP_DEVICE_IO", "0")
     elif request.param != "bits":
         monkeypatch.setenv("CSADP_BITS", "0")
-    if request.param == "int32":
+    if request.param in ("cells", "tiles32"):          # the general 32-bit kernels, here on pairs
         monkeypatch.setenv("CSADP_PK16", "0")
+    if request.param == "tiles32":
+        monkeypatch.setenv("CSADP_CELLS", "0")
+    return request.param
+
+
+# Profile steps (i >= 2, stale borders) run the persistent cell-per-lane kernel (csadp_cells.hip);
+# CSADP_CELLS=0 keeps the tiled kernel with one launch per tile anti-diagonal.
+@pytest.fixture(params=["cells", "tiles"])
+def profile_mode(request, monkeypatch):
+    if request.param == "tiles":
+        monkeypatch.setenv("CSADP_CELLS", "0")
     return request.param
 
 
@@ -53,7 +64,7 @@ def test_tiny_pairs_golden(fill_mode):
         _check_case(c, g)
 
 
-def test_tiny_families_golden():
+def test_tiny_families_golden(profile_mode):
     """N=3..8 progressive tasks: profile mode of the kernel, stale borders (Q1),
     DeleteGappedColumns on the host, zero-length regions."""
     cases = load_golden("tiny_families.json")
@@ -103,7 +114,7 @@ def test_unrelated_pair_negative_scores(fill_mode):
     assert g["aligned"] == strs and g["score"] == st.last_score
 
 
-def test_families_vs_oracle_medium():
+def test_families_vs_oracle_medium(profile_mode):
     r = rng(99)
     tasks = []
     for n, length in [(3, 900), (5, 1500), (8, 700), (16, 300)]:
@@ -116,6 +127,45 @@ def test_families_vs_oracle_medium():
         assert g["aligned"] == strs
         assert g["score"] == st.last_score
         assert g["cells"] == st.cells and g["fills"] == st.fills
+
+
+@pytest.mark.parametrize("length", [1, 2, 31, 63, 64, 65, 191, 255, 256, 257, 513, 1030, 4100])
+def test_cells_kernel_strip_chunk_and_block_boundaries(length):
+    """nw_fill_cells / nw_traceback_cells at the boundaries of their geometry: a lane per column, 64 per
+    strip, 4 strips per workgroup (wider jobs chain workgroups through HBM), 32 steps per hand-off block,
+    16 steps per direction word, a 16-strip traceback window.  Families of 3..6 sequences (profile steps,
+    stale borders, DeleteGappedColumns between them) against the oracle, string for string."""
+    r = rng(1000 + length)
+    tasks = []
+    for n in (3, 4, 6):
+        fam = random_family(r, n, length, mut=0.12, indel=0.05)
+        fam = [f if f else b"A" for f in fam]
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    # very different lengths: few rows under many columns and the reverse
+    short = bytes(r.choice(b"ACGT") for _ in range(max(1, length // 20)))
+    fam = random_family(r, 3, length, mut=0.1, indel=0.03)
+    tasks.append(([short] + [f if f else b"C" for f in fam], [0, 0, 0, 0], None, None))
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["status"] == 0 and g["consensus"] == cons, (length, len(t[0]))
+        assert g["aligned"] == strs, (length, len(t[0]))
+        assert g["score"] == st.last_score and g["fills"] == st.fills
+
+
+def test_cells_kernel_paths_that_leave_the_traceback_window():
+    """Profiles whose optimal path drifts far from the diagonal (a 700-letter insertion in the middle of the
+    row sequence): the walk leaves its LDS window and must reload it around the current cell."""
+    r = rng(4711)
+    base = bytes(r.choice(b"ACGT") for _ in range(2500))
+    ins = bytes(r.choice(b"ACGT") for _ in range(700))
+    fam = [base, base[:1200] + ins + base[1200:], base[:400] + base[900:], base]
+    got = csa_amd.align_batch([(fam, [0, 0, 0, 0], None, None), (fam[::-1], [3, 2, 1, 0], None, None)])
+    for t, g in zip([fam, fam[::-1]], got):
+        pass
+    for (f, rot), g in zip([(fam, [0, 0, 0, 0]), (fam[::-1], [3, 2, 1, 0])], got):
+        cons, strs, st = oracle_progressive(f, rot)
+        assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score
 
 
 def test_device_io_alphabet_regions_and_rotations():
@@ -288,7 +338,7 @@ def test_config5_mixed_lengths_sample():
 
 
 @pytest.mark.parametrize("nseq", [33, 40, 64])
-def test_wide_profile_more_than_32_sequences(nseq):
+def test_wide_profile_more_than_32_sequences(nseq, profile_mode):
     """i >= 32 switches the batch to the 6-bit-count table format (csadp_device.h); 64 is the
     reference's MAXNUMBEROFSEQS (csamsa.c:23)."""
     r = rng(1000 + nseq)
