@@ -20,8 +20,9 @@
  * offset of that row come from lane L-1 (v_mov_b32_dpp wave_shr:1), which had the row one step
  * earlier.  Lane 0 takes them from LDS (`inject`, prepared per block of 32 steps): the border column
  * and the row letters for the first strip of a job, else the words the previous strip's lane 63
- * left in the LDS ring 63 steps earlier (same workgroup) or in `hand` in HBM (previous chunk,
- * published block by block through an agent-scope counter).  Directions: 16 steps of 2-bit tags per
+ * left in the LDS ring 63 steps earlier (same workgroup) or in `hand` in HBM (previous chunk: 8-byte
+ * granules tagged with the launch's epoch, written through by one store each and requested one block
+ * ahead by the consumer -- no counter, no fence).  Directions: 16 steps of 2-bit tags per
  * word and lane, one coalesced 256-byte store per wave every 16 steps = 0.25 B/cell, the algorithmic
  * figure of SURVEY 8(d).
  *
@@ -46,21 +47,14 @@ constexpr int kRingSteps = kRing * kCellBlock;
 constexpr int kSpinMax = 1 << 22;
 constexpr int DPP_WAVE_SHR1 = 0x138;
 
+/* Counters in LDS that order LDS data only: the LDS executes one wave's instructions in order and is
+ * coherent inside the compute unit, so relaxed accesses suffice -- a workgroup-scope release/acquire
+ * would also drain the wave's outstanding direction stores (vmcnt(0)), a microsecond per 32-step block. */
 __device__ __forceinline__ bool wait_lds(const int *counter, int need)
 {
 	int spins = 0;
-	while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
 		__builtin_amdgcn_s_sleep(1);
-		if (++spins > kSpinMax) return false;
-	}
-	return true;
-}
-
-__device__ __forceinline__ bool wait_hbm(const int *counter, int need)
-{
-	int spins = 0;
-	while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
-		__builtin_amdgcn_s_sleep(4);
 		if (++spins > kSpinMax) return false;
 	}
 	return true;
@@ -75,41 +69,44 @@ struct CellState {
 
 /* 32 steps.  inject[t] = (X, letter offset) entering lane 0 at step t; every lane stores what it hands
  * to the right to lanebuf[t] (the ring for lane 63, a scrap area for all others: no EXEC change);
- * dirs points at this lane's word of the block's first 16 steps. */
+ * dirs points at this lane's word of the block's first 16 steps.
+ * A step is ~8 VALU instructions, far shorter than an LDS round trip, so nothing inside the step may wait
+ * for LDS: the block's 32 inject entries are read into registers up front (64 VGPRs; all lanes read the
+ * same address, only lane 0's copy is used), one wait per block, and the per-step hand-off stores are
+ * never waited for. */
 template <bool WIDE, bool RAMP>
 __device__ __forceinline__ void cell_block(CellState &S, uint32_t tab, int32_t leftc, const uint2 *inject, uint2 *lanebuf,
                                            uint32_t *dirs, int l0, int lane)
 {
 	uint32_t ioff = 0;
-	asm volatile("" : "+v"(ioff));                     /* keep the address in a VGPR: one broadcast LDS read per step */
-	uint2 cur = inject[ioff];
+	asm volatile("" : "+v"(ioff));                     /* keep the address in a VGPR: broadcast LDS reads */
+	uint2 inj[kCellBlock];
+#pragma unroll
+	for (int t = 0; t < kCellBlock; ++t) inj[t] = inject[ioff + t];
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__builtin_amdgcn_sched_barrier(0);                 /* the reads stay here, ahead of the steps */
 	uint32_t acc = 0;
 #pragma unroll
 	for (int t = 0; t < kCellBlock; ++t) {
-		const uint2 nxt = inject[ioff + (t + 1 < kCellBlock ? t + 1 : t)];
-		const int32_t in = __builtin_amdgcn_update_dpp((int)cur.x, S.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)cur.y, (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		cur = nxt;
+		const int32_t in = __builtin_amdgcn_update_dpp((int)inj[t].x, S.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
+		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)inj[t].y, (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
 		int32_t dg;
 		if (WIDE) dg = S.diag + 2 + (int32_t)(__builtin_amdgcn_ubfe(tab, sh, 6) << 3);    /* 6-bit counts: gain = 8*sv + 2 */
 		else dg = S.diag + (int32_t)__builtin_amdgcn_ubfe(tab, sh, 8);                    /* pre-scaled byte 8*sv + 2      */
 		const int32_t lf = in + leftc;
 		int32_t h = max(max(dg, S.hup), lf);
+		acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
+		h &= ~3;
 		if (RAMP) {
 			/* rows above the matrix: the lane keeps its border values until its first row arrives */
 			const bool live = l0 + t >= lane;
-			acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
-			h &= ~3;
 			S.diag = live ? in : S.diag;
 			S.hup = live ? h : S.hup;
-			S.outv = S.hup;
 		} else {
-			acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
-			h &= ~3;
 			S.diag = in;
 			S.hup = h;
-			S.outv = h;
 		}
+		S.outv = S.hup;
 		S.outs = sh;
 		lanebuf[t] = make_uint2((uint32_t)S.outv, S.outs);
 		if ((t & 15) == 15) dirs[(t >> 4) * kLanes] = acc;
@@ -120,9 +117,12 @@ __device__ __forceinline__ void cell_block(CellState &S, uint32_t tab, int32_t l
 
 template <bool WIDE>
 __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
-                                                                    const TileRef *__restrict__ work, int *__restrict__ abort_word)
+                                                                    const TileRef *__restrict__ work, uint32_t epoch,
+                                                                    int *__restrict__ abort_word)
 {
-	__shared__ __attribute__((aligned(16))) uint2 ring[kCellWaves][kRingSteps];
+	/* the ring is mirrored: a block written to slots [0, 64) is also written to [256, 320), so that the 32
+	 * consecutive slots a consumer block needs never wrap and can be read in place (no staging copy) */
+	__shared__ __attribute__((aligned(16))) uint2 ring[kCellWaves][kRingSteps + 2 * kCellBlock];
 	__shared__ __attribute__((aligned(16))) uint2 inject[kCellWaves][kCellBlock];
 	__shared__ uint2 scrap[kCellWaves][kLanes + kCellBlock];   /* lane l, step t -> slot l + t: conflict-free */
 	__shared__ int made[kCellWaves], taken[kCellWaves];
@@ -146,13 +146,14 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	const int32_t *top = reinterpret_cast<const int32_t *>(arena + J.top);
 	const uint8_t *rsh = arena + J.rowshift;
 	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + (size_t)s * (J.steps_pad / 16) * kLanes + lane;
-	uint2 *hand_out = reinterpret_cast<uint2 *>(arena + J.hand) + (size_t)chunk * J.steps_pad;
-	const uint2 *hand_in = reinterpret_cast<const uint2 *>(arena + J.hand) + (size_t)(chunk > 0 ? chunk - 1 : 0) * J.steps_pad;
-	int *progress = reinterpret_cast<int *>(arena + J.progress);
+	unsigned long long *hand_out = reinterpret_cast<unsigned long long *>(arena + J.hand) + (size_t)chunk * J.steps_pad;
+	const unsigned long long *hand_in =
+	    reinterpret_cast<const unsigned long long *>(arena + J.hand) + (size_t)(chunk > 0 ? chunk - 1 : 0) * J.steps_pad;
 	const bool feeds = wv + 1 < kCellWaves && s + 1 < J.nstrips;        /* a wave of this workgroup reads my ring */
 	const bool publishes = wv + 1 == kCellWaves && s + 1 < J.nstrips;   /* the next chunk reads my hand-off words  */
 	const bool first_strip = s == 0;
 	const bool from_chunk = wv == 0 && chunk > 0;
+	const int t = lane & 31;
 
 	CellState S;
 	S.hup = top[col + 1];
@@ -162,57 +163,75 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	/* row letters of the job's first strip, fetched two blocks ahead (lane t: row 32b + t + 1) */
 	uint32_t let0 = 0, let1 = 0;
 	if (first_strip) {
-		let0 = rsh[lane & 31];
-		let1 = rsh[kCellBlock + (lane & 31)];
+		let0 = rsh[t];
+		let1 = rsh[kCellBlock + t];
 	}
+	/* Hand-off words from the previous chunk: 8-byte granules {X, letter offset | epoch << 8}, each written by
+	 * ONE write-through store and valid exactly when it carries this launch's epoch -- no counter, no fence,
+	 * one memory round trip, and that one is hidden: the granules of block b + 1 are requested while block b
+	 * is computed and only re-read (bounded) if they had not arrived. */
+	unsigned long long pre = 0;
+	if (from_chunk && 63 + t < J.steps_pad) pre = __hip_atomic_load(hand_in + 63 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	for (int b = 0; b < nb; ++b) {
-		/* what enters lane 0 during this block: lane t prepares step t */
-		uint2 word = make_uint2(0u, 0u);
-		const int t = lane & 31;
 		const int ps = b * kCellBlock + 63 + t;                 /* the producer's lane 63 is 63 steps ahead */
-		const int need = (b + 3 < nb) ? b + 3 : nb;
+		const uint2 *src = inject[wv];                          /* where lane 0's inputs of this block are read from */
 		if (first_strip) {
+			uint2 word;
 			word.x = (uint32_t)(J.leftmul * (b * kCellBlock + t + 1));      /* border column: X[r][0] = leftmul * r */
 			word.y = let0;
 			let0 = let1;
 			let1 = rsh[(b + 2) * kCellBlock + t];                             /* rowshift is padded by 64 bytes */
+			if (lane < kCellBlock) inject[wv][lane] = word;
 		} else if (wv > 0) {
+			const int need = (b + 3 < nb) ? b + 3 : nb;             /* producer steps up to 32b + 94 */
 			if (!wait_lds(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps];
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		} else if (from_chunk) {
-			if (!wait_hbm(&progress[chunk - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			if (ps < J.steps_pad) {
-				const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(hand_in + ps), __ATOMIC_RELAXED,
-				                                               __HIP_MEMORY_SCOPE_AGENT);
-				word = make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+			src = &ring[wv - 1][(b * kCellBlock + 63) % kRingSteps];   /* 32 consecutive slots thanks to the mirror */
+		} else {
+			unsigned long long v = pre;
+			int spins = 0;
+			for (;;) {
+				const bool ok = ps >= J.steps_pad || (uint32_t)(v >> 40) == epoch;
+				if (__all(ok)) break;
+				__builtin_amdgcn_s_sleep(2);
+				if (++spins > kSpinMax) { if (lane == 0) atomicExch(abort_word, 1); return; }
+				if (!ok) v = __hip_atomic_load(hand_in + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
+			if (ps + kCellBlock < J.steps_pad) pre = __hip_atomic_load(hand_in + ps + kCellBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (lane < kCellBlock) inject[wv][lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xffu);
 		}
-		if (lane < kCellBlock) inject[wv][lane] = word;
 		const bool ringer = lane == kLanes - 1 && (feeds || publishes);
 		uint2 *lanebuf = ringer ? &ring[wv][(b * kCellBlock) % kRingSteps] : &scrap[wv][lane];
 		if (feeds) {
-			/* the ring slots of this block last held block b - kRing, which the consumer reads while
-			 * preparing its blocks b - kRing - 2 and b - kRing - 1 */
+			/* the ring slots of this block last held block b - kRing, which the consumer reads during its
+			 * blocks b - kRing - 2 and b - kRing - 1 */
 			if (!wait_lds(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
 		uint32_t *d = dirs + (size_t)b * (kCellBlock / 16) * kLanes;
-		if (b < 2) cell_block<WIDE, true>(S, tab, leftc, inject[wv], lanebuf, d, b * kCellBlock, lane);
-		else cell_block<WIDE, false>(S, tab, leftc, inject[wv], lanebuf, d, b * kCellBlock, lane);
+		if (b < 2) cell_block<WIDE, true>(S, tab, leftc, src, lanebuf, d, b * kCellBlock, lane);
+		else cell_block<WIDE, false>(S, tab, leftc, src, lanebuf, d, b * kCellBlock, lane);
+		if (wv > 0 && !first_strip && lane == 0)                /* this block's ring words are in registers (cell_block waits) */
+			__hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (feeds || publishes) {
+			if ((b * kCellBlock) % kRingSteps < 2 * kCellBlock) {  /* mirror the ring's first two blocks behind its end */
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				if (lane < kCellBlock) {
+					const int at = (b * kCellBlock) % kRingSteps + lane;
+					ring[wv][kRingSteps + at] = ring[wv][at];
+				}
+			}
+		}
 		if (feeds) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* this block's ring stores have been executed */
+			if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		if (publishes) {
-			/* this block's 32 hand-off words: LDS -> HBM with agent-scope stores, drained, then the counter */
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			if (lane < kCellBlock) {
-				const uint2 v = ring[wv][(b * kCellBlock + lane) % kRingSteps];
-				__hip_atomic_store(reinterpret_cast<unsigned long long *>(hand_out + b * kCellBlock + lane),
-				                   (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint2 v = ring[wv][(b * kCellBlock) % kRingSteps + lane];
+				__hip_atomic_store(hand_out + b * kCellBlock + lane,
+				                   (unsigned long long)v.x | ((unsigned long long)((v.y & 0xffu) | (epoch << 8)) << 32), __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
 			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (lane == 0) __hip_atomic_store(&progress[chunk], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }
@@ -267,29 +286,37 @@ __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ 
 		}
 		__syncthreads();
 		if (wave == 0) {
+			/* lane b < kTbStrips keeps wlo[b] in a register: the 64 cells of an iteration touch at most two
+			 * strips, whose window origins are fetched with v_readlane instead of a second LDS round trip */
+			const int wreg = lane < kTbStrips ? wlo[lane] : 0;
 			for (;;) {
 				const int ri = j - lane, ki = k - lane;
+				const int Bk = s0 - ((k - 1) >> 6);             /* strip block of lane 0's cell (wave-uniform) */
+				if (Bk >= kTbStrips) break;
+				const int wloA = __builtin_amdgcn_readlane(wreg, Bk);
+				const int wloB = __builtin_amdgcn_readlane(wreg, Bk + 1 < kTbStrips ? Bk + 1 : Bk);
 				uint32_t code = 3;                              /* 3 = stop: border or outside the window */
 				if (ri > 0 && ki > 0) {
 					const int sc = (ki - 1) >> 6;
 					const int B = s0 - sc;
 					if (B < kTbStrips) {
 						const int l = ri + ki - 2 - 64 * sc;
-						const int u = (l >> 4) - wlo[B];
+						const int u = (l >> 4) - (B == Bk ? wloA : wloB);
 						if (u >= 0 && u < kTbWords) code = (win[(B * kTbWords + u) * kLanes + ((ki - 1) & 63)] >> (2 * (l & 15))) & 3u;
 					}
 				}
+				/* a run of 'D' and the gap move that ends it are taken in ONE iteration */
 				const unsigned long long stop = __ballot(code != DIR_D);
 				const int run = stop ? __builtin_ctzll(stop) : kLanes;
-				if (run > 0) {
-					if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
-					n += run;
-					j -= run;
-					k -= run;
+				const uint32_t c0 = run < kLanes ? (uint32_t)__builtin_amdgcn_readlane((int)code, run) : 3u;
+				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+				n += run;
+				j -= run;
+				k -= run;
+				if (c0 == 3) {
+					if (run == 0) break;                        /* border reached or window left: the outer loop decides */
 					continue;
 				}
-				const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
-				if (c0 == 3) break;
 				if (lane == 0) ops[n] = (uint8_t)c0;
 				++n;
 				if (c0 == DIR_L) --k; else --j;
@@ -314,11 +341,13 @@ __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ 
 	}
 }
 
-hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, int *abort_word, hipStream_t st)
+hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,
+                             hipStream_t st)
 {
 	if (nwork <= 0) return hipSuccess;
-	if (wide) hipLaunchKernelGGL(nw_fill_cells<true>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, abort_word);
-	else hipLaunchKernelGGL(nw_fill_cells<false>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, abort_word);
+	epoch &= 0xffffffu;                                /* 24 bits travel in a granule */
+	if (wide) hipLaunchKernelGGL(nw_fill_cells<true>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, epoch, abort_word);
+	else hipLaunchKernelGGL(nw_fill_cells<false>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, epoch, abort_word);
 	return hipGetLastError();
 }
 

@@ -99,6 +99,14 @@ void Engine::shutdown_all()
 	g_primary = nullptr;
 }
 
+uint32_t Engine::next_epoch()
+{
+	static std::atomic<uint32_t> counter{0};
+	uint32_t e;
+	do e = (counter.fetch_add(1) + 1) & 0xffffffu; while (e == 0);
+	return e;
+}
+
 int Engine::bind() const
 {
 	HIP_TRY(hipSetDevice(device_));
@@ -566,9 +574,14 @@ int FillBatch::layout_cells()
 			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
 			C.dirs = off;
 			off = align_up(off + (size_t)C.nstrips * (C.steps_pad / 16) * kLanes * 4, 256);
-			C.hand = off;
-			off = align_up(off + (size_t)C.nchunks * C.steps_pad * 8, 256);
 		}
+		hand_off_[sl] = off;                          /* the hand-off granules of all jobs, contiguous: zeroed by upload() */
+		for (int j = 0; j < nj; ++j) {
+			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
+			C.hand = off;
+			off = align_up(off + (size_t)std::max(C.nchunks - 1, 0) * C.steps_pad * 8, 256);
+		}
+		hand_bytes_ = off - hand_off_[sl];
 	}
 	total_bytes_ = off;
 	const int rc = finish_layout();
@@ -1065,6 +1078,8 @@ int FillBatch::upload()
 {
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!laid_out_) return CSADP_ERR_STATE;
+	if (cells_mode_ && hand_bytes_ > 0)
+		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, E_->stream(0)));
 	/* every slot's stream must see the inputs: copy on slot 0 and wait (upload is not on the
 	 * timed path; run() calls may follow on any stream) */
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, E_->stream(0)));
@@ -1235,13 +1250,16 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	int *abort_word = reinterpret_cast<int *>(arena_ + abort_off_);
 	if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));
 	HIP_TRY(hipEventRecord(ev[0], st));
-	if (flags_bytes_ > 0) HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
+	/* the hand-off granules between chunks are valid when they carry this pass' epoch: unique per process,
+	 * and the hand regions are zeroed when a batch is laid out (epoch 0 is never used), so whatever an
+	 * earlier pass or an earlier owner of the arena left there is never mistaken for this pass' data */
+	const uint32_t epoch = E_->next_epoch();
 	if (!serial) {
-		HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), abort_word, st));
+		HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st));
 	} else {
 		for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
 			HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
-			                          (int)(chunk_first_[c + 1] - chunk_first_[c]), abort_word, st));
+			                          (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 	}
 	HIP_TRY(hipEventRecord(ev[1], st));
 	HIP_TRY(launch_traceback_cells(arena_, cj, (int)cjobs_.size(), st));

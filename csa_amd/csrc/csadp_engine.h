@@ -37,6 +37,8 @@ public:
 	static void shutdown_all();
 	int bind() const;                /* hipSetDevice(device_) on the calling thread */
 	int rotate_stream() { return stream_rr_.fetch_add(1); }
+	/* 1, 2, ... (never 0 modulo 2^24 within 16 M passes): tags of the hand-off granules of nw_fill_cells */
+	static uint32_t next_epoch();
 	bool ready() const { return ready_; }
 	static constexpr int kMaxSlots = 16;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
@@ -175,6 +177,7 @@ private:
 	int run_slot_cells(int sl, bool serial);
 	std::vector<CellJob> cjobs_;
 	bool cells_mode_ = false;
+	size_t hand_off_[Engine::kMaxSlots] = {}, hand_bytes_ = 0;
 	int flush_bits(int k);
 	int launch_bits_pass(int first, int g, hipStream_t st, bool serial);
 	int check_abort();

@@ -39,7 +39,9 @@ hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, 
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
 hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st);
 /* csadp_cells.hip: any fill as a persistent cell-per-lane wavefront; work = (job, chunk) items */
-hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, int *abort_word, hipStream_t st);
+/* epoch: a value no earlier launch on this memory has used (24 bits): it tags the hand-off granules between chunks */
+hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,
+                             hipStream_t st);
 hipError_t launch_traceback_cells(uint8_t *arena, const CellJob *jobs, int njobs, hipStream_t st);
 /* csadp_pairio.hip: 2-sequence tasks whose letters live in the arena (BitJob::text): bit planes from
  * the raw circular texts, and the two aligned rows + the DP score from the traceback's op list */

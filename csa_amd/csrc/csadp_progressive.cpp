@@ -8,6 +8,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
+#include <stdio.h>
 
 #include "csadp_device.h"
 
@@ -357,7 +359,18 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 	cells_ += (long long)nrows * (long long)ncols;
 	++fills_;
 	tokens_.push_back('.');                                 /* :1156 */
-	if (i > 1) delete_gapped_columns(i + 1, (i + 1) / 2);   /* :1157 */
+	if (i > 1) {
+		static const bool trace = getenv("CSADP_TRACE_HOST") != nullptr;
+		if (trace) {
+			const auto t0 = std::chrono::steady_clock::now();
+			delete_gapped_columns(i + 1, (i + 1) / 2);
+			dgc_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+			if (step_ + 1 == nseq_ && cells_ > 100000000)
+				fprintf(stderr, "csadp task: %d sequences, %lld cells: DeleteGappedColumns %.2f ms in total\n", nseq_, cells_, dgc_ms_);
+		} else {
+			delete_gapped_columns(i + 1, (i + 1) / 2);   /* :1157 */
+		}
+	}
 	++step_;
 	pending_ = false;
 	return CSADP_OK;
@@ -378,7 +391,30 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		std::vector<int> best;        /* bestworkingsv, maxaffected x 5                    */
 		int maxaffected = 0;
 	};
-	auto SV = [&](int col, int sym) -> int & { return sv_[(size_t)col * kSym + sym]; };
+	/*
+	 * Storage during the pass: a gap buffer.  The reference deletes a run of all-gap columns by moving
+	 * every later column of the profile and of every string down (:865-887), O(consensus x numseqs) per
+	 * deletion -- the 19-sequence example set spends more time there than in its 20 000 x 17 000 fills
+	 * on the GPU.  Here logical column j lives at physical index j for j <= split and at j + gap behind
+	 * it; a deletion moves the split to the run (the scan only moves forward, so those moves add up to
+	 * one pass over the columns) and widens the gap.  The logical content after every operation is the
+	 * reference's; the arrays are compacted once at the end.
+	 */
+	int split = consensus_, gap = 0;
+	auto phys = [&](int j) { return j <= split ? j : j + gap; };
+	auto SV = [&](int col, int sym) -> int & { return sv_[(size_t)phys(col) * kSym + sym]; };
+	auto CH = [&](int seq, int col) -> char & { return str_[seq][(size_t)phys(col) - 1]; };
+	auto move_split = [&](int to) {                 /* make logical columns 1..to the left segment */
+		if (gap == 0) { split = to; return; }
+		for (; split > to; --split) {               /* column `split` joins the right segment */
+			memcpy(&sv_[(size_t)(split + gap) * kSym], &sv_[(size_t)split * kSym], kSym * sizeof(int));
+			for (int t = 0; t < numseqs; ++t) { std::string &r = str_[order_[t]]; r[(size_t)split + gap - 1] = r[(size_t)split - 1]; }
+		}
+		for (; split < to; ++split) {               /* column split + 1 joins the left segment */
+			memcpy(&sv_[(size_t)(split + 1) * kSym], &sv_[(size_t)(split + 1 + gap) * kSym], kSym * sizeof(int));
+			for (int t = 0; t < numseqs; ++t) { std::string &r = str_[order_[t]]; r[(size_t)split] = r[(size_t)split + gap]; }
+		}
+	};
 	const int mingaps = numseqs - maxnongaps;
 	std::vector<int> movers;          /* seqstoshift */
 	std::vector<int> block, nextgaps, affected, statv, movv, workv;
@@ -386,10 +422,14 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 
 	for (int col = 1; col <= consensus_; ++col) {
 		if (SV(col, kGap) < mingaps) continue;                       /* :678 */
+		/* the split follows the scan: everything at or right of `col` is in the right segment (physical
+		 * index + gap), everything left of it in the left one, so each direction below reads its side
+		 * with ONE fixed offset instead of a comparison per access */
+		move_split(col - 1);
 		movers.clear();
 		for (int t = 0; t < numseqs; ++t) {
 			const int s = order_[t];
-			if (str_[s][col - 1] != '-') movers.push_back(s);
+			if (CH(s, col) != '-') movers.push_back(s);
 		}
 		const int nmov = (int)movers.size();
 		if (nmov == 0) { tokens_.push_back('!'); continue; }          /* :688-690 */
@@ -401,15 +441,17 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			const int limit = (dir > 0) ? consensus_ + 1 : 0;
 			int farthest = 0, minnext = consensus_;
 			bool blocked = false;
+			move_split(dir > 0 ? col - 1 : col);                      /* all of this direction's columns on one side */
+			const int off = dir > 0 ? gap : 0;
 			for (int t = 0; t < nmov; ++t) {                          /* :699-715 */
-				const std::string &row = str_[movers[t]];
+				const char *row = str_[movers[t]].data() + off - 1;   /* row[j] = logical column j on this side */
 				int j = col;
 				block[t] = 0;
-				while (j != limit && row[j - 1] != '-') { block[t]++; j += dir; }
+				while (j != limit && row[j] != '-') { block[t]++; j += dir; }
 				if (j == limit) { blocked = true; break; }
 				farthest = std::max(farthest, block[t]);
 				nextgaps[t] = 0;
-				while (j != limit && row[j - 1] == '-') { nextgaps[t]++; j += dir; }
+				while (j != limit && row[j] == '-') { nextgaps[t]++; j += dir; }
 				minnext = std::min(minnext, nextgaps[t]);
 			}
 			if (blocked) continue;                                    /* :716-721 */
@@ -421,10 +463,11 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			int current = 0;
 			for (int j = 0; j < maxaff; ++j) {                        /* :739-761 */
 				const int jj = col + dir * j;
-				for (int y = 0; y < kSym; ++y) statv[(size_t)j * kSym + y] = SV(jj, y);
+				const int *svjj = &sv_[(size_t)(jj + off) * kSym];
+				for (int y = 0; y < kSym; ++y) statv[(size_t)j * kSym + y] = svjj[y];
 				for (int t = 0; t < nmov; ++t) {
 					if (j < affected[t]) {
-						const int c = code_of(str_[movers[t]][jj - 1]);
+						const int c = code_of(str_[movers[t]][(size_t)(jj + off) - 1]);
 						movv[(size_t)j * kSym + c]++;
 						statv[(size_t)j * kSym + c]--;
 					}
@@ -433,11 +476,11 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 				for (int y = 0; y < kGap; ++y) {
 					const int mv = movv[(size_t)j * kSym + y];
 					if (mv != 0)
-						colscore += mv * (kMatch * (SV(jj, y) - 1) + kMismatch * (numseqs - (SV(jj, y) + SV(jj, kGap)))
-						                  + kIndel * SV(jj, kGap));
+						colscore += mv * (kMatch * (svjj[y] - 1) + kMismatch * (numseqs - (svjj[y] + svjj[kGap]))
+						                  + kIndel * svjj[kGap]);
 				}
 				const int mg = movv[(size_t)j * kSym + kGap];
-				if (mg != 0) colscore += mg * (kDoubleGap * (SV(jj, kGap) - 1) + kIndel * (numseqs - SV(jj, kGap)));
+				if (mg != 0) colscore += mg * (kDoubleGap * (svjj[kGap] - 1) + kIndel * (numseqs - svjj[kGap]));
 				current += colscore;
 			}
 			for (int sh = 1; sh <= minnext; ++sh) {                   /* :762-795 */
@@ -497,10 +540,10 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		for (int j = 0; j < keep.maxaffected; ++j)                    /* :837-840 */
 			for (int y = 0; y < kSym; ++y) SV(col + dir * j, y) = keep.best[(size_t)j * kSym + y];
 		for (int t = 0; t < nmov; ++t) {                              /* :841-852 */
-			std::string &row = str_[movers[t]];
+			const int sq = movers[t];
 			for (int j = keep.affected[t] - 1; j >= 0; --j) {
 				const int c = col + dir * j;
-				row[c - 1] = (j < sh) ? '-' : row[c - dir * sh - 1];
+				CH(sq, c) = (j < sh) ? '-' : CH(sq, c - dir * sh);
 			}
 		}
 		int right = 0, left = 0;                                      /* :853-864 */
@@ -508,12 +551,21 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		for (int j = col - 1; j >= 1; --j) { if (SV(j, kGap) != numseqs) break; ++left; }
 		const int drop = right + left;
 		if (drop > 0) {                                               /* :865-887 */
-			const int from = col - left;
-			sv_.erase(sv_.begin() + (size_t)from * kSym, sv_.begin() + (size_t)(from + drop) * kSym);
-			for (int t = 0; t < numseqs; ++t) str_[order_[t]].erase((size_t)(from - 1), (size_t)drop);
+			move_split(col - left - 1);                               /* the run becomes the head of the right segment */
+			gap += drop;
 			consensus_ -= drop;
 		}
 		col -= left + 1;                                              /* :888 */
+	}
+	if (gap > 0) {                                                    /* compact: the right segment moves down by `gap` */
+		const size_t from = (size_t)split + 1 + gap, count = (size_t)consensus_ - split;
+		memmove(&sv_[((size_t)split + 1) * kSym], &sv_[from * kSym], count * kSym * sizeof(int));
+		sv_.resize((size_t)(consensus_ + 1) * kSym);
+		for (int t = 0; t < numseqs; ++t) {
+			std::string &r = str_[order_[t]];
+			memmove(&r[(size_t)split], &r[from - 1], count);
+			r.resize((size_t)consensus_);
+		}
 	}
 }
 

@@ -98,6 +98,7 @@ private:
 	int last_score_ = 0;
 	long long cells_ = 0;
 	int fills_ = 0;
+	double dgc_ms_ = 0;                          /* CSADP_TRACE_HOST: time spent in delete_gapped_columns */
 	std::string tokens_;                         /* '.' per fill (:1156), '!' per all-gap column met (:689) */
 };
 
