@@ -280,8 +280,7 @@ def main():
     tm_pipe = batch.timing()                     # HIP events of the launch that held the LAST timed pass
     # one FULL launch alone (nothing else in flight): the bit-parallel path merges up to
     # `passes_per_launch` consecutive passes into one launch, whatever --steps is
-    full_group = int(os.environ.get("CSADP_BITS_GROUP", "0")) or max(1, min(4, -(-2 * csa_amd.device_info()[1] // max(len(tasks), 1))))
-    for _ in range(full_group):
+    for _ in range(max(tm_pipe["merge_group"], 1)):
         batch.run()
     sync()
     tm = batch.timing()

@@ -70,7 +70,7 @@ class Timing(ctypes.Structure):
                 ("traceback_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("dir_bytes", ctypes.c_longlong), ("border_bytes", ctypes.c_longlong),
                 ("launch_passes", ctypes.c_int), ("bit_parallel", ctypes.c_int),
-                ("recoveries", ctypes.c_int), ("device_io", ctypes.c_int)]
+                ("merge_group", ctypes.c_int), ("recoveries", ctypes.c_int), ("device_io", ctypes.c_int)]
 
 
 # symbols declared in include/csadp.h and include/csadp_debug.h
@@ -83,7 +83,7 @@ EXPORTS = [
     "csadp_partition_lpt", "csadp_fnv1a", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
     "csadp_build_anchor_map", "csadp_free_anchor_map", "csadp_msa", "csadp_free_rows", "csadp_write_aligned_fasta",
-    "csadp_debug_align_with_filler",
+    "csadp_debug_align_with_filler", "csadp_debug_pool_selftest",
 ]
 
 DEBUG_FILL_FN = ctypes.CFUNCTYPE(

@@ -264,7 +264,9 @@ struct csadp_pairbatch {
 	std::vector<PairGeom> geom;
 };
 
+extern "C" {
 static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntasks, bool pipelined, bool strings);
+}
 
 namespace {
 
@@ -748,6 +750,15 @@ int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out)
 	if (d_chars) (void)hipFree(d_chars);
 	if (d_out) (void)hipFree(d_out);
 	return rc;
+}
+
+int csadp_debug_pool_selftest(int items, long long *sum)
+{
+	if (items < 0 || !sum) return CSADP_ERR_ARG;
+	std::atomic<long long> acc(0);
+	parallel_for(items, [&](int i) { acc.fetch_add(i, std::memory_order_relaxed); });
+	*sum = acc.load();
+	return CSADP_OK;
 }
 
 /* ---- test seam: run the HOST logic of one task with a caller-supplied matrix filler ------- */

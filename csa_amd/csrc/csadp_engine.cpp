@@ -839,16 +839,18 @@ int FillBatch::layout_bits()
 		for (const BitJob &B : bjobs_)
 			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 * kBitCkptWords + (long long)B.nstrips * B.steps_pad * 16;
 	}
-	/* A job is one workgroup of up to 16 waves and 128 VGPR-limited workgroups fill half of the
-	 * chip, so consecutive passes are MERGED: `group` passes (slots) form one launch of
-	 * group * nj workgroups, aiming at two workgroups per compute unit, and two such groups are
-	 * kept in flight on 2-3 streams so that the tail and the traceback of one overlap the next. */
+	/* A job is one workgroup of up to 16 waves, and 128 jobs fill half of the chip's compute units, so
+	 * consecutive passes are MERGED: `group` passes (slots) form one launch of group * nj workgroups, aiming at
+	 * ONE workgroup per compute unit, and three such launches are kept in flight on three streams so that the
+	 * tail and the traceback of one overlap the next.  Measured on the bench batch (tools/sweep_groups.sh,
+	 * ms per pass sustained): 1 x 3: 1.53-1.65, 2 x 3: 0.952-0.958, 4 x 3: 0.966-1.014, 8 x 3: 0.952-0.960 --
+	 * two workgroups of one launch on a compute unit gain less than two launches sharing it. */
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
 	bits_group_ = 1;
 	nslots_ = 1;
 	if (pipelined_) {
-		const int want = 2 * std::max(E.compute_units(), 1);
+		const int want = std::max(E.compute_units(), 1);
 		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
 		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
 		/* launches in flight: 2 with direction planes in HBM (8.6 GB per bench pass), 3 in
@@ -1368,6 +1370,7 @@ int FillBatch::timing(csadp_timing *t)
 	HIP_TRY(hipEventElapsedTime(&t->traceback_ms, ev[1], ev[2]));
 	HIP_TRY(hipEventElapsedTime(&t->total_ms, ev[0], ev[2]));
 	t->launch_passes = bits_ ? last_group_ : 1;
+	t->merge_group = bits_ ? bits_group_ : 1;
 	t->recoveries = recoveries_;
 	t->device_io = io_ ? 1 : 0;
 	t->bit_parallel = bits_ ? (bits_ckpt_ ? 2 : 1) : 0;

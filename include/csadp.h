@@ -188,6 +188,7 @@ typedef struct csadp_timing {
 	int bit_parallel;       /* 0 = tiled kernels, 1 = bit-parallel kernels (nw_fill_bits) with  */
 	                        /* direction planes in HBM, 2 = bit-parallel with checkpoints and    */
 	                        /* replay traceback (default)                                        */
+	int merge_group;        /* passes a full launch of this batch carries (bit-parallel path)     */
 	int recoveries;         /* passes repeated on the wait-free path after a bounded wait of the  */
 	                        /* chunked fill ran out (0 in any healthy run)                        */
 	int device_io;          /* 1 = a pass starts from the raw letters in HBM and ends with the    */

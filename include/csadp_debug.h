@@ -32,6 +32,12 @@ typedef int (*csadp_debug_fill_fn)(void *user, int nrows, int ncols, int nprev, 
 CSADP_API int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fill, void *user,
                                   csadp_result *result);
 
+/* Runs one parallel region of the library's persistent host thread pool (the one that spreads per-task
+ * host work: table packing, traceback application, result strings) over `items` work items, each adding
+ * its index to an atomic; *sum receives items*(items-1)/2.  For the thread-sanitizer build: callable from
+ * several threads at once. */
+CSADP_API int csadp_debug_pool_selftest(int items, long long *sum);
+
 #ifdef __cplusplus
 }
 #endif
