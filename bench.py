@@ -316,7 +316,7 @@ def main():
         rank_cells = tm["cells"]
         launch_cells = lp * rank_cells
         fill_s = tm["fill_ms"] * 1e-3
-        achieved_tops = BITS_VALU_PER_CELL * launch_cells / fill_s / 1e12           # lane operations per second
+        alone_tops = BITS_VALU_PER_CELL * launch_cells / fill_s / 1e12               # lane operations per second
         sustained_tops = BITS_VALU_PER_CELL * rank_cells * args.steps / elapsed / 1e12
         calibrated_peak_gcups = 256 * 4 * 64 / BITS_CYCLES_PER_64_CELLS * 2.4
         pmc = pmc_summary("nw_fill_bits")
@@ -350,14 +350,20 @@ def main():
                                       "fetch = one D2H + result strings (Python unpacking included here; the C-ABI "
                                       "figure is streaming.ms_per_batch)"},
             "roofline": {"bound": "valu-issue", "kernel": "nw_fill_bits",
-                         "achieved": round(achieved_tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "TOP/s",
-                         "frac": round(achieved_tops / VALU_PEAK_TOPS, 4),
+                         "achieved": round(sustained_tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "TOP/s",
+                         "frac": round(sustained_tops / VALU_PEAK_TOPS, 4),
                          "traffic": traffic,
-                         "what": "integer VALU lane-operations: %.0f wave64 VALU instructions per 2048 cells (ISA count of the "
-                                 "compiled step) x cells of one launch / its HIP-event duration; peak = 256 CUs x 4 SIMDs x "
-                                 "32 lanes/clk x 2.4 GHz (nominal 2 issue cycles per wave64 instruction)" % (BITS_VALU_PER_CELL * 32),
-                         "cells_per_launch": launch_cells, "avg_launch_us": round(tm["fill_ms"] * 1e3, 1),
-                         "sustained_frac": round(sustained_tops / VALU_PEAK_TOPS, 4),
+                         "what": "integer VALU lane-operations per second of the fill kernel over the timed region: %.0f wave64 "
+                                 "VALU instructions per 2048 cells (ISA count of the compiled step; PMC SQ_INSTS_VALU agrees "
+                                 "within 3 %%) x cells of all timed passes / wall time -- launches of `passes_per_launch` passes "
+                                 "rotate over three streams, so the kernel is in flight during the whole region and its "
+                                 "launches overlap; peak = 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (nominal 2 issue "
+                                 "cycles per wave64 instruction, MI355X_MICROARCH.md)" % (BITS_VALU_PER_CELL * 32),
+                         "one_launch_alone": {"cells": launch_cells, "avg_launch_us": round(tm["fill_ms"] * 1e3, 1),
+                                              "achieved": round(alone_tops, 2), "frac": round(alone_tops / VALU_PEAK_TOPS, 4),
+                                              "what": "HIP events around ONE launch with nothing else in flight (one workgroup "
+                                                      "per compute unit = two waves per SIMD; the timed region keeps three "
+                                                      "such launches in flight); rocprofv3: profiles/r02_bench_kernel_solo.csv"},
                          "calibrated": {"peak_gcups": round(calibrated_peak_gcups, 1),
                                         "frac_alone": round(launch_cells / fill_s / 1e9 / calibrated_peak_gcups, 4),
                                         "frac_sustained": round(value / args.gpus / calibrated_peak_gcups, 4),

@@ -140,3 +140,72 @@ def test_score_pairs_device_scores_on_hard_inputs():
     assert status == [0] * len(tasks)
     assert scores == [g["score"] for g in full]
     assert scores[-6:] == [c["sp"] for c in load_golden("config4_pairs.json")[:6]]
+
+
+# ---- more than one device from one process (csadp_align_batch_on / _multi, csa_pairs --gpus) ------------------
+
+def test_device_ordinals_and_explicit_device():
+    """csadp_device_count; an ordinal that does not exist is CSADP_ERR_NO_DEVICE (never silently another GPU);
+    the batch on an explicitly named device equals the batch on the primary one; with more than one GPU visible
+    the LAST device gives the same bytes as device 0 (every entry point re-binds its device on the calling
+    thread -- hipSetDevice is per host thread)."""
+    csa_amd.init(device=0)
+    n = csa_amd.device_count()
+    assert n >= 1
+    r = rng(31)
+    tasks = []
+    for k, length in [(2, 700), (4, 300), (2, 64), (7, 150)]:
+        fam = random_family(r, k, length, mut=0.1, indel=0.05)
+        fam = [f if f else b"A" for f in fam]
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    base = csa_amd.align_batch(tasks)
+    assert all(b["status"] == 0 for b in base)
+    with pytest.raises(csa_amd.CsadpError) as e:
+        csa_amd.align_batch_on(n, tasks)
+    assert e.value.code == csa_amd.ERR_NO_DEVICE
+    for dev in sorted({0, n - 1}):
+        got = csa_amd.align_batch_on(dev, tasks)
+        assert [g["aligned"] for g in got] == [b["aligned"] for b in base]
+        assert [g["score"] for g in got] == [b["score"] for b in base]
+
+
+def test_align_batch_multi_equals_single_device():
+    """csadp_align_batch_multi: LPT partition + one host thread per device + results in task order.  On a one-GPU
+    box both threads drive device 0 (two batches on one engine at once: pools, streams, the host thread pool);
+    with several GPUs visible every device takes a part.  Results must equal the single-call results."""
+    csa_amd.init(device=0)
+    n = csa_amd.device_count()
+    r = rng(77)
+    tasks = []
+    for i in range(24):
+        k = r.choice([2, 2, 2, 3, 5])
+        fam = random_family(r, k, r.choice([40, 300, 900, 2500]), mut=0.1, indel=0.04)
+        fam = [f if f else b"C" for f in fam]
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    base = csa_amd.align_batch(tasks)
+    devices = list(range(n)) if n > 1 else [0, 0]
+    got, st = csa_amd.align_batch_multi(tasks, devices)
+    assert [g["aligned"] for g in got] == [b["aligned"] for b in base]
+    assert [g["score"] for g in got] == [b["score"] for b in base]
+    assert st["ndevices"] == len(devices) and sum(st["tasks"]) == len(tasks)
+    assert sum(st["cost"]) == st["total_cost"] == sum(csa_amd.task_cost(t) for t in tasks)
+    assert st["max_cost"] == max(st["cost"]) and min(st["tasks"]) >= 1
+
+
+def test_csa_pairs_over_two_devices(monkeypatch):
+    """The C harness with --gpus 2: csadp_align_batch_multi from plain C.  CSADP_SHARE_DEVICE=1 lets the second
+    ordinal fall back onto the one GPU of this box (rehearsal switch); the 66 Mammals pairs must still equal the
+    reference digests and the LPT split must be balanced."""
+    if csa_amd.device_count() < 2:
+        monkeypatch.setenv("CSADP_SHARE_DEVICE", "1")
+    log = _run([os.path.join(GOLDEN, "data", "Mammals.txt"), "--rot", ROT["Mammals"], "--gpus", "2"])
+    gold = {(c["a"], c["b"]): c for c in load_golden("real_pairs.json") if c["set"] == "Mammals"}
+    seen = 0
+    for m in re.finditer(r"pair (\d+) (\d+) len (\d+) SP (-?\d+) score (-?\d+) fnv1a ([0-9a-f]{8})", log):
+        g = gold[(int(m.group(1)), int(m.group(2)))]
+        assert (int(m.group(3)), int(m.group(4)), int(m.group(5)), m.group(6)) == (g["consensus"], g["sp"], g["sp"], g["fnv1a"])
+        seen += 1
+    assert seen == 66
+    m = re.search(r"over 2 GPUs: imbalance ([0-9.]+)", log)
+    assert m and float(m.group(1)) <= 1.05
+    assert log.count("> gpu ") == 2
