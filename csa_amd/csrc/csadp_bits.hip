@@ -312,46 +312,48 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 }
 
 /*
- * K1b for jobs wider than one workgroup (more than 16 strips; checkpoint mode only): the same
- * step function, one workgroup per CHUNK of 16 strips, all chunks of a job in flight at once.
- * The first strip of chunk c reads the hand-off words recorded by the last strip of chunk c-1
- * (stream 3 of its marks, in HBM) and follows that strip's published block counter
- * (BitJob::progress, agent scope) at the usual distance of three blocks.  The work list puts a
- * job's chunks in ascending order and workgroups are dispatched in linear order, so the chunk a
- * workgroup waits for is resident or done; the waits are bounded all the same.  The list starts
- * with the longest jobs (the critical path of a mixed batch), and the launch reserves enough LDS
- * for ONE workgroup per compute unit: 4 instead of 8 waves per SIMD halve a step's latency at the
- * same VALU throughput.  Kept apart from nw_fill_bits, whose common case would pay
- * for the extra cases (7 % measured).
+ * K1b for jobs that do not run as ONE workgroup (checkpoint mode only): the same step function, one
+ * workgroup per CHUNK of WAVES strips, all chunks of a job in flight at once.  Two uses: jobs wider than
+ * 16 strips (WAVES = 16), and small batches of large jobs -- a single 16 kbp pair, the first fill of a
+ * whole-genome profile alignment, config 5's 200 kbp pairs -- whose strips are spread over compute
+ * units at ONE wave per SIMD (WAVES = 4) or two (WAVES = 8) instead of sharing one unit's SIMDs: a step's
+ * latency is what bounds such a launch.
+ * The first strip of chunk c takes the hand-off words that left the last strip of chunk c-1 from stream 3 of
+ * that strip's marks in HBM.  Only bits 31 / 23 / 15 of those words are ever used (the outgoing planes'
+ * top bits; the row letter comes from the row planes), so the other bits of bytes 1..3 carry the launch's
+ * epoch: a word is valid exactly when it holds this launch's epoch, each is written by one write-through
+ * store, and the consumer requests a block's 32 words one block ahead and re-reads (bounded) only what
+ * had not arrived -- no counter, no fence (MI355X_MICROARCH.md, data-tagged granules; the round-1 form
+ * published a counter behind an agent-scope release per block, which stalls a lone wave for microseconds).
+ * The marks are zeroed when the batch is laid out and epochs are unique per process.  The work list puts
+ * a job's chunks in ascending order, so the chunk a workgroup waits for was dispatched before it -- for
+ * speed only: every wait is bounded, a time-out raises the abort word and the host repeats the pass chunk
+ * by chunk.  The launch reserves enough LDS for ONE workgroup per compute unit.
  */
-__device__ __forceinline__ bool wait_global(const int *counter, int need)
+constexpr uint32_t kMarkPayload = 0x80808000u;            /* bits 31, 23, 15 */
+__device__ __forceinline__ uint32_t mark_tag(uint32_t epoch)   /* 21 bits of epoch into bits 30..24, 22..16, 14..8 */
 {
-	int spins = 0;
-	while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need) {
-		__builtin_amdgcn_s_sleep(8);
-		if (++spins > kSpinMax) return false;
-	}
-	return true;
+	return ((epoch & 0x7fu) << 8) | (((epoch >> 7) & 0x7fu) << 16) | (((epoch >> 14) & 0x7fu) << 24);
 }
 
-__global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8_t *__restrict__ arena,
-                                                                      const BitJob *__restrict__ jobs, int njobs,
-                                                                      const TileRef *__restrict__ work,
-                                                                      int *__restrict__ abort_word)
+template <int WAVES>
+__global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs, int njobs,
+                                                                   const TileRef *__restrict__ work, uint32_t epoch,
+                                                                   int *__restrict__ abort_word)
 {
 	constexpr int OUT = OUT_NONE;
 	constexpr int W = kCkptWords;
-	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
-	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
-	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
-	__shared__ uint32_t scrap[kBitMaxStrips][kLanes + kBitBlock];   /* lane l, step t -> word l + t: 64 different banks per store */
-	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
+	__shared__ uint32_t ring[WAVES][kRingSteps];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[WAVES][kBitBlock];
+	__shared__ uint32_t mbuf[WAVES][3][kBitBlock];
+	__shared__ uint32_t scrap[WAVES][kLanes + kBitBlock];
+	__shared__ int made[WAVES], taken[WAVES];
 	const TileRef item = work[blockIdx.x];                      /* x: the work list of one pass, y: the pass */
 	const BitJob &J = jobs[(size_t)blockIdx.y * njobs + item.job];
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 	const int chunk = item.a;
-	const int s = chunk * kBitMaxStrips + wv;                  /* this wave's strip */
-	if (threadIdx.x < kBitMaxStrips) {
+	const int s = chunk * WAVES + wv;                          /* this wave's strip */
+	if (threadIdx.x < WAVES) {
 		made[threadIdx.x] = 0;
 		taken[threadIdx.x] = 0;
 	}
@@ -367,13 +369,14 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 		B0[h] = cp[(s * kLanes + lane) * W + h];
 		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
 	}
-	const bool feeds = wv + 1 < kBitMaxStrips && s + 1 < J.nstrips;   /* a wave of this workgroup reads my ring */
-	const bool publishes = wv + 1 == kBitMaxStrips && s + 1 < J.nstrips;   /* the next chunk reads my marks */
+	const bool feeds = wv + 1 < WAVES && s + 1 < J.nstrips;          /* a wave of this workgroup reads my ring */
+	const bool publishes = wv + 1 == WAVES && s + 1 < J.nstrips;     /* the next chunk reads my marks */
 	uint32_t *marks = reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad;
 	const bool from_left_chunk = wv == 0 && chunk > 0;
 	const uint32_t *left_marks = from_left_chunk ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
-	int *progress = reinterpret_cast<int *>(arena + J.progress);
 	const bool writes = (lane == kLanes - 1) ? (feeds || publishes) : ((lane & 15) == 15);
+	const uint32_t tag = mark_tag(epoch);
+	constexpr uint32_t kTagMask = ~kMarkPayload & 0xffffff00u;
 
 	BitState<W> S;
 #pragma unroll
@@ -382,6 +385,9 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 		S.H1[h] = S.H2[h] = 0;
 	}
 	S.PP = 0;
+	/* the previous chunk's words for block 0, requested now; inside the loop always one block ahead */
+	uint32_t pre = 0;
+	if (from_left_chunk && 63 + (lane & 31) < J.steps_pad) pre = __hip_atomic_load(&left_marks[63 + (lane & 31)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	for (int b = 0; b < nb; ++b) {
 		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
 		 * the producer's step 32b + t + 63, row letter of row 32b + t */
@@ -394,8 +400,17 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 		} else if (from_left_chunk) {
-			if (!wait_global(&progress[chunk - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			if (ps < J.steps_pad) word = __hip_atomic_load(&left_marks[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 0xffffff00u;
+			uint32_t v = pre;
+			int spins = 0;
+			for (;;) {
+				const bool ok = ps >= J.steps_pad || (v & kTagMask) == tag;
+				if (__all(ok)) break;
+				__builtin_amdgcn_s_sleep(2);
+				if (++spins > kSpinMax) { if (lane == 0) atomicExch(abort_word, 1); return; }
+				if (!ok) v = __hip_atomic_load(&left_marks[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (ps + kBitBlock < J.steps_pad) pre = __hip_atomic_load(&left_marks[ps + kBitBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (ps < J.steps_pad) word = v & kMarkPayload;
 		}
 		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
@@ -412,17 +427,19 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits_wide(uint8
 			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
 			const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
 			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
-			marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
-			    (g == 0) ? mbuf[wv][2][t] : ((feeds || publishes) ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u);
+			if (g == 0) {
+				marks[(size_t)2 * J.steps_pad + b * kBitBlock + t] = mbuf[wv][2][t];
+			} else if (publishes) {                             /* for another compute unit: tagged, written through */
+				const uint32_t v = (ring[wv][(b * kBitBlock + t) % kRingSteps] & kMarkPayload) | tag;
+				__hip_atomic_store(&marks[(size_t)3 * J.steps_pad + b * kBitBlock + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			} else {
+				marks[(size_t)3 * J.steps_pad + b * kBitBlock + t] = feeds ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u;
+			}
 			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
 		if (feeds) {
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-		if (publishes) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     /* the marks above, for another compute unit */
-			if (lane == 0) __hip_atomic_store(&progress[chunk], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 		}
 	}
 }
@@ -537,19 +554,22 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 						if (SCORE) match = (mtile[d][at] & bit) != 0;
 					}
 				}
+				/* a run of 'D' and the gap move that ends it are taken in ONE iteration */
 				const unsigned long long stop = __ballot(code != DIR_D);
 				const int run = stop ? __builtin_ctzll(stop) : kLanes;
-				if (run > 0) {
-					if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+				const uint32_t c0 = run < kLanes ? (uint32_t)__builtin_amdgcn_readlane((int)code, run) : 3u;
+				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+				if (SCORE) {
 					const unsigned long long hits = __ballot(match) & (run == kLanes ? ~0ull : ((1ull << run) - 1));
 					score += 2 * __builtin_popcountll(hits) - run;          /* +1 per match, -1 per mismatch */
-					n += run;
-					r -= run;
-					k -= run;
+				}
+				n += run;
+				r -= run;
+				k -= run;
+				if (c0 == 3) {
+					if (run == 0) break;                            /* border, or outside the replayed pieces */
 					continue;
 				}
-				const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
-				if (c0 == 3) break;
 				if (lane == 0) ops[n] = (uint8_t)c0;
 				++n;
 				--score;                                        /* a gap in either sequence */
@@ -669,13 +689,16 @@ __global__ __launch_bounds__(64) void nw_traceback_bits(uint8_t *__restrict__ ar
 	}
 }
 
-/* 27 KB static + this = more than half of a compute unit's 160 KB: one nw_fill_bits_wide workgroup per unit */
-constexpr size_t kWideReserve = 56 * 1024;
+/* static LDS (8 .. 30 KB) + this = more than half of a compute unit's 160 KB: one nw_fill_bits_wide workgroup per unit */
+constexpr size_t kWideReserve = 76 * 1024;
 
 /* function attributes are per device: called by Engine::init with that device current */
 hipError_t configure_kernels()
 {
-	return hipFuncSetAttribute((const void *)nw_fill_bits_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
+	hipError_t e = hipFuncSetAttribute((const void *)nw_fill_bits_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nw_fill_bits_wide<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
+	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nw_fill_bits_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
+	return e;
 }
 
 hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
@@ -688,11 +711,16 @@ hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int m
 	return hipGetLastError();
 }
 
-hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
-                                 int *abort_word, hipStream_t st)
+hipError_t launch_fill_bits_wide(int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
+                                 uint32_t epoch, int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0 || nwork <= 0 || passes <= 0) return hipSuccess;
-	hipLaunchKernelGGL(nw_fill_bits_wide, dim3(nwork, passes), dim3(kBitMaxStrips * kLanes), kWideReserve, st, arena, jobs, njobs, work, abort_word);
+	epoch &= 0x1fffffu;                                /* 21 bits travel in a mark word */
+	const dim3 grid(nwork, passes);
+	if (waves == 4) hipLaunchKernelGGL(nw_fill_bits_wide<4>, grid, dim3(4 * kLanes), kWideReserve, st, arena, jobs, njobs, work, epoch, abort_word);
+	else if (waves == 8) hipLaunchKernelGGL(nw_fill_bits_wide<8>, grid, dim3(8 * kLanes), kWideReserve, st, arena, jobs, njobs, work, epoch, abort_word);
+	else if (waves == 16) hipLaunchKernelGGL(nw_fill_bits_wide<16>, grid, dim3(16 * kLanes), kWideReserve, st, arena, jobs, njobs, work, epoch, abort_word);
+	else return hipErrorInvalidValue;
 	return hipGetLastError();
 }
 

@@ -824,7 +824,6 @@ int FillBatch::layout_bits()
 		B.steps_pad = (int)align_up((size_t)J.nrows + 64, kBitBlock);
 		B.rowwords = B.steps_pad / 32;
 		bits_maxstrips_ = std::max(bits_maxstrips_, B.nstrips);
-		if (B.nstrips > kBitMaxStrips) bits_wide_ = true;
 		extra_[(size_t)j].ncols_pad = B.nwords_pad * 32;
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)J.nrows * words * 8;
@@ -860,6 +859,26 @@ int FillBatch::layout_bits()
 		bits_streams_ = std::min(bits_streams_, Engine::kMaxSlots / bits_group_);
 		nslots_ = bits_streams_ * bits_group_;
 	}
+	/* How many strips share a workgroup.  A job is normally ONE workgroup (nw_fill_bits, up to 16 strips).  A
+	 * launch with few strips in all -- a single 16 kbp pair, the first fills of a whole-genome profile
+	 * alignment, a 200 kbp pair -- is latency-bound: its strips are spread over compute units, 4 per
+	 * workgroup = one wave per SIMD while the launch fits the chip that way, else 8 (checkpoint mode only:
+	 * the chunks of a job hand over through the marks in HBM). */
+	bits_chunk_ = kBitMaxStrips;
+	if (bits_ckpt_) {
+		long long launch_strips = 0;
+		for (const BitJob &B : bjobs_) launch_strips += B.nstrips;
+		launch_strips *= bits_group_;
+		const long long simds = 4LL * std::max(E.compute_units(), 1);
+		if (launch_strips <= simds) bits_chunk_ = 4;
+		else if (launch_strips <= 2 * simds) bits_chunk_ = 8;
+		const int forced = env_int("CSADP_BITS_CHUNK", 0);
+		if (forced == 4 || forced == 8 || forced == 16) bits_chunk_ = forced;
+	}
+	bits_wide_ = false;
+	for (const BitJob &B : bjobs_)
+		if (B.nstrips > bits_chunk_) bits_wide_ = true;
+	if (!bits_wide_) bits_chunk_ = kBitMaxStrips;
 	next_slot_ = 0;
 	size_t off = 0;
 	for (int sl = 0; sl < nslots_; ++sl) {
@@ -872,7 +891,7 @@ int FillBatch::layout_bits()
 	tiles_off_ = off;
 	chunk_first_.clear();
 	if (bits_wide_) {
-		/* work list of the chunked kernel: (job, chunk of 16 strips), the longest jobs first -- they
+		/* work list of the chunked kernel: (job, chunk of bits_chunk_ strips), the longest jobs first -- they
 		 * are the critical path of a mixed batch -- and a job's chunks in ascending order, so that the
 		 * workgroup a chunk waits for is always dispatched before it */
 		std::vector<int> order((size_t)nj);
@@ -881,7 +900,7 @@ int FillBatch::layout_bits()
 			return (long long)bjobs_[(size_t)a].steps_pad * bjobs_[(size_t)a].nstrips > (long long)bjobs_[(size_t)b].steps_pad * bjobs_[(size_t)b].nstrips;
 		});
 		for (int j : order)
-			for (int c = 0; c * kBitMaxStrips < bjobs_[(size_t)j].nstrips; ++c) {
+			for (int c = 0; c * bits_chunk_ < bjobs_[(size_t)j].nstrips; ++c) {
 				TileRef t;
 				t.job = j;
 				t.a = c;
@@ -976,24 +995,23 @@ int FillBatch::layout_bits()
 				off = align_up(off + (size_t)2 * B.rowwords * 4, 256);
 			}
 		}
-		flags_off_[sl] = off;                     /* abort word | progress counters of wide jobs: zeroed before every launch */
-		off += 256;
+		flags_off_[sl] = off;
+		flags_bytes_ = 0;
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
-			B.progress = off;
-			if (B.nstrips > kBitMaxStrips) off = align_up(off + (size_t)((B.nstrips + kBitMaxStrips - 1) / kBitMaxStrips) * 4, 64);
-		}
-		off = align_up(off, 256);
-		flags_bytes_ = off - flags_off_[sl];
-		for (int j = 0; j < nj; ++j) {
-			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
+			B.progress = 0;
 			B.dirs = off;
 			if (!bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * kLanes * 8, 256);
 			B.ckpt = off;
 			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 * kBitCkptWords, 256);
+		}
+		hand_off_[sl] = off;                      /* the marks of all jobs, contiguous: zeroed by upload() when chunks hand over through them */
+		for (int j = 0; j < nj; ++j) {
+			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
 			B.hand = off;
 			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * 16, 256);
 		}
+		hand_bytes_ = off - hand_off_[sl];
 	}
 	total_bytes_ = off;
 	const int rc = finish_layout();
@@ -1080,7 +1098,7 @@ int FillBatch::upload()
 {
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!laid_out_) return CSADP_ERR_STATE;
-	if (cells_mode_ && hand_bytes_ > 0)
+	if ((cells_mode_ || (bits_ && bits_wide_)) && hand_bytes_ > 0)
 		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, E_->stream(0)));
 	/* every slot's stream must see the inputs: copy on slot 0 and wait (upload is not on the
 	 * timed path; run() calls may follow on any stream) */
@@ -1098,6 +1116,8 @@ int FillBatch::upload_async()
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	const int nst = std::max(E_->slots(), 2);
 	hipStream_t s0 = E_->stream(bits_ ? base_stream_ : 0);
+	if (bits_ && bits_wide_ && hand_bytes_ > 0)
+		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, s0));
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, s0));
 	if (!ev_up_) HIP_TRY(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
 	HIP_TRY(hipEventRecord(ev_up_, s0));
@@ -1173,14 +1193,15 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, bool serial)
 	HIP_TRY(hipEventRecord(ev[0], st));
 	if (io_) HIP_TRY(launch_pack_planes(arena_, bj, g * nj, st));
 	if (bits_wide_) {
-		for (int sl = first; sl < first + g; ++sl)         /* progress counters of the chunked jobs */
-			HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
+		/* hand-off words between the chunks of a job carry this pass' epoch (see nw_fill_bits_wide) */
+		const uint32_t epoch = Engine::next_epoch();
 		if (!serial) {
-			HIP_TRY(launch_fill_bits_wide(arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), abort_word, st));
+			HIP_TRY(launch_fill_bits_wide(bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch,
+			                              abort_word, st));
 		} else {
 			for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
-				HIP_TRY(launch_fill_bits_wide(arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
-				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), abort_word, st));
+				HIP_TRY(launch_fill_bits_wide(bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
+				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 		}
 	} else {
 		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, abort_word, st));

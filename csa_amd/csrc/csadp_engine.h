@@ -192,7 +192,7 @@ private:
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
 	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false, want_scores_ = false;
-	int bits_maxstrips_ = 1;
+	int bits_maxstrips_ = 1, bits_chunk_ = kBitMaxStrips;
 	int run_slot(int sl, bool persistent);
 	std::vector<PairJob> pjobs_;
 	std::vector<PairExtra> pextra_;

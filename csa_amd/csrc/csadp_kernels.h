@@ -31,11 +31,11 @@ hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int n
 /* csadp_bits.hip: bit-parallel first fills, one workgroup per job, and their traceback */
 hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
                             hipStream_t st);
-/* batches with jobs of more than kBitMaxStrips strips (checkpoint mode): one workgroup per work item
- * = (job, chunk of kBitMaxStrips strips); `work` lists the items of ONE pass, `passes` consecutive
- * passes (job tables of njobs entries each) share a launch */
-hipError_t launch_fill_bits_wide(uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
-                                 int *abort_word, hipStream_t st);
+/* chunked form (checkpoint mode): one workgroup per work item = (job, chunk of `waves` strips; 4, 8 or 16); `work`
+ * lists the items of ONE pass, `passes` consecutive passes (job tables of njobs entries each) share a launch;
+ * epoch = a value no earlier launch on this memory has used (21 bits): it tags the hand-off words between chunks */
+hipError_t launch_fill_bits_wide(int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
+                                 uint32_t epoch, int *abort_word, hipStream_t st);
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
 hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st);
 /* csadp_cells.hip: any fill as a persistent cell-per-lane wavefront; work = (job, chunk) items */

@@ -416,6 +416,8 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		}
 	};
 	const int mingaps = numseqs - maxnongaps;
+	struct Run { bool valid; int a, b; bool at, bt; int gl, gr; };
+	std::vector<Run> runs((size_t)nseq_, Run{false, 0, 0, false, false, -1, -1});
 	std::vector<int> movers;          /* seqstoshift */
 	std::vector<int> block, nextgaps, affected, statv, movv, workv;
 	Probe keep;
@@ -444,14 +446,51 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			move_split(dir > 0 ? col - 1 : col);                      /* all of this direction's columns on one side */
 			const int off = dir > 0 ? gap : 0;
 			for (int t = 0; t < nmov; ++t) {                          /* :699-715 */
+				/* The reference walks the residue run of the mover from `col` to its end for every candidate
+				 * column (:700-712); consecutive candidates inside one long run -- e.g. the newest, longest
+				 * sequence over a short gap: 6944 candidates x 6993 letters on the third example set -- re-walk
+				 * the same letters.  What the walk found is remembered per row: the residues known around the
+				 * last candidate, [a, b), whether a / b are the run's true ends, and the lengths of the gap
+				 * runs beyond them; a row's memory is dropped when the row changes, everybody's when columns
+				 * are deleted.  Same block / nextgaps / blocked values, one walk per run instead of one per
+				 * column. */
 				const char *row = str_[movers[t]].data() + off - 1;   /* row[j] = logical column j on this side */
-				int j = col;
-				block[t] = 0;
-				while (j != limit && row[j] != '-') { block[t]++; j += dir; }
-				if (j == limit) { blocked = true; break; }
+				Run &R = runs[(size_t)movers[t]];
+				if (!(R.valid && R.a <= col && col < R.b)) R = Run{true, col, col + 1, false, false, -1, -1};
+				if (dir > 0) {
+					if (!R.bt) {
+						int j = R.b;
+						while (j != limit && row[j] != '-') ++j;
+						R.b = j;
+						R.bt = true;
+						R.gr = -1;
+					}
+					block[t] = R.b - col;
+					if (R.b == limit) { blocked = true; break; }
+					if (R.gr < 0) {
+						int j = R.b, g = 0;
+						while (j != limit && row[j] == '-') { ++g; ++j; }
+						R.gr = g;
+					}
+					nextgaps[t] = R.gr;
+				} else {
+					if (!R.at) {
+						int j = R.a - 1;
+						while (j != limit && row[j] != '-') --j;
+						R.a = j + 1;
+						R.at = true;
+						R.gl = -1;
+					}
+					block[t] = col - R.a + 1;
+					if (R.a - 1 == limit) { blocked = true; break; }
+					if (R.gl < 0) {
+						int j = R.a - 1, g = 0;
+						while (j != limit && row[j] == '-') { ++g; --j; }
+						R.gl = g;
+					}
+					nextgaps[t] = R.gl;
+				}
 				farthest = std::max(farthest, block[t]);
-				nextgaps[t] = 0;
-				while (j != limit && row[j] == '-') { nextgaps[t]++; j += dir; }
 				minnext = std::min(minnext, nextgaps[t]);
 			}
 			if (blocked) continue;                                    /* :716-721 */
@@ -541,6 +580,7 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			for (int y = 0; y < kSym; ++y) SV(col + dir * j, y) = keep.best[(size_t)j * kSym + y];
 		for (int t = 0; t < nmov; ++t) {                              /* :841-852 */
 			const int sq = movers[t];
+			runs[(size_t)sq].valid = false;
 			for (int j = keep.affected[t] - 1; j >= 0; --j) {
 				const int c = col + dir * j;
 				CH(sq, c) = (j < sh) ? '-' : CH(sq, c - dir * sh);
@@ -551,6 +591,7 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		for (int j = col - 1; j >= 1; --j) { if (SV(j, kGap) != numseqs) break; ++left; }
 		const int drop = right + left;
 		if (drop > 0) {                                               /* :865-887 */
+			for (Run &R : runs) R.valid = false;
 			move_split(col - left - 1);                               /* the run becomes the head of the right segment */
 			gap += drop;
 			consensus_ -= drop;
