@@ -81,8 +81,10 @@ def main():
     if "bench" in out:                      # what bench.py reads: the bench workload's kernels at top level
         for key, o in out["bench"].items():
             top = dict(o)
-            if key == "nw_fill_bits":       # 4 merged passes of 128 pairs of 16384 letters per launch under CSADP_BITS_STREAMS=1
-                top["launch_shape"] = {"jobs": 512, "len": 16384}
+            if key == "nw_fill_bits":       # merged passes of 128 pairs of 16384 letters: jobs = workgroups of the launch
+                grid = next(iter(o.get("grids", {"0 x 1": 1})))
+                g, w = grid.split(" x ")
+                top["launch_shape"] = {"jobs": int(g) // max(int(w), 1), "len": 16384}
             out[key] = top
     with open(prefix + "_pmc_summary.json", "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
