@@ -36,11 +36,12 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # "Wave scheduling"; it is the FP32 vector peak of 157.3 TFLOP/s counted without the FMA's factor 2).
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 # VALU instructions of the compiled steady-state step of nw_fill_bits per 32 cells (one lane, one
-# row of 32 columns): ISA count of the shipped code object (tools/count_valu.py); PMC cross-check
-# SQ_INSTS_VALU / cells in profiles/.  The calibrated ceiling prices each instruction kind at the issue
+# row of 32 columns): `python tools/count_valu.py` on the shipped source -- 20 v_bitop3, 10 half-rate
+# (2 v_add3, 2 v_perm, 4 v_bfe, v_alignbit, the DPP move), 1 v_xor = 31; PMC cross-check: SQ_INSTS_VALU
+# per wave / steps = 32.9 including the per-block work (profiles/r02_pmc_summary.json).  The calibrated ceiling prices each instruction kind at the issue
 # cost measured alone on this chip (profiles/r01_valu_microbench.txt): v_bitop3 2.6, DPP /
 # three-operand 4.3, two-operand 2.1 cycles per wave64 and SIMD.
-BITS_STEP_MIX = {"v_bitop3": (20, 2.6), "dpp_or_three_operand": (10, 4.3), "two_operand": (2, 2.1)}
+BITS_STEP_MIX = {"v_bitop3": (20, 2.6), "dpp_or_three_operand": (10, 4.3), "two_operand": (1, 2.1)}
 BITS_VALU_PER_CELL = sum(n for n, _ in BITS_STEP_MIX.values()) / 32.0
 BITS_CYCLES_PER_64_CELLS = sum(n * c for n, c in BITS_STEP_MIX.values()) / 32.0
 ALG_BYTES_PER_CELL = 0.25             # the 2-bit direction of every cell

@@ -11,7 +11,8 @@
  * critical path is its nrows + ncols anti-diagonals.  The tiled kernel (csadp_kernels.hip) gives a
  * lane 16 columns x 2 rows per step -- ~200 dependent-issue-bound instructions -- and needs
  * nrows/2 + ncols/16 such steps; here a step is ONE cell (8 VALU instructions: two DPP moves, the
- * table lookup, two additions, max3, the direction shift, the tag mask) and a matrix takes
+ * table lookup, two additions, max3, the direction shift, the tag mask; the compiler adds a ninth, a
+ * register copy that pairs value and letter offset for the 64-bit hand-off store) and a matrix takes
  * nrows + ncols of them, on one wave per SIMD so that nothing else competes for the issue slot.
  * Gain form and tie-break as in csadp_device.h: X = 4*H + 4*i*r, candidates tagged U 0 / L 1 / D 2,
  * one v_max3_i32 yields the reference's H and the reference's direction (D >= L >= U, :1014-1025).
