@@ -276,34 +276,15 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 	/* The profile is only read again by a later step of the same task (and by
 	 * DeleteGappedColumns, i > 1): the last step of a 2-sequence task need not maintain it. */
 	const bool profile = !(nseq_ == 2 && i == 1);
-	std::vector<int> newsv;
-	std::vector<std::string> newstr;
-	std::vector<int> *svp = &sv_;
-	std::vector<std::string> *strp = &str_;
-	if (!inplace) {
-		if (profile) newsv.assign((size_t)(newcons + 1) * kSym, 0);
-		newstr.assign(nseq_, std::string());
-		for (int l = 0; l < i; ++l) newstr[order_[l]].assign((size_t)newcons, '\0');
-		svp = &newsv;
-		strp = &newstr;
-	}
+	/* The reference writes, for every cell of the path, one letter into each of the i old strings and five
+	 * counts (:1075-1105): i scattered writes per op.  Here the walk only records where every new column
+	 * comes from (`src`: the old column, 0 = a column the row sequence opens) and the new row; profile and
+	 * strings are then rebuilt string by string -- the same bytes, sequential access. */
 	std::string cur((size_t)newcons, '\0');
+	std::vector<int> src;
+	if (!inplace) src.assign((size_t)newcons, 0);
 	int j = nrows, k = ncols, m = newcons - 1;
 	int pos = ends_[n] - 1;
-	auto copy_column = [&](int kk, int mm) {               /* :1075-1079 */
-		if (profile)
-			for (int l = 0; l < kSym; ++l) (*svp)[(size_t)(mm + 1) * kSym + l] = sv_[(size_t)kk * kSym + l];
-		for (int l = 0; l < i; ++l) { const int p = order_[l]; (*strp)[p][mm] = str_[p][kk - 1]; }
-	};
-	auto new_column = [&](int mm) {                         /* :1100-1105 / :1116-1120 */
-		for (int l = 0; l < i; ++l) {
-			(*strp)[order_[l]][mm] = '-';
-			if (profile) (*svp)[(size_t)(mm + 1) * kSym + kGap]++;
-		}
-	};
-	auto count = [&](int mm, int sym) {                     /* the new row's symbol joins column mm */
-		if (profile) (*svp)[(size_t)(mm + 1) * kSym + sym]++;
-	};
 	long long score = 0;                                    /* sum of move scores, :993-998 */
 	for (int t = 0; t < nops; ++t, --m) {                   /* :1072-1114 */
 		const int op = ops[t];
@@ -312,23 +293,18 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 			const int c = code_of(ch);
 			const int *col = &sv_[(size_t)k * kSym];
 			score += kMatch * col[c] + kIndel * col[kGap] + kMismatch * (i - (col[c] + col[kGap]));
-			if (!inplace) copy_column(k, m);
-			cur[m] = ch;
-			count(m, c);
+			if (!inplace) src[(size_t)m] = k;               /* :1075-1079 */
+			cur[(size_t)m] = ch;
 			--pos; --j; --k;
 		} else if (op == DIR_L) {
 			const int g = sv_[(size_t)k * kSym + kGap];
 			score += kDoubleGap * g + kIndel * (i - g);
-			if (!inplace) copy_column(k, m);
-			cur[m] = '-';
-			count(m, kGap);
+			if (!inplace) src[(size_t)m] = k;
+			cur[(size_t)m] = '-';
 			--k;
-		} else {
+		} else {                                            /* :1100-1105: a new column, old sequences get '-' */
 			score += kIndel * i;
-			if (!inplace) new_column(m);
-			const char ch = char_at(pos, n);
-			cur[m] = ch;
-			count(m, code_of(ch));
+			cur[(size_t)m] = char_at(pos, n);
 			--pos; --j;
 		}
 	}
@@ -336,20 +312,35 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 	score += (j > 0) ? -(long long)border_i_ * j : (long long)border_top_[(size_t)k];
 	if (expect_score && *expect_score != (int)score) return CSADP_ERR_HIP;
 	for (; j > 0; --j, --m) {                               /* :1115-1127 */
-		new_column(m);
-		const char ch = char_at(pos, n);
-		cur[m] = ch;
-		count(m, code_of(ch));
+		cur[(size_t)m] = char_at(pos, n);
 		--pos;
 	}
 	for (; k > 0; --k, --m) {                               /* :1128-1138 */
-		if (!inplace) copy_column(k, m);
-		cur[m] = '-';
-		count(m, kGap);
+		if (!inplace) src[(size_t)m] = k;
+		cur[(size_t)m] = '-';
 	}
-	if (!inplace) {                                         /* :1139-1153 */
-		if (profile) sv_.swap(newsv);
-		for (int l = 0; l < i; ++l) str_[order_[l]].swap(newstr[order_[l]]);
+	if (inplace) {                                          /* no new column: the row's symbols join the old columns */
+		if (profile)
+			for (int c = 0; c < newcons; ++c) sv_[(size_t)(c + 1) * kSym + code_of(cur[(size_t)c])]++;
+	} else {                                                /* :1139-1153 */
+		if (profile) {
+			std::vector<int> newsv((size_t)(newcons + 1) * kSym, 0);
+			for (int c = 0; c < newcons; ++c) {
+				int *dst = &newsv[(size_t)(c + 1) * kSym];
+				if (src[(size_t)c]) memcpy(dst, &sv_[(size_t)src[(size_t)c] * kSym], kSym * sizeof(int));
+				else dst[kGap] = i;
+				dst[code_of(cur[(size_t)c])]++;
+			}
+			sv_.swap(newsv);
+		}
+		std::string nw;
+		for (int l = 0; l < i; ++l) {
+			std::string &old = str_[order_[l]];
+			nw.assign((size_t)newcons, '-');
+			for (int c = 0; c < newcons; ++c)
+				if (src[(size_t)c]) nw[(size_t)c] = old[(size_t)src[(size_t)c] - 1];
+			old.swap(nw);
+		}
 	}
 	str_[n].swap(cur);
 	have_[n] = 1;
