@@ -127,7 +127,8 @@ int Engine::init(int dev, const csadp_config *cfg)
 	cus_ = prop.multiProcessorCount;
 	slots_ = env_int("CSADP_SLOTS", 4);
 	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
-	for (int i = 0; i < std::max(slots_, 2); ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+	nstreams_ = 2 * main_streams();
+	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
 	C_ = env_int("CSADP_COLS_PER_LANE", 16);
 	R_ = env_int("CSADP_ROWS_PER_STEP", 2);
 	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 64);
@@ -223,7 +224,7 @@ void Engine::shutdown()
 		for (auto &e : pinned_pool_) (void)hipHostFree(e.first);
 		pinned_pool_.clear();
 	}
-	for (int i = 0; i < std::max(slots_, 2); ++i) {
+	for (int i = 0; i < nstreams_; ++i) {
 		(void)hipStreamSynchronize(streams_[i]);
 		(void)hipStreamDestroy(streams_[i]);
 		streams_[i] = nullptr;
@@ -238,7 +239,7 @@ FillBatch::~FillBatch()
 	(void)E_->bind();
 	/* the arena and the pinned mirrors go back to the engine's pools: nothing may still be using them */
 	if (laid_out_)
-		for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl)
+		for (int sl = 0; sl < E_->nstreams(); ++sl)
 			if (!bits_ || (used_streams_ >> sl) & 1u) (void)hipStreamSynchronize(E_->stream(sl));
 	if (arena_) E_->give_arena(arena_, arena_cap_);
 	if (h_in_) E_->give_pinned(h_in_, h_in_cap_);
@@ -840,10 +841,11 @@ int FillBatch::layout_bits()
 	}
 	/* A job is one workgroup of up to 16 waves, and 128 jobs fill half of the chip's compute units, so
 	 * consecutive passes are MERGED: `group` passes (slots) form one launch of group * nj workgroups, aiming at
-	 * ONE workgroup per compute unit, and three such launches are kept in flight on three streams so that the
-	 * tail and the traceback of one overlap the next.  Measured on the bench batch (tools/sweep_groups.sh,
-	 * ms per pass sustained): 1 x 3: 1.53-1.65, 2 x 3: 0.952-0.958, 4 x 3: 0.966-1.014, 8 x 3: 0.952-0.960 --
-	 * two workgroups of one launch on a compute unit gain less than two launches sharing it. */
+	 * ONE workgroup per compute unit, and two such fill launches are kept in flight on two streams, each with
+	 * its traceback on a side stream (launch_bits_pass), so that fills never pause for a traceback.  Measured
+	 * on the bench batch (tools/sweep2.sh, ms per pass sustained over 48 passes; group x streams): 2 x 2:
+	 * 0.920-0.929, 4 x 2: 1.003-1.021, 8 x 2: 1.135-1.146, 2 x 3: 1.089-1.090, 4 x 1: 1.059-1.063 (before the
+	 * side streams: 2 x 3: 0.952-0.958, tools/sweep_groups.sh). */
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
 	bits_group_ = 1;
@@ -852,12 +854,11 @@ int FillBatch::layout_bits()
 		const int want = std::max(E.compute_units(), 1);
 		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
 		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
-		/* launches in flight: 2 with direction planes in HBM (8.6 GB per bench pass), 3 in
-		 * checkpoint mode (0.6 GB), where the long replay traceback of one launch should hide
-		 * under the fills of the next two */
-		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", bits_ckpt_ ? 3 : 2), std::max(E.slots(), 2)));
-		bits_streams_ = std::min(bits_streams_, Engine::kMaxSlots / bits_group_);
-		nslots_ = bits_streams_ * bits_group_;
+		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", 2), E.main_streams()));
+		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
+		 * stream while the next fill of the stream already works on the other range */
+		bits_streams_ = std::max(1, std::min(bits_streams_, Engine::kMaxSlots / (2 * bits_group_)));
+		nslots_ = bits_streams_ * 2 * bits_group_;
 	}
 	/* How many strips share a workgroup.  A job is normally ONE workgroup (nw_fill_bits, up to 16 strips).  A
 	 * launch with few strips in all -- a single 16 kbp pair, the first fills of a whole-genome profile
@@ -1023,9 +1024,10 @@ int FillBatch::layout_bits()
 		memcpy(h_in_ + serial_off_, serial_tiles_.data(), serial_tiles_.size() * sizeof(TileRef));
 	}
 	next_stream_ = 0;
+	launch_no_ = 0;
 	/* batches of one engine start on different streams, so that a streaming caller's batches (each one
 	 * pass, several in flight) overlap instead of queueing behind each other */
-	base_stream_ = E.rotate_stream() % std::max(E.slots(), 2);
+	base_stream_ = E.rotate_stream() % E.main_streams();
 	used_streams_ = 0;
 	bjobs_ = slot_jobs[0];
 	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
@@ -1114,7 +1116,7 @@ int FillBatch::upload_async()
 {
 	if (!laid_out_) return CSADP_ERR_STATE;
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
-	const int nst = std::max(E_->slots(), 2);
+	const int nst = E_->nstreams();
 	hipStream_t s0 = E_->stream(bits_ ? base_stream_ : 0);
 	if (bits_ && bits_wide_ && hand_bytes_ > 0)
 		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, s0));
@@ -1162,34 +1164,40 @@ int FillBatch::flush()
 int FillBatch::flush_bits(int k)
 {
 	Engine &E = *E_;
-	const int nj = (int)bjobs_.size();
+	const int mainN = E.main_streams();
 	while (k > 0) {
-		const int qi = nslots_ > 1 ? next_stream_ : 0;                 /* slot range of this launch */
-		const int q = (base_stream_ + qi) % std::max(E.slots(), 2);   /* its stream */
-		const int first = qi * bits_group_;
+		const bool piped = nslots_ > 1;
+		const int qi = piped ? next_stream_ : 0;                        /* which of the batch's streams */
+		const int parity = piped ? (launch_no_ / bits_streams_) & 1 : 0;  /* which of that stream's two slot ranges */
+		const int q = (base_stream_ + qi) % mainN;
+		const int qs = piped ? mainN + q : q;                           /* its side stream */
+		const int first = (qi * 2 + parity) * bits_group_;
 		const int g = std::min(k, bits_group_);
-		const int rc = launch_bits_pass(first, g, E.stream(q), false);
-		used_streams_ |= 1u << q;
-		last_stream_ = q;
+		const int rc = launch_bits_pass(first, g, E.stream(q), E.stream(qs), false);
+		used_streams_ |= (1u << q) | (1u << qs);
+		last_stream_ = qs;
 		if (rc != CSADP_OK) return rc;
-		for (int sl = first; sl < first + g; ++sl) slot_used_[sl] = true;
+		last_first_ = first;
 		last_slot_ = first + g - 1;
 		last_group_ = g;
 		next_stream_ = (next_stream_ + 1) % bits_streams_;
+		++launch_no_;
 		k -= g;
 	}
-	(void)nj;
 	return CSADP_OK;
 }
 
-/* g merged passes (slots first .. first+g-1) on stream st: [pack planes] fill, traceback, [expand rows].
- * serial = the wait-free form of the chunked fill: one launch per chunk index (recover_bits). */
-int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, bool serial)
+/* g merged passes (slots first .. first+g-1): [pack planes] and fill on stream st, then traceback and [expand
+ * rows] on `side` behind an event, so st is free for the fill of its other slot range at once; a range is
+ * re-entered only after its own previous traceback has finished.  The three events of a launch live at
+ * ev_[first].  serial = the wait-free form of the chunked fill: one launch per chunk index (check_abort). */
+int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial)
 {
 	const int nj = (int)bjobs_.size();
-	hipEvent_t *ev = ev_[first + g - 1];
+	hipEvent_t *ev = ev_[first];
 	const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
 	int *abort_word = reinterpret_cast<int *>(arena_ + abort_off_);
+	if (slot_used_[first] && side != st) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));
 	HIP_TRY(hipEventRecord(ev[0], st));
 	if (io_) HIP_TRY(launch_pack_planes(arena_, bj, g * nj, st));
 	if (bits_wide_) {
@@ -1207,9 +1215,11 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, bool serial)
 		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, abort_word, st));
 	}
 	HIP_TRY(hipEventRecord(ev[1], st));
-	HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, st));
-	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, st));
-	HIP_TRY(hipEventRecord(ev[2], st));
+	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
+	HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, side));
+	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
+	HIP_TRY(hipEventRecord(ev[2], side));
+	slot_used_[first] = true;
 	return CSADP_OK;
 }
 
@@ -1250,8 +1260,7 @@ int FillBatch::check_abort()
 	fprintf(stderr, "csadp: a cross-workgroup wait of the chunked fill timed out; repeating the pass chunk by chunk\n");
 	++recoveries_;
 	HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 0, 4, st));
-	const int first = (last_slot_ / bits_group_) * bits_group_;
-	const int rc = launch_bits_pass(first, last_slot_ - first + 1, st, true);
+	const int rc = launch_bits_pass(last_first_, last_slot_ - last_first_ + 1, st, st, true);
 	if (rc != CSADP_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1335,8 +1344,8 @@ int FillBatch::sync()
 	const int rc = flush();
 	if (rc != CSADP_OK) return rc;
 	/* bit-parallel batches wait for the streams THEY used: other batches of the engine keep running */
-	for (int sl = 0; sl < std::max(E_->slots(), 2); ++sl)
-		if (!bits_ || (used_streams_ >> sl) & 1u) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
+	for (int sl = 0; sl < E_->nstreams(); ++sl)
+		if (bits_ ? ((used_streams_ >> sl) & 1u) != 0 : sl < E_->main_streams()) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
 	return ran_ ? check_abort() : CSADP_OK;
 }
 
@@ -1379,7 +1388,7 @@ int FillBatch::timing(csadp_timing *t)
 		if (rc != CSADP_OK) return rc;
 	}
 	memset(t, 0, sizeof(*t));
-	hipEvent_t *ev = ev_[last_slot_];
+	hipEvent_t *ev = ev_[bits_ ? last_first_ : last_slot_];
 	HIP_TRY(hipEventSynchronize(ev[2]));
 	{
 		const int before = recoveries_;

@@ -43,6 +43,10 @@ public:
 	static constexpr int kMaxSlots = 16;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
 	int slots() const { return slots_; }
+	/* streams [0, main_streams()) carry fills; stream main_streams() + q is the side stream of main stream q:
+	 * the traceback of a bit-parallel launch runs there, so the next fill of stream q need not wait for it */
+	int main_streams() const { return slots_ < 2 ? 2 : slots_; }
+	int nstreams() const { return nstreams_; }
 	int C() const { return C_; }
 	int R() const { return R_; }
 	int TR() const { return TR_; }
@@ -71,8 +75,8 @@ private:
 	int C_ = 16, R_ = 2, TR_ = 128;
 	int cus_ = 0;
 	char name_[256] = {0};
-	int slots_ = 2;
-	hipStream_t streams_[kMaxSlots] = {};
+	int slots_ = 2, nstreams_ = 0;
+	hipStream_t streams_[2 * kMaxSlots] = {};
 	std::atomic<int> stream_rr_{0};
 	std::mutex pool_mutex_;
 	std::vector<std::pair<uint8_t *, size_t>> arena_pool_, pinned_pool_;
@@ -179,10 +183,10 @@ private:
 	bool cells_mode_ = false;
 	size_t hand_off_[Engine::kMaxSlots] = {}, hand_bytes_ = 0;
 	int flush_bits(int k);
-	int launch_bits_pass(int first, int g, hipStream_t st, bool serial);
+	int launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial);
 	int check_abort();
 	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0;
-	int base_stream_ = 0, last_stream_ = 0;
+	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	unsigned used_streams_ = 0;
 	size_t abort_off_ = 0, serial_off_ = 0;
 	std::vector<TileRef> serial_tiles_;
