@@ -1214,6 +1214,8 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 	} else {
 		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, abort_word, st));
 	}
+	if (!serial && bits_wide_ && env_int("CSADP_TEST_FORCE_ABORT", 0) != 0)   /* testing: see run_slot_cells */
+		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
 	HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, side));
@@ -1293,6 +1295,8 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 			HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
 			                          (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 	}
+	if (!serial && env_int("CSADP_TEST_FORCE_ABORT", 0) != 0)   /* testing: pretend a bounded wait ran out, so that the repeat path runs */
+		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	HIP_TRY(launch_traceback_cells(arena_, cj, (int)cjobs_.size(), st));
 	HIP_TRY(hipEventRecord(ev[2], st));

@@ -223,3 +223,24 @@ def test_device_path_scores_cross_checked(monkeypatch):
     got = pb.fetch()
     pb.close()
     assert all(g["status"] == 0 for g in got)
+
+
+def test_abort_word_triggers_the_chunk_by_chunk_repeat(monkeypatch, capfd):
+    """The chunked fills (nw_fill_bits_wide, nw_fill_cells) wait across workgroups with bounded spins; when
+    one runs out the batch's abort word is raised and the host repeats the pass chunk by chunk -- one launch
+    per chunk index, every producer finished before its consumer starts.  CSADP_TEST_FORCE_ABORT raises the
+    word behind a normal launch: the repeat path must run (the library says so on stderr) and the results
+    must be the oracle's.  Covers a pair wider than one chunk (bit-parallel, 4-strip chunks) and families
+    whose profile steps span several chunks of the cell-per-lane kernel."""
+    r = rng(606)
+    a, b = related(r, 9000, None)
+    tasks = [([a, b], [11, 7], None, None)]
+    fam = [related(r, 700, None)[1] for _ in range(4)]
+    tasks.append((fam, [0, 1, 2, 3], None, None))
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    monkeypatch.setenv("CSADP_TEST_FORCE_ABORT", "1")
+    got = [csa_amd.align_batch([t])[0] for t in tasks]
+    err = capfd.readouterr().err
+    assert "repeating the pass chunk by chunk" in err
+    for g, (cons, strs, st) in zip(got, want):
+        assert g["status"] == 0 and g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
