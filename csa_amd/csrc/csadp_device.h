@@ -128,8 +128,10 @@ struct BitJob {
 	uint64_t ckpt;            /* checkpoint mode: u32 [nstrips][steps_pad/32][64][words][4] lane state (per word of a lane: */
 	                          /*     nH0, H1, H2; + the hand-off word) after every block of 32 steps                      */
 	uint64_t hand;            /* checkpoint mode: u32 [nstrips][4][steps_pad] hand-off words leaving lanes 15, 31, 47 and   */
-	                          /*     63 after each step: a replay can restart at any 16-lane boundary of a strip           */
-	uint64_t progress;        /* wide jobs: i32 [chunks] blocks finished by the last strip of each chunk of 16 strips      */
+	                          /*     63 after each step: a replay can restart at any 16-lane boundary of a strip.  Stream 3  */
+	                          /*     of a chunk's last strip also feeds the next chunk (nw_fill_bits_wide): there only bits   */
+	                          /*     31/23/15 are payload, the rest of bytes 1..3 holds the launch's epoch                    */
+	uint64_t progress;        /* unused since round 2 (chunks hand over through epoch-tagged mark words, csadp_bits.hip)     */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;
@@ -168,8 +170,9 @@ struct CellJob {
 	uint64_t top;             /* i32 [ncols_pad + 1] X of border row 0 (possibly stale, survey Q1)                        */
 	uint64_t dirs;            /* u32 [nstrips][steps_pad/16][64]: the 2-bit tags of 16 consecutive local steps of one      */
 	                          /*     column; local step l of the column with lane L is row l - L + 1; first step in bits 1:0 */
-	uint64_t hand;            /* u32 [nchunks][steps_pad][2] (value, letter offset) leaving the last lane of each chunk    */
-	uint64_t progress;        /* i32 [nchunks] blocks finished by the last strip of each chunk                             */
+	uint64_t hand;            /* u64 [nchunks-1][steps_pad] granules {X, letter offset | epoch << 8} leaving the last lane of   */
+	                          /*     each chunk but the last: valid when they carry the launch's epoch                       */
+	uint64_t progress;        /* unused (kept for layout stability)                                                          */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;

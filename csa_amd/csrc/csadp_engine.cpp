@@ -563,14 +563,8 @@ int FillBatch::layout_cells()
 		}
 		res_bytes_ = off - res_off_[sl];
 		sum_bytes_ = res_bytes_;
-		flags_off_[sl] = off;                     /* progress counters of the chunked jobs: zeroed before every pass */
-		for (int j = 0; j < nj; ++j) {
-			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
-			C.progress = off;
-			off += (size_t)C.nchunks * 4;
-		}
-		off = align_up(off, 256);
-		flags_bytes_ = off - flags_off_[sl];
+		flags_off_[sl] = off;
+		flags_bytes_ = 0;
 		for (int j = 0; j < nj; ++j) {
 			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
 			C.dirs = off;
@@ -1274,8 +1268,8 @@ int FillBatch::check_abort()
 }
 
 /* Enqueue ONE pass (fill + traceback) of slot sl on stream sl. */
-/* one pass of the cell-per-lane kernels on slot sl: progress counters, fill (one launch, or one per
- * chunk index on the wait-free path), traceback */
+/* one pass of the cell-per-lane kernels on slot sl: fill (one launch, or one per chunk index on the
+ * wait-free path), traceback */
 int FillBatch::run_slot_cells(int sl, bool serial)
 {
 	hipStream_t st = E_->stream(sl);
