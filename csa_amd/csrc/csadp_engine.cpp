@@ -1074,10 +1074,22 @@ int FillBatch::alloc_buffers()
 int FillBatch::finish_layout()
 {
 	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
-	for (int sl = 0; sl < nslots_; ++sl)
+	/* events: the bit-parallel path keeps a launch's three events at the first slot of its range only */
+	for (int sl = 0; sl < nslots_; ++sl) {
+		if (bits_ && nslots_ > 1 && sl % bits_group_ != 0) continue;
 		for (auto &e : ev_[sl])
 			if (!e) HIP_TRY(hipEventCreate(&e));
-	memset(h_in_, 0, in_bytes_);
+	}
+	/* zeroed inputs (padding the kernels rely on, the abort word, the status words) -- except the raw texts of
+	 * a device-I/O batch, which the caller overwrites letter for letter: a streaming caller's create() would
+	 * otherwise clear megabytes of pinned memory twice */
+	if (io_ && !texts_.empty()) {
+		const size_t tbeg = texts_.front().off, tend = texts_.back().off + (size_t)texts_.back().size;
+		memset(h_in_, 0, tbeg);
+		memset(h_in_ + tend, 0, in_bytes_ - tend);
+	} else {
+		memset(h_in_, 0, in_bytes_);
+	}
 	laid_out_ = true;
 	ran_ = false;
 	pending_ = 0;
