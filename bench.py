@@ -325,7 +325,8 @@ def main():
         if pmc and pmc.get("launch_shape") == {"jobs": lp * len(tasks), "len": args.length}:
             traffic = int(pmc["hbm_write_bytes_per_launch"] + pmc["hbm_read_bytes_per_launch_x2_corrected"])
         line = {
-            "metric": "DP cells/sec (GCUPS) on 16 kbp x 16 kbp pairs, letters in HBM -> aligned rows in HBM, whole job",
+            "metric": "DP cells/sec (GCUPS) on %s, letters in HBM -> aligned rows in HBM, whole job" % (
+                "1-200 kbp mixed-length pairs (config 5)" if args.workload == "config5" and args.mode == "strong" else "16 kbp x 16 kbp pairs"),
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
@@ -334,7 +335,8 @@ def main():
             "per_gpu_gcups": round(value / args.gpus, 3),
             "config": {"workload": workload + "; linear-gap NW: pack + fill + traceback + row expansion on the device, "
                                               "bit-exact vs the reference",
-                       "pairs_this_rank": len(tasks), "seq_len": args.length, "kernel": "nw_fill_bits",
+                       "pairs_this_rank": len(tasks), "seq_len": "1000..200000" if args.workload == "config5" and args.mode == "strong" else args.length,
+                       "kernel": "nw_fill_bits",
                        "passes_per_launch": max(tm_pipe["launch_passes"], 1), "device_io": tm["device_io"],
                        "parallelism": "independent tasks over %d GPU(s); no collective in the timed region; result records "
                                       "all-gathered over %s afterwards" % (args.gpus, "RCCL" if args.backend == "nccl" else "gloo"),
