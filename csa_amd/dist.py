@@ -27,16 +27,23 @@ def shard_range(total, rank, world):
 
 
 class Group:
-    """Thin wrapper: becomes a no-op when world == 1 (no process group is created)."""
+    """Thin wrapper: becomes a no-op when world == 1 (no process group is created), unless
+    CSADP_DIST_FORCE_GROUP=1 asks for a real one-rank group -- that is how the RCCL calls below are
+    exercised on a one-GPU box."""
 
     def __init__(self, backend="nccl", device=None):
         self.rank, self.local_rank, self.world = env_world()
         self.backend = backend
         self.device = device
         self._dist = None
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("CSADP_DIST_FORCE_GROUP") == "1":
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:          # only the forced one-rank group gets here
+                import socket
+                with socket.socket() as s:
+                    s.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s.getsockname()[1])
             if not dist.is_initialized():
                 kw = {}
                 if backend == "nccl" and device is not None:

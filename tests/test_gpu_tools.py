@@ -209,3 +209,23 @@ def test_csa_pairs_over_two_devices(monkeypatch):
     m = re.search(r"over 2 GPUs: imbalance ([0-9.]+)", log)
     assert m and float(m.group(1)) <= 1.05
     assert log.count("> gpu ") == 2
+
+
+def test_bench_collectives_run_over_rccl_on_one_rank():
+    """bench.py's multi-GPU plumbing with the REAL backend: CSADP_DIST_FORCE_GROUP=1 makes the single rank
+    create an nccl (= RCCL) process group, so the LPT broadcast, the barriers, the max/sum reductions and the
+    all-gather of the 16-byte records run on device tensors; the gathered records must cover the whole list."""
+    import json
+    import sys
+    env = dict(os.environ, CSADP_DIST_FORCE_GROUP="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--mode", "strong", "--workload", "config4", "--len", "1024",
+                        "--no-cpu-baseline", "--no-extra-legs"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["verified"] is True
+    assert line["records"]["gathered"] == 1024
+    assert line["config"]["lpt_imbalance"] == 1.0
