@@ -70,14 +70,14 @@ struct CellState {
 
 /* 32 steps.  inject[t] = (X, letter offset) entering lane 0 at step t; every lane stores what it hands
  * to the right to lanebuf[t] (the ring for lane 63, a scrap area for all others: no EXEC change);
- * dirs points at this lane's word of the block's first 16 steps.
+ * words receives this lane's two direction words of the block (the caller stores them one block later).
  * A step is ~8 VALU instructions, far shorter than an LDS round trip, so nothing inside the step may wait
  * for LDS: the block's 32 inject entries are read into registers up front (64 VGPRs; all lanes read the
  * same address, only lane 0's copy is used), one wait per block, and the per-step hand-off stores are
  * never waited for. */
 template <bool WIDE, bool RAMP>
 __device__ __forceinline__ void cell_block(CellState &S, uint32_t tab, int32_t leftc, const uint2 *inject, uint2 *lanebuf,
-                                           uint32_t *dirs, int l0, int lane)
+                                           uint32_t (&words)[kCellBlock / 16], int l0, int lane)
 {
 	uint32_t ioff = 0;
 	asm volatile("" : "+v"(ioff));                     /* keep the address in a VGPR: broadcast LDS reads */
@@ -110,11 +110,129 @@ __device__ __forceinline__ void cell_block(CellState &S, uint32_t tab, int32_t l
 		S.outv = S.hup;
 		S.outs = sh;
 		lanebuf[t] = make_uint2((uint32_t)S.outv, S.outs);
-		if ((t & 15) == 15) dirs[(t >> 4) * kLanes] = acc;
+		if ((t & 15) == 15) words[t >> 4] = acc;
 	}
 }
 
 }  // namespace
+
+/* What feeds lane 0 of a strip: the border column and the row letters (the job's first strip), the ring
+ * of the wave to the left (same workgroup), or the previous chunk's hand-off granules in HBM.  One loop
+ * per role, so that the compiler's wait-count bookkeeping stays exact: with the three merged into one
+ * loop body every wave waited for ALL its outstanding global accesses -- the direction stores it had just
+ * issued -- once per 32-step block (s_waitcnt vmcnt(0) at the merge points). */
+enum { ROLE_FIRST = 0, ROLE_RING = 1, ROLE_CHUNK = 2 };
+constexpr int kFirstGroup = 8;                    /* blocks of row letters the first strip stages at once */
+
+struct StripShared {
+	uint2 *ring_mine;            /* ring[wv]                           */
+	const uint2 *ring_prev;      /* ring[wv - 1]                       */
+	uint2 *inject_mine;          /* inject[wv]                         */
+	uint2 *first_inject;         /* kFirstGroup * kCellBlock entries   */
+	uint2 *scrap_mine;           /* scrap[wv]                          */
+	int *made, *taken;
+};
+
+template <bool WIDE, int ROLE>
+__device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, CellState &S, uint32_t tab, int32_t leftc, uint32_t *dirs,
+                                          const StripShared &L, unsigned long long *hand_out, const unsigned long long *hand_in, int wv,
+                                          int lane, int nb, bool feeds, bool publishes, uint32_t epoch)
+{
+	const int t = lane & 31;
+	/* ROLE_FIRST: the letters of kFirstGroup blocks = 256 rows, one dword per lane, requested one group ahead */
+	uint32_t letters = 0;
+	if (ROLE == ROLE_FIRST) letters = *reinterpret_cast<const uint32_t *>(rsh + 4 * lane);
+	/* ROLE_CHUNK: 8-byte granules {X, letter offset | epoch << 8}, each written by ONE write-through store and
+	 * valid exactly when it carries this launch's epoch -- no counter, no fence, one memory round trip, and
+	 * that one is hidden: the granules of block b + 1 are requested while block b is computed and only
+	 * re-read (bounded) if they had not arrived. */
+	unsigned long long pre = 0;
+	if (ROLE == ROLE_CHUNK && 63 + t < J.steps_pad) pre = __hip_atomic_load(hand_in + 63 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	/* Order of global accesses.  The compiler's wait before the first use of a loaded value is
+	 * s_waitcnt vmcnt(0): it also waits for every store issued since.  So a block first consumes what was
+	 * loaded for it, THEN stores the direction words of the previous block and requests the next block's
+	 * data: everything a wait can see was issued a whole block (~1 us) earlier and costs nothing. */
+	uint32_t words[kCellBlock / 16] = {0, 0};
+	for (int b = 0; b < nb; ++b) {
+		const uint2 *src = L.inject_mine;                     /* where lane 0's inputs of this block are read from */
+		if (ROLE == ROLE_FIRST) {
+			if (b % kFirstGroup == 0) {
+				/* lane l builds rows 4l + 1 .. 4l + 4 of the group: border column X[r][0] = leftmul * r (:967) */
+				const int r0 = b * kCellBlock + 4 * lane + 1;
+#pragma unroll
+				for (int u = 0; u < 4; ++u)
+					L.first_inject[4 * lane + u] = make_uint2((uint32_t)(J.leftmul * (r0 + u)), (letters >> (8 * u)) & 0xffu);
+			}
+			src = L.first_inject + (b % kFirstGroup) * kCellBlock;
+		} else if (ROLE == ROLE_RING) {
+			const int need = (b + 3 < nb) ? b + 3 : nb;           /* producer steps up to 32b + 94 */
+			if (!wait_lds(&L.made[wv - 1], need)) return false;
+			src = L.ring_prev + (b * kCellBlock + 63) % kRingSteps;  /* 32 consecutive slots thanks to the mirror */
+		} else {
+			const int ps = b * kCellBlock + 63 + t;               /* the producer's lane 63 is 63 steps ahead */
+			unsigned long long v = pre;
+			int spins = 0;
+			for (;;) {
+				const bool ok = ps >= J.steps_pad || (uint32_t)(v >> 40) == epoch;
+				if (__all(ok)) break;
+				__builtin_amdgcn_s_sleep(2);
+				if (++spins > kSpinMax) return false;
+				if (!ok) v = __hip_atomic_load(hand_in + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (lane < kCellBlock) L.inject_mine[lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xffu);
+		}
+		if (b > 0) {
+			uint32_t *d = dirs + (size_t)(b - 1) * (kCellBlock / 16) * kLanes;
+			d[0] = words[0];
+			d[kLanes] = words[1];
+		}
+		if (ROLE == ROLE_FIRST && b % kFirstGroup == 0)         /* rowshift is padded by two groups */
+			letters = *reinterpret_cast<const uint32_t *>(rsh + (b / kFirstGroup + 1) * (kFirstGroup * kCellBlock) + 4 * lane);
+		if (ROLE == ROLE_CHUNK) {
+			const int ps = (b + 1) * kCellBlock + 63 + t;
+			if (ps < J.steps_pad) pre = __hip_atomic_load(hand_in + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		const bool ringer = lane == kLanes - 1 && (feeds || publishes);
+		uint2 *lanebuf = ringer ? L.ring_mine + (b * kCellBlock) % kRingSteps : L.scrap_mine + lane;
+		if (feeds) {
+			/* the ring slots of this block last held block b - kRing, which the consumer reads during its
+			 * blocks b - kRing - 2 and b - kRing - 1 */
+			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
+		}
+		if (b < 2) cell_block<WIDE, true>(S, tab, leftc, src, lanebuf, words, b * kCellBlock, lane);
+		else cell_block<WIDE, false>(S, tab, leftc, src, lanebuf, words, b * kCellBlock, lane);
+		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers (cell_block waits) */
+			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (feeds || publishes) {
+			if ((b * kCellBlock) % kRingSteps < 2 * kCellBlock) {  /* mirror the ring's first two blocks behind its end */
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+				if (lane < kCellBlock) {
+					const int at = (b * kCellBlock) % kRingSteps + lane;
+					L.ring_mine[kRingSteps + at] = L.ring_mine[at];
+				}
+			}
+		}
+		if (feeds) {
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* this block's ring stores have been executed */
+			if (lane == kLanes - 1) __hip_atomic_store(&L.made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		if (publishes) {
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+			if (lane < kCellBlock) {
+				const uint2 v = L.ring_mine[(b * kCellBlock) % kRingSteps + lane];
+				__hip_atomic_store(hand_out + b * kCellBlock + lane,
+				                   (unsigned long long)v.x | ((unsigned long long)((v.y & 0xffu) | (epoch << 8)) << 32), __ATOMIC_RELAXED,
+				                   __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+	{
+		uint32_t *d = dirs + (size_t)(nb - 1) * (kCellBlock / 16) * kLanes;
+		d[0] = words[0];
+		d[kLanes] = words[1];
+	}
+	return true;
+}
 
 template <bool WIDE>
 __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
@@ -125,6 +243,7 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	 * consecutive slots a consumer block needs never wrap and can be read in place (no staging copy) */
 	__shared__ __attribute__((aligned(16))) uint2 ring[kCellWaves][kRingSteps + 2 * kCellBlock];
 	__shared__ __attribute__((aligned(16))) uint2 inject[kCellWaves][kCellBlock];
+	__shared__ __attribute__((aligned(16))) uint2 first_inject[kFirstGroup * kCellBlock];
 	__shared__ uint2 scrap[kCellWaves][kLanes + kCellBlock];   /* lane l, step t -> slot l + t: conflict-free */
 	__shared__ int made[kCellWaves], taken[kCellWaves];
 
@@ -152,89 +271,25 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	    reinterpret_cast<const unsigned long long *>(arena + J.hand) + (size_t)(chunk > 0 ? chunk - 1 : 0) * J.steps_pad;
 	const bool feeds = wv + 1 < kCellWaves && s + 1 < J.nstrips;        /* a wave of this workgroup reads my ring */
 	const bool publishes = wv + 1 == kCellWaves && s + 1 < J.nstrips;   /* the next chunk reads my hand-off words  */
-	const bool first_strip = s == 0;
-	const bool from_chunk = wv == 0 && chunk > 0;
-	const int t = lane & 31;
 
 	CellState S;
 	S.hup = top[col + 1];
 	S.diag = top[col];
 	S.outv = S.hup;
 	S.outs = 0;
-	/* row letters of the job's first strip, fetched two blocks ahead (lane t: row 32b + t + 1) */
-	uint32_t let0 = 0, let1 = 0;
-	if (first_strip) {
-		let0 = rsh[t];
-		let1 = rsh[kCellBlock + t];
-	}
-	/* Hand-off words from the previous chunk: 8-byte granules {X, letter offset | epoch << 8}, each written by
-	 * ONE write-through store and valid exactly when it carries this launch's epoch -- no counter, no fence,
-	 * one memory round trip, and that one is hidden: the granules of block b + 1 are requested while block b
-	 * is computed and only re-read (bounded) if they had not arrived. */
-	unsigned long long pre = 0;
-	if (from_chunk && 63 + t < J.steps_pad) pre = __hip_atomic_load(hand_in + 63 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	for (int b = 0; b < nb; ++b) {
-		const int ps = b * kCellBlock + 63 + t;                 /* the producer's lane 63 is 63 steps ahead */
-		const uint2 *src = inject[wv];                          /* where lane 0's inputs of this block are read from */
-		if (first_strip) {
-			uint2 word;
-			word.x = (uint32_t)(J.leftmul * (b * kCellBlock + t + 1));      /* border column: X[r][0] = leftmul * r */
-			word.y = let0;
-			let0 = let1;
-			let1 = rsh[(b + 2) * kCellBlock + t];                             /* rowshift is padded by 64 bytes */
-			if (lane < kCellBlock) inject[wv][lane] = word;
-		} else if (wv > 0) {
-			const int need = (b + 3 < nb) ? b + 3 : nb;             /* producer steps up to 32b + 94 */
-			if (!wait_lds(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			src = &ring[wv - 1][(b * kCellBlock + 63) % kRingSteps];   /* 32 consecutive slots thanks to the mirror */
-		} else {
-			unsigned long long v = pre;
-			int spins = 0;
-			for (;;) {
-				const bool ok = ps >= J.steps_pad || (uint32_t)(v >> 40) == epoch;
-				if (__all(ok)) break;
-				__builtin_amdgcn_s_sleep(2);
-				if (++spins > kSpinMax) { if (lane == 0) atomicExch(abort_word, 1); return; }
-				if (!ok) v = __hip_atomic_load(hand_in + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			if (ps + kCellBlock < J.steps_pad) pre = __hip_atomic_load(hand_in + ps + kCellBlock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (lane < kCellBlock) inject[wv][lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xffu);
-		}
-		const bool ringer = lane == kLanes - 1 && (feeds || publishes);
-		uint2 *lanebuf = ringer ? &ring[wv][(b * kCellBlock) % kRingSteps] : &scrap[wv][lane];
-		if (feeds) {
-			/* the ring slots of this block last held block b - kRing, which the consumer reads during its
-			 * blocks b - kRing - 2 and b - kRing - 1 */
-			if (!wait_lds(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-		}
-		uint32_t *d = dirs + (size_t)b * (kCellBlock / 16) * kLanes;
-		if (b < 2) cell_block<WIDE, true>(S, tab, leftc, src, lanebuf, d, b * kCellBlock, lane);
-		else cell_block<WIDE, false>(S, tab, leftc, src, lanebuf, d, b * kCellBlock, lane);
-		if (wv > 0 && !first_strip && lane == 0)                /* this block's ring words are in registers (cell_block waits) */
-			__hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (feeds || publishes) {
-			if ((b * kCellBlock) % kRingSteps < 2 * kCellBlock) {  /* mirror the ring's first two blocks behind its end */
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				if (lane < kCellBlock) {
-					const int at = (b * kCellBlock) % kRingSteps + lane;
-					ring[wv][kRingSteps + at] = ring[wv][at];
-				}
-			}
-		}
-		if (feeds) {
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* this block's ring stores have been executed */
-			if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-		if (publishes) {
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			if (lane < kCellBlock) {
-				const uint2 v = ring[wv][(b * kCellBlock) % kRingSteps + lane];
-				__hip_atomic_store(hand_out + b * kCellBlock + lane,
-				                   (unsigned long long)v.x | ((unsigned long long)((v.y & 0xffu) | (epoch << 8)) << 32), __ATOMIC_RELAXED,
-				                   __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
-	}
+	StripShared L;
+	L.ring_mine = ring[wv];
+	L.ring_prev = ring[wv > 0 ? wv - 1 : 0];
+	L.inject_mine = inject[wv];
+	L.first_inject = first_inject;
+	L.scrap_mine = scrap[wv];
+	L.made = made;
+	L.taken = taken;
+	bool ok;
+	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, tab, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	else if (wv > 0) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, tab, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, tab, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }
 
 /*

@@ -543,7 +543,7 @@ int FillBatch::layout_cells()
 		X.in_leftc = C.leftc = off;
 		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
 		X.in_rowshift = C.rowshift = off;
-		off = align_up(off + (size_t)C.steps_pad + 64, 256);
+		off = align_up(off + (size_t)C.steps_pad + 64 + 512, 256);   /* the first strip reads 256-byte groups, one group ahead */
 		X.in_top = C.top = off;
 		off = align_up(off + ((size_t)X.ncols_pad + 1) * 4, 256);
 	}

@@ -323,12 +323,23 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 		if (profile)
 			for (int c = 0; c < newcons; ++c) sv_[(size_t)(c + 1) * kSym + code_of(cur[(size_t)c])]++;
 	} else {                                                /* :1139-1153 */
+		/* old columns keep their order, so src[] is a few long runs of consecutive columns: block copies */
+		struct Span { int dst, src, len; };
+		std::vector<Span> spans;
+		for (int c = 0; c < newcons;) {
+			if (!src[(size_t)c]) { ++c; continue; }
+			int e = c + 1;
+			while (e < newcons && src[(size_t)e] == src[(size_t)e - 1] + 1) ++e;
+			spans.push_back(Span{c, src[(size_t)c], e - c});
+			c = e;
+		}
 		if (profile) {
 			std::vector<int> newsv((size_t)(newcons + 1) * kSym, 0);
+			for (const Span &sp : spans)
+				memcpy(&newsv[(size_t)(sp.dst + 1) * kSym], &sv_[(size_t)sp.src * kSym], (size_t)sp.len * kSym * sizeof(int));
 			for (int c = 0; c < newcons; ++c) {
 				int *dst = &newsv[(size_t)(c + 1) * kSym];
-				if (src[(size_t)c]) memcpy(dst, &sv_[(size_t)src[(size_t)c] * kSym], kSym * sizeof(int));
-				else dst[kGap] = i;
+				if (!src[(size_t)c]) dst[kGap] = i;
 				dst[code_of(cur[(size_t)c])]++;
 			}
 			sv_.swap(newsv);
@@ -337,8 +348,7 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 		for (int l = 0; l < i; ++l) {
 			std::string &old = str_[order_[l]];
 			nw.assign((size_t)newcons, '-');
-			for (int c = 0; c < newcons; ++c)
-				if (src[(size_t)c]) nw[(size_t)c] = old[(size_t)src[(size_t)c] - 1];
+			for (const Span &sp : spans) memcpy(&nw[(size_t)sp.dst], &old[(size_t)sp.src - 1], (size_t)sp.len);
 			old.swap(nw);
 		}
 	}
@@ -394,23 +404,31 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 	int split = consensus_, gap = 0;
 	auto phys = [&](int j) { return j <= split ? j : j + gap; };
 	auto SV = [&](int col, int sym) -> int & { return sv_[(size_t)phys(col) * kSym + sym]; };
-	auto CH = [&](int seq, int col) -> char & { return str_[seq][(size_t)phys(col) - 1]; };
-	auto move_split = [&](int to) {                 /* make logical columns 1..to the left segment */
-		if (gap == 0) { split = to; return; }
-		for (; split > to; --split) {               /* column `split` joins the right segment */
-			memcpy(&sv_[(size_t)(split + gap) * kSym], &sv_[(size_t)split * kSym], kSym * sizeof(int));
-			for (int t = 0; t < numseqs; ++t) { std::string &r = str_[order_[t]]; r[(size_t)split + gap - 1] = r[(size_t)split - 1]; }
+	/* the rows' storage does not move during the pass (they are resized once, at the end) */
+	std::vector<char *> rowp((size_t)numseqs), seqp((size_t)nseq_, nullptr);
+	for (int t = 0; t < numseqs; ++t) rowp[(size_t)t] = seqp[(size_t)order_[t]] = &str_[order_[t]][0];
+	auto CH = [&](int seq, int col) -> char & { return seqp[(size_t)seq][(size_t)phys(col) - 1]; };
+	auto move_split = [&](int to) {                 /* make logical columns 1..to the left segment: one block move per array */
+		if (gap != 0 && to < split) {               /* columns to+1..split join the right segment */
+			const size_t n = (size_t)(split - to);
+			memmove(&sv_[(size_t)(to + 1 + gap) * kSym], &sv_[(size_t)(to + 1) * kSym], n * kSym * sizeof(int));
+			for (int t = 0; t < numseqs; ++t) memmove(rowp[(size_t)t] + to + gap, rowp[(size_t)t] + to, n);
+		} else if (gap != 0 && to > split) {        /* columns split+1..to join the left segment */
+			const size_t n = (size_t)(to - split);
+			memmove(&sv_[(size_t)(split + 1) * kSym], &sv_[(size_t)(split + 1 + gap) * kSym], n * kSym * sizeof(int));
+			for (int t = 0; t < numseqs; ++t) memmove(rowp[(size_t)t] + split, rowp[(size_t)t] + split + gap, n);
 		}
-		for (; split < to; ++split) {               /* column split + 1 joins the left segment */
-			memcpy(&sv_[(size_t)(split + 1) * kSym], &sv_[(size_t)(split + 1 + gap) * kSym], kSym * sizeof(int));
-			for (int t = 0; t < numseqs; ++t) { std::string &r = str_[order_[t]]; r[(size_t)split] = r[(size_t)split + gap]; }
-		}
+		split = to;
 	};
 	const int mingaps = numseqs - maxnongaps;
 	struct Run { bool valid; int a, b; bool at, bt; int gl, gr; };
 	std::vector<Run> runs((size_t)nseq_, Run{false, 0, 0, false, false, -1, -1});
 	std::vector<int> movers;          /* seqstoshift */
-	std::vector<int> block, nextgaps, affected, statv, movv, workv;
+	std::vector<int> block, nextgaps, affected, statv, movv, vacp;
+	std::vector<signed char> codev((size_t)consensus_ + 2);      /* scratch sized for the widest search: no growth inside the scan */
+	vacp.resize((size_t)consensus_ + 3);
+	statv.resize(((size_t)consensus_ + 2) * kSym);
+	movv.reserve(((size_t)consensus_ + 2) * kSym);
 	Probe keep;
 
 	for (int col = 1; col <= consensus_; ++col) {
@@ -434,7 +452,8 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			const int limit = (dir > 0) ? consensus_ + 1 : 0;
 			int farthest = 0, minnext = consensus_;
 			bool blocked = false;
-			move_split(dir > 0 ? col - 1 : col);                      /* all of this direction's columns on one side */
+			/* column `col` itself is the head of the right segment (offset gap); the columns the leftward
+			 * search reads beyond it are in the left segment (offset 0) */
 			const int off = dir > 0 ? gap : 0;
 			for (int t = 0; t < nmov; ++t) {                          /* :699-715 */
 				/* The reference walks the residue run of the mover from `col` to its end for every candidate
@@ -445,7 +464,7 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 				 * runs beyond them; a row's memory is dropped when the row changes, everybody's when columns
 				 * are deleted.  Same block / nextgaps / blocked values, one walk per run instead of one per
 				 * column. */
-				const char *row = str_[movers[t]].data() + off - 1;   /* row[j] = logical column j on this side */
+				const char *row = seqp[(size_t)movers[t]] + off - 1;       /* row[j] = logical column j on this side */
 				Run &R = runs[(size_t)movers[t]];
 				if (!(R.valid && R.a <= col && col < R.b)) R = Run{true, col, col + 1, false, false, -1, -1};
 				if (dir > 0) {
@@ -487,61 +506,106 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			if (blocked) continue;                                    /* :716-721 */
 			for (int t = 0; t < nmov; ++t) affected[t] = block[t] + minnext;
 			const int maxaff = farthest + minnext;
-			statv.assign((size_t)maxaff * kSym, 0);
-			movv.assign((size_t)maxaff * kSym, 0);
-			workv.assign((size_t)maxaff * kSym, 0);
-			int current = 0;
-			for (int j = 0; j < maxaff; ++j) {                        /* :739-761 */
-				const int jj = col + dir * j;
-				const int *svjj = &sv_[(size_t)(jj + off) * kSym];
-				for (int y = 0; y < kSym; ++y) statv[(size_t)j * kSym + y] = svjj[y];
+			/* statv = the columns without the movers, movv = the movers' symbols, current = what the movers
+			 * score where they stand (:739-761) */
+			auto build_arrays = [&]() {
+				movv.assign((size_t)maxaff * kSym, 0);
+				for (int j = 0; j < maxaff; ++j) memcpy(&statv[(size_t)j * kSym], &sv_[(size_t)(col + dir * j + (j ? off : gap)) * kSym], kSym * sizeof(int));
+				int cur = 0;
 				for (int t = 0; t < nmov; ++t) {
-					if (j < affected[t]) {
-						const int c = code_of(str_[movers[t]][(size_t)(jj + off) - 1]);
+					const char *row = seqp[(size_t)movers[t]] + off - 1;
+					for (int j = 0; j < affected[t]; ++j) {
+						const int jj = col + dir * j, o = j ? off : gap;
+						const int c = code_of(row[jj + o - off]);
+						const int *svjj = &sv_[(size_t)(jj + o) * kSym];
 						movv[(size_t)j * kSym + c]++;
 						statv[(size_t)j * kSym + c]--;
+						cur += (c != kGap) ? kMatch * (svjj[c] - 1) + kMismatch * (numseqs - (svjj[c] + svjj[kGap])) + kIndel * svjj[kGap]
+						                   : kDoubleGap * (svjj[kGap] - 1) + kIndel * (numseqs - svjj[kGap]);
 					}
 				}
-				int colscore = 0;
-				for (int y = 0; y < kGap; ++y) {
-					const int mv = movv[(size_t)j * kSym + y];
-					if (mv != 0)
-						colscore += mv * (kMatch * (svjj[y] - 1) + kMismatch * (numseqs - (svjj[y] + svjj[kGap]))
-						                  + kIndel * svjj[kGap]);
-				}
-				const int mg = movv[(size_t)j * kSym + kGap];
-				if (mg != 0) colscore += mg * (kDoubleGap * (svjj[kGap] - 1) + kIndel * (numseqs - svjj[kGap]));
-				current += colscore;
-			}
-			for (int sh = 1; sh <= minnext; ++sh) {                   /* :762-795 */
-				int shifted = 0;
-				for (int t = 0; t < nmov; ++t) {
-					movv[(size_t)(affected[t] - 1) * kSym + kGap]--;
-					affected[t]--;
-				}
-				for (int j = 0; j < maxaff; ++j) {
-					int *w = &workv[(size_t)j * kSym];
-					if (j < sh) {
-						for (int y = 0; y < kGap; ++y) w[y] = 0;
-						w[kGap] = statv[(size_t)j * kSym + kGap] + nmov;
-						if (w[kGap] == numseqs) continue;
-						shifted += nmov * (kDoubleGap * (w[kGap] - 1) + kIndel * (numseqs - w[kGap]));
-						continue;
+				return cur;
+			};
+			if (nmov == 1) {
+				/*
+				 * One mover (most candidates: a long insertion of one sequence): the same sums without the
+				 * per-column count vectors.  Relative column q holds the mover's letter for q < B and one of its
+				 * gaps for B <= q < B + G.  After a slide by sh the vacated columns [0, sh) and the columns
+				 * [B + sh, B + G) that keep one of the mover's gaps score vac(q) (a prefix sum), and letter q
+				 * scores against column q + sh without the mover's own symbol there.
+				 */
+				const int B = block[0], G = minnext, n = B + G;
+				const char *row = seqp[(size_t)movers[0]] + off - 1;
+				vacp[0] = 0;
+				int current = 0;
+				for (int q = 0; q < n; ++q) {
+					const int o = q ? off : gap;
+					const int *sq = &sv_[(size_t)(col + dir * q + o) * kSym];
+					int wg;                                               /* gaps of the column once the mover has a gap there */
+					if (q < B) {
+						const int c = code_of(row[col + dir * q + o - off]);
+						codev[(size_t)q] = (signed char)c;
+						current += kMatch * (sq[c] - 1) + kMismatch * (numseqs - (sq[c] + sq[kGap])) + kIndel * sq[kGap];
+						wg = sq[kGap] + 1;
+					} else {
+						codev[(size_t)q] = kGap;
+						current += kDoubleGap * (sq[kGap] - 1) + kIndel * (numseqs - sq[kGap]);
+						wg = sq[kGap];
 					}
-					const int *mvp = &movv[(size_t)(j - sh) * kSym];
-					for (int y = 0; y < kSym; ++y) w[y] = statv[(size_t)j * kSym + y] + mvp[y];
-					if (w[kGap] == numseqs) continue;
-					int colscore = 0;
-					for (int y = 0; y < kGap; ++y)
-						if (mvp[y] != 0)
-							colscore += mvp[y] * (kMatch * (w[y] - 1) + kMismatch * (numseqs - (w[y] + w[kGap])) + kIndel * w[kGap]);
-					if (mvp[kGap] != 0) colscore += mvp[kGap] * (kDoubleGap * (w[kGap] - 1) + kIndel * (numseqs - w[kGap]));
-					shifted += colscore;
+					vacp[(size_t)q + 1] = vacp[(size_t)q] + (wg == numseqs ? 0 : kDoubleGap * (wg - 1) + kIndel * (numseqs - wg));
 				}
-				shifted -= current;
-				if (shifted >= bestscore) {                           /* :791 */
-					bestshift = dir * sh;
-					bestscore = shifted;
+				for (int sh = 1; sh <= G; ++sh) {
+					int shifted = vacp[(size_t)sh] + vacp[(size_t)n] - vacp[(size_t)B + sh];
+					for (int q = 0; q < B; ++q) {
+						const int j = q + sh, c = codev[(size_t)q], cj = codev[(size_t)j];
+						const int *sj = &sv_[(size_t)(col + dir * j + off) * kSym];
+						const int wc = sj[c] + 1 - (cj == c), wg = sj[kGap] - (cj == kGap);
+						if (wg == numseqs) continue;
+						shifted += kMatch * (wc - 1) + kMismatch * (numseqs - (wc + wg)) + kIndel * wg;
+					}
+					shifted -= current;
+					if (shifted >= bestscore) {                           /* :791 */
+						bestshift = dir * sh;
+						bestscore = shifted;
+					}
+				}
+				if (bestshift != 0 && bestshift * dir > 0) {              /* the arrays the winner is applied from */
+					build_arrays();
+					for (int y = 0; y < G; ++y) movv[(size_t)(B + y) * kSym + kGap]--;
+				}
+			} else {
+				const int current = build_arrays();
+				/* the columns a slide vacates hold the movers' gaps only: a prefix sum over the slide length */
+				vacp[0] = 0;
+				for (int j = 0; j < minnext; ++j) {
+					const int wg = statv[(size_t)j * kSym + kGap] + nmov;
+					vacp[(size_t)j + 1] = vacp[(size_t)j] + (wg == numseqs ? 0 : nmov * (kDoubleGap * (wg - 1) + kIndel * (numseqs - wg)));
+				}
+				for (int sh = 1; sh <= minnext; ++sh) {               /* :762-795 (workingsv is not kept: only its score is used) */
+					for (int t = 0; t < nmov; ++t) {
+						movv[(size_t)(affected[t] - 1) * kSym + kGap]--;
+						affected[t]--;
+					}
+					int shifted = vacp[(size_t)sh];
+					for (int j = sh; j < maxaff; ++j) {
+						const int *mvp = &movv[(size_t)(j - sh) * kSym];
+						const int *st = &statv[(size_t)j * kSym];
+						const int wg = st[kGap] + mvp[kGap];
+						if (wg == numseqs) continue;
+						int colscore = 0;
+						for (int y = 0; y < kGap; ++y)
+							if (mvp[y] != 0) {
+								const int wy = st[y] + mvp[y];
+								colscore += mvp[y] * (kMatch * (wy - 1) + kMismatch * (numseqs - (wy + wg)) + kIndel * wg);
+							}
+						if (mvp[kGap] != 0) colscore += mvp[kGap] * (kDoubleGap * (wg - 1) + kIndel * (numseqs - wg));
+						shifted += colscore;
+					}
+					shifted -= current;
+					if (shifted >= bestscore) {                       /* :791 */
+						bestshift = dir * sh;
+						bestscore = shifted;
+					}
 				}
 			}
 			if (bestshift != 0 && bestshift * dir > 0) {              /* :796-818 */
