@@ -62,35 +62,44 @@ __device__ __forceinline__ bool wait_lds(const int *counter, int need)
 }
 
 struct CellState {
-	int32_t hup;        /* X of the cell above (this column, previous row)              */
-	int32_t diag;       /* X of the cell above-left = what came from the left last step */
-	int32_t outv;       /* this lane's X of the current row, tag cleared                */
-	uint32_t outs;      /* the letter offset of the row this lane has just worked on    */
+	int32_t hup;        /* X of the cell above (this column, previous row)                              */
+	int32_t diag;       /* X of the cell above-left = what came from the left last step (ramp blocks);
+	                     * the hand-scheduled blocks keep D = that value + leftc instead                */
+	int32_t outv;       /* this lane's X of the current row, tag cleared                                */
+	uint32_t outs;      /* the letter offset of the row this lane has just worked on                    */
 };
 
-/* 32 steps.  inject[t] = (X, letter offset) entering lane 0 at step t; every lane stores what it hands
- * to the right to lanebuf[t] (the ring for lane 63, a scrap area for all others: no EXEC change);
- * words receives this lane's two direction words of the block (the caller stores them one block later).
- * A step is ~8 VALU instructions, far shorter than an LDS round trip, so nothing inside the step may wait
- * for LDS: the block's 32 inject entries are read into registers up front (64 VGPRs; all lanes read the
- * same address, only lane 0's copy is used), one wait per block, and the per-step hand-off stores are
- * never waited for. */
-template <bool WIDE, bool RAMP>
-__device__ __forceinline__ void cell_block(CellState &S, uint32_t tab, int32_t leftc, const uint2 *inject, uint2 *lanebuf,
-                                           uint32_t (&words)[kCellBlock / 16], int l0, int lane)
+/* What feeds lane 0 of a strip: the border column (the job's first strip), the ring of the wave to the
+ * left (same workgroup), or the previous chunk's hand-off granules in HBM (staged in `inject`).  One loop
+ * per role, so that the compiler's wait-count bookkeeping stays exact: with the three merged into one
+ * loop body every wave waited for ALL its outstanding global accesses -- the direction stores it had just
+ * issued -- once per 32-step block (s_waitcnt vmcnt(0) at the merge points). */
+enum { ROLE_FIRST = 0, ROLE_RING = 1, ROLE_CHUNK = 2 };
+
+/* byte t of the eight words that hold a block's 32 letter offsets */
+__device__ __forceinline__ uint32_t letter_of(const uint32_t (&lw)[kCellBlock / 4], int t) { return (lw[t >> 2] >> (8 * (t & 3))) & 0xffu; }
+
+/*
+ * The first two blocks of a strip (the ramp: a lane keeps its border values until its first row arrives),
+ * plain C++.  xin[t] = hand-off value entering lane 0 at step t (ROLE_FIRST: computed from the border
+ * column), lw = the block's letter offsets, lanebuf[t] = where this lane's value of step t goes (the ring
+ * for lane 63, a scrap area for all others: no EXEC change).
+ */
+template <bool WIDE, int ROLE>
+__device__ __forceinline__ void cell_block_ramp(CellState &S, uint32_t tab, int32_t leftc, const uint32_t *xin, int32_t xfirst, int32_t leftmul,
+                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[kCellBlock / 16],
+                                                int l0, int lane)
 {
 	uint32_t ioff = 0;
 	asm volatile("" : "+v"(ioff));                     /* keep the address in a VGPR: broadcast LDS reads */
-	uint2 inj[kCellBlock];
+	uint32_t inx[kCellBlock];
 #pragma unroll
-	for (int t = 0; t < kCellBlock; ++t) inj[t] = inject[ioff + t];
-	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-	__builtin_amdgcn_sched_barrier(0);                 /* the reads stay here, ahead of the steps */
+	for (int t = 0; t < kCellBlock; ++t) inx[t] = ROLE == ROLE_FIRST ? (uint32_t)(xfirst + leftmul * t) : xin[ioff + t];
 	uint32_t acc = 0;
 #pragma unroll
 	for (int t = 0; t < kCellBlock; ++t) {
-		const int32_t in = __builtin_amdgcn_update_dpp((int)inj[t].x, S.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)inj[t].y, (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
+		const int32_t in = __builtin_amdgcn_update_dpp((int)inx[t], S.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
+		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)letter_of(lw, t), (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
 		int32_t dg;
 		if (WIDE) dg = S.diag + 2 + (int32_t)(__builtin_amdgcn_ubfe(tab, sh, 6) << 3);    /* 6-bit counts: gain = 8*sv + 2 */
 		else dg = S.diag + (int32_t)__builtin_amdgcn_ubfe(tab, sh, 8);                    /* pre-scaled byte 8*sv + 2      */
@@ -98,78 +107,137 @@ __device__ __forceinline__ void cell_block(CellState &S, uint32_t tab, int32_t l
 		int32_t h = max(max(dg, S.hup), lf);
 		acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
 		h &= ~3;
-		if (RAMP) {
-			/* rows above the matrix: the lane keeps its border values until its first row arrives */
-			const bool live = l0 + t >= lane;
-			S.diag = live ? in : S.diag;
-			S.hup = live ? h : S.hup;
-		} else {
-			S.diag = in;
-			S.hup = h;
-		}
+		/* rows above the matrix: the lane keeps its border values until its first row arrives */
+		const bool live = l0 + t >= lane;
+		S.diag = live ? in : S.diag;
+		S.hup = live ? h : S.hup;
 		S.outv = S.hup;
 		S.outs = sh;
-		lanebuf[t] = make_uint2((uint32_t)S.outv, S.outs);
+		lanebuf[t] = (uint32_t)S.outv;
 		if ((t & 15) == 15) words[t >> 4] = acc;
 	}
 }
 
-}  // namespace
+/*
+ * The same 32 steps for all later blocks, hand-scheduled: ONE inline-assembly statement on fixed registers,
+ * generated by tools/gen_cells_block.py (csadp_cells_block.inc).  Measured on a wave alone on its SIMD
+ * (tools/cellstep_microbench.hip): a VALU instruction costs ~4.2 cycles whatever it is and whatever it depends
+ * on, an LDS store 16-27 cycles of the WAVE's issue time (b32 16, 2 x b32 20, b128 27), an LDS load ~6.  So:
+ *   - the value from the left and the column's gap term are ONE instruction (v_add_u32_dpp: lf = X[left
+ *     lane] + leftc; lane 0 has no source lane and keeps what the destination held: its hand-off value +
+ *     leftc, prepared at the head of the block);
+ *   - the letter offset runs one step ahead of the values (it only ever moves to the right), the next step's
+ *     diagonal candidate dg' = lf + gain'(letter') is finished inside this step: the table bytes are
+ *     pre-reduced by leftc (gain' = 8*sv + 2 - leftc), which makes lf + gain' = in + gain;
+ *   - only X is handed to the next strip (its lane 0 takes the letters from the row sequence, like every first
+ *     strip): lane 63's 32 values stay in registers and leave in 8 x ds_write_b128, 9 x ds_read_b128 bring the
+ *     next strip's in -- 17 LDS instructions per block where the plain form has 48.
+ * 7 VALU per step + 2 per step at the block's head (lane-0 presets of X and letter offset).
+ */
+#include "csadp_cells_block.inc"
 
-/* What feeds lane 0 of a strip: the border column and the row letters (the job's first strip), the ring
- * of the wave to the left (same workgroup), or the previous chunk's hand-off granules in HBM.  One loop
- * per role, so that the compiler's wait-count bookkeeping stays exact: with the three merged into one
- * loop body every wave waited for ALL its outstanding global accesses -- the direction stores it had just
- * issued -- once per 32-step block (s_waitcnt vmcnt(0) at the merge points). */
-enum { ROLE_FIRST = 0, ROLE_RING = 1, ROLE_CHUNK = 2 };
-constexpr int kFirstGroup = 8;                    /* blocks of row letters the first strip stages at once */
+template <bool WIDE, int ROLE>
+__device__ __forceinline__ void cell_block_fast(CellState &S, uint32_t tabf, int32_t leftc, const uint32_t *window, int32_t xfirst, int32_t leftmul,
+                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[kCellBlock / 16])
+{
+	int32_t outv = S.outv, dg = S.diag;
+	uint32_t sh = S.outs, w0, w1;
+	const uint32_t waddr = (uint32_t)(uintptr_t)lanebuf;       /* LDS byte address = low half of the generic pointer */
+	const uint32_t raddr = (uint32_t)(uintptr_t)window;
+	const int32_t c2 = 2 - leftc;
+#define CELLS_BLOCK_OPERANDS                                                                                                   \
+	: [outv] "+v"(outv), [dg] "+v"(dg), [sh] "+v"(sh), [w0] "=&v"(w0), [w1] "=&v"(w1)                                         \
+	: [tab] "v"(tabf), [leftc] "v"(leftc), [c2] "v"(c2), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst),            \
+	  [lm] "v"(leftmul), [l0] "s"(lw[0]), [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]),                 \
+	  [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7])                                                                       \
+	: CELLS_BLOCK_CLOBBERS
+	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
+	else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
+	else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
+	else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
+#undef CELLS_BLOCK_OPERANDS
+	S.outv = outv;
+	S.hup = outv;
+	S.diag = dg;
+	S.outs = sh;
+	words[0] = w0;
+	words[1] = w1;
+}
+
+constexpr int kRingWords = kRingSteps + 2 * kCellBlock;    /* the ring + the mirror of its first two blocks */
+constexpr int kInjectWords = 40;                           /* X of step t at word 3 + t: the same 9 x 16-byte window as the ring's */
+constexpr int kScrapWords = 4 * kLanes + 64;               /* lane l: 16 bytes at 16 l (+ 16 q per store of a block) */
+
+/* A hand-off granule requested far ahead.  The request is inline assembly so that the compiler's wait counts do
+ * not know it: its own waits (vmcnt(0) at every merge point of the loop below) would otherwise wait for the
+ * request issued one block ago, i.e. for a trip through memory per block.  `dst` holds 0 (never a valid epoch)
+ * until the data arrives; should the compiler ever copy the register before that, the copy fails validation and
+ * the granule is simply read again. */
+__device__ __forceinline__ void granule_request(unsigned long long &dst, const unsigned long long *p)
+{
+	asm volatile("global_load_dwordx2 %0, %1, off sc1" : "+v"(dst) : "v"(p) : "memory");
+}
+/* the rare second look at a granule that had not arrived: request and wait in one piece */
+__device__ __forceinline__ void granule_reload(unsigned long long &dst, const unsigned long long *p)
+{
+	asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "+v"(dst) : "v"(p) : "memory");
+}
+/* vmcnt counts in order and EVERY block issues exactly one request after consuming one: when a request is due,
+ * exactly one younger request is in flight (and possibly the two direction stores between them, a block old) */
+__device__ __forceinline__ void granule_wait(unsigned long long &dst) { asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory"); }
 
 struct StripShared {
-	uint2 *ring_mine;            /* ring[wv]                           */
-	const uint2 *ring_prev;      /* ring[wv - 1]                       */
-	uint2 *inject_mine;          /* inject[wv]                         */
-	uint2 *first_inject;         /* kFirstGroup * kCellBlock entries   */
-	uint2 *scrap_mine;           /* scrap[wv]                          */
+	uint32_t *ring_mine;         /* ring[wv]       */
+	const uint32_t *ring_prev;   /* ring[wv - 1]   */
+	uint32_t *inject_mine;       /* inject[wv]     */
+	uint32_t *scrap_mine;        /* scrap[wv]      */
 	int *made, *taken;
 };
 
 template <bool WIDE, int ROLE>
-__device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, CellState &S, uint32_t tab, int32_t leftc, uint32_t *dirs,
+__device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, CellState &S, uint32_t tab, uint32_t tabf, int32_t leftc, uint32_t *dirs,
                                           const StripShared &L, unsigned long long *hand_out, const unsigned long long *hand_in, int wv,
                                           int lane, int nb, bool feeds, bool publishes, uint32_t epoch)
 {
 	const int t = lane & 31;
-	/* ROLE_FIRST: the letters of kFirstGroup blocks = 256 rows, one dword per lane, requested one group ahead */
-	uint32_t letters = 0;
-	if (ROLE == ROLE_FIRST) letters = *reinterpret_cast<const uint32_t *>(rsh + 4 * lane);
-	/* ROLE_CHUNK: 8-byte granules {X, letter offset | epoch << 8}, each written by ONE write-through store and
-	 * valid exactly when it carries this launch's epoch -- no counter, no fence, one memory round trip, and
-	 * that one is hidden: the granules of block b + 1 are requested while block b is computed and only
-	 * re-read (bounded) if they had not arrived. */
-	unsigned long long pre = 0;
-	if (ROLE == ROLE_CHUNK && 63 + t < J.steps_pad) pre = __hip_atomic_load(hand_in + 63 + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	/* the letter offsets of a block's 32 rows: eight uniform words (scalar loads), requested one block ahead;
+	 * the same for every strip -- lane 0 of each takes them from here, the others get them through DPP */
+	/* (constant address space: the row table is written by the host only, so these become scalar loads, counted
+	 * apart from the vector memory accesses) */
+	typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
+	ConstWords rw = (ConstWords)(uintptr_t)rsh;
+	uint32_t nx[kCellBlock / 4];
+#pragma unroll
+	for (int q = 0; q < kCellBlock / 4; ++q) nx[q] = rw[q];
+	/* ROLE_CHUNK: 8-byte granules {X, epoch << 8}, each written by ONE write-through store and valid exactly
+	 * when it carries this launch's epoch -- no counter, no fence, one memory round trip, and that one is
+	 * hidden: the granules of block b + 2 are requested while block b is computed and only re-read (bounded)
+	 * if they had not arrived.  TWO blocks ahead, because producer and consumer usually sit on different XCDs and
+	 * the round trip through memory (~1.3 us) is longer than a block (~0.8 us); the loop below is unrolled by two
+	 * so that each of the two requests in flight has its own register and no copy waits for it early. */
+	unsigned long long preA = 0, preB = 0;
+	const int last_granule = J.steps_pad - 1;                   /* requests past the end repeat this one; nobody looks at them */
+	if (ROLE == ROLE_CHUNK) {
+		granule_request(preA, hand_in + min(63 + t, last_granule));
+		granule_request(preB, hand_in + min(kCellBlock + 63 + t, last_granule));
+	}
 	/* Order of global accesses.  The compiler's wait before the first use of a loaded value is
 	 * s_waitcnt vmcnt(0): it also waits for every store issued since.  So a block first consumes what was
 	 * loaded for it, THEN stores the direction words of the previous block and requests the next block's
 	 * data: everything a wait can see was issued a whole block (~1 us) earlier and costs nothing. */
 	uint32_t words[kCellBlock / 16] = {0, 0};
-	for (int b = 0; b < nb; ++b) {
-		const uint2 *src = L.inject_mine;                     /* where lane 0's inputs of this block are read from */
-		if (ROLE == ROLE_FIRST) {
-			if (b % kFirstGroup == 0) {
-				/* lane l builds rows 4l + 1 .. 4l + 4 of the group: border column X[r][0] = leftmul * r (:967) */
-				const int r0 = b * kCellBlock + 4 * lane + 1;
+	auto block = [&](int b, unsigned long long &pre) -> bool {
+		uint32_t lw[kCellBlock / 4];
 #pragma unroll
-				for (int u = 0; u < 4; ++u)
-					L.first_inject[4 * lane + u] = make_uint2((uint32_t)(J.leftmul * (r0 + u)), (letters >> (8 * u)) & 0xffu);
-			}
-			src = L.first_inject + (b % kFirstGroup) * kCellBlock;
-		} else if (ROLE == ROLE_RING) {
+		for (int q = 0; q < kCellBlock / 4; ++q) lw[q] = nx[q];
+		const uint32_t *window = L.inject_mine;                 /* 16-byte aligned; X of step t at word 3 + t */
+		if (ROLE == ROLE_RING) {
 			const int need = (b + 3 < nb) ? b + 3 : nb;           /* producer steps up to 32b + 94 */
 			if (!wait_lds(&L.made[wv - 1], need)) return false;
-			src = L.ring_prev + (b * kCellBlock + 63) % kRingSteps;  /* 32 consecutive slots thanks to the mirror */
-		} else {
+			window = L.ring_prev + (b * kCellBlock + 60) % kRingSteps;   /* 36 consecutive words thanks to the mirror */
+		} else if (ROLE == ROLE_CHUNK) {
 			const int ps = b * kCellBlock + 63 + t;               /* the producer's lane 63 is 63 steps ahead */
+			granule_wait(pre);
 			unsigned long long v = pre;
 			int spins = 0;
 			for (;;) {
@@ -177,31 +245,36 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 				if (__all(ok)) break;
 				__builtin_amdgcn_s_sleep(2);
 				if (++spins > kSpinMax) return false;
-				if (!ok) v = __hip_atomic_load(hand_in + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (!ok) granule_reload(v, hand_in + ps);
 			}
-			if (lane < kCellBlock) L.inject_mine[lane] = make_uint2((uint32_t)v, (uint32_t)(v >> 32) & 0xffu);
+			if (lane < kCellBlock) L.inject_mine[3 + lane] = (uint32_t)v;
 		}
 		if (b > 0) {
 			uint32_t *d = dirs + (size_t)(b - 1) * (kCellBlock / 16) * kLanes;
 			d[0] = words[0];
 			d[kLanes] = words[1];
 		}
-		if (ROLE == ROLE_FIRST && b % kFirstGroup == 0)         /* rowshift is padded by two groups */
-			letters = *reinterpret_cast<const uint32_t *>(rsh + (b / kFirstGroup + 1) * (kFirstGroup * kCellBlock) + 4 * lane);
+#pragma unroll
+		for (int q = 0; q < kCellBlock / 4; ++q) nx[q] = rw[(b + 1) * (kCellBlock / 4) + q];   /* rowshift is padded */
 		if (ROLE == ROLE_CHUNK) {
-			const int ps = (b + 1) * kCellBlock + 63 + t;
-			if (ps < J.steps_pad) pre = __hip_atomic_load(hand_in + ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			pre = 0;
+			granule_request(pre, hand_in + min((b + 2) * kCellBlock + 63 + t, last_granule));
 		}
 		const bool ringer = lane == kLanes - 1 && (feeds || publishes);
-		uint2 *lanebuf = ringer ? L.ring_mine + (b * kCellBlock) % kRingSteps : L.scrap_mine + lane;
+		uint32_t *lanebuf = ringer ? L.ring_mine + (b * kCellBlock) % kRingSteps : L.scrap_mine + 4 * lane;
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, which the consumer reads during its
 			 * blocks b - kRing - 2 and b - kRing - 1 */
 			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
 		}
-		if (b < 2) cell_block<WIDE, true>(S, tab, leftc, src, lanebuf, words, b * kCellBlock, lane);
-		else cell_block<WIDE, false>(S, tab, leftc, src, lanebuf, words, b * kCellBlock, lane);
-		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers (cell_block waits) */
+		const int32_t xfirst = J.leftmul * (b * kCellBlock + 1);   /* border column: X[r][0] = leftmul * r (:967) */
+		if (b < 2) {
+			cell_block_ramp<WIDE, ROLE>(S, tab, leftc, window + 3, xfirst, J.leftmul, lw, lanebuf, words, b * kCellBlock, lane);
+			if (b == 1) S.diag += leftc;                        /* the hand-scheduled blocks keep D = diag + leftc */
+		} else {
+			cell_block_fast<WIDE, ROLE>(S, tabf, leftc, window, xfirst + leftc, J.leftmul, lw, lanebuf, words);
+		}
+		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers */
 			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (feeds || publishes) {
 			if ((b * kCellBlock) % kRingSteps < 2 * kCellBlock) {  /* mirror the ring's first two blocks behind its end */
@@ -219,12 +292,16 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		if (publishes) {
 			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			if (lane < kCellBlock) {
-				const uint2 v = L.ring_mine[(b * kCellBlock) % kRingSteps + lane];
-				__hip_atomic_store(hand_out + b * kCellBlock + lane,
-				                   (unsigned long long)v.x | ((unsigned long long)((v.y & 0xffu) | (epoch << 8)) << 32), __ATOMIC_RELAXED,
-				                   __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t x = L.ring_mine[(b * kCellBlock) % kRingSteps + lane];
+				__hip_atomic_store(hand_out + b * kCellBlock + lane, (unsigned long long)x | ((unsigned long long)(epoch << 8) << 32),
+				                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
 		}
+		return true;
+	};
+	for (int b = 0; b < nb; b += 2) {
+		if (!block(b, preA)) return false;
+		if (b + 1 < nb && !block(b + 1, preB)) return false;
 	}
 	{
 		uint32_t *d = dirs + (size_t)(nb - 1) * (kCellBlock / 16) * kLanes;
@@ -234,17 +311,18 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	return true;
 }
 
+}  // namespace
+
 template <bool WIDE>
 __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
                                                                     const TileRef *__restrict__ work, uint32_t epoch,
                                                                     int *__restrict__ abort_word)
 {
-	/* the ring is mirrored: a block written to slots [0, 64) is also written to [256, 320), so that the 32
-	 * consecutive slots a consumer block needs never wrap and can be read in place (no staging copy) */
-	__shared__ __attribute__((aligned(16))) uint2 ring[kCellWaves][kRingSteps + 2 * kCellBlock];
-	__shared__ __attribute__((aligned(16))) uint2 inject[kCellWaves][kCellBlock];
-	__shared__ __attribute__((aligned(16))) uint2 first_inject[kFirstGroup * kCellBlock];
-	__shared__ uint2 scrap[kCellWaves][kLanes + kCellBlock];   /* lane l, step t -> slot l + t: conflict-free */
+	/* the ring is mirrored: a block written to words [0, 64) is also written to [256, 320), so that the 36
+	 * consecutive words a consumer block reads never wrap */
+	__shared__ __attribute__((aligned(16))) uint32_t ring[kCellWaves][kRingWords];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[kCellWaves][kInjectWords];
+	__shared__ __attribute__((aligned(16))) uint32_t scrap[kCellWaves][kScrapWords];
 	__shared__ int made[kCellWaves], taken[kCellWaves];
 
 	const TileRef item = work[blockIdx.x];
@@ -281,14 +359,21 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	L.ring_mine = ring[wv];
 	L.ring_prev = ring[wv > 0 ? wv - 1 : 0];
 	L.inject_mine = inject[wv];
-	L.first_inject = first_inject;
 	L.scrap_mine = scrap[wv];
 	L.made = made;
 	L.taken = taken;
+	/* table of the hand-scheduled blocks: gain bytes reduced by leftc (8*sv + 2 - leftc = 8*sv + 4*(i - gaps) + 1 <= 12*i + 1:
+	 * the host takes the WIDE form from i = 22 on); WIDE keeps the counts and adds 2 - leftc in the step */
+	uint32_t tabf = tab;
+	if (!WIDE) {
+		tabf = 0;
+#pragma unroll
+		for (int y = 0; y < 4; ++y) tabf |= ((((tab >> (8 * y)) & 255u) - (uint32_t)leftc) & 255u) << (8 * y);
+	}
 	bool ok;
-	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, tab, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
-	else if (wv > 0) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, tab, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
-	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, tab, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, tab, tabf, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	else if (wv > 0) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, tab, tabf, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, tab, tabf, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
 	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }
 

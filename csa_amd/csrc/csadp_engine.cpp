@@ -479,7 +479,7 @@ int FillBatch::layout_cells()
 		const long long nprev = J.nprev;
 		if (nprev < 1 || nprev > 63) return CSADP_ERR_ARG;
 		if (nprev * (2LL * J.nrows + J.ncols) * 4 + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
-		if (nprev > 31) wide_ = true;
+		if (nprev > 21) wide_ = true;                  /* nw_fill_cells folds leftc into the gain bytes: 12 * nprev + 1 <= 255 */
 		CellJob &C = cjobs_[(size_t)j];
 		memset(&C, 0, sizeof(C));
 		C.nrows = J.nrows;
