@@ -55,7 +55,6 @@ __device__ __forceinline__ bool wait_lds(const int *counter, int need)
 {
 	int spins = 0;
 	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-		__builtin_amdgcn_s_sleep(1);
 		if (++spins > kSpinMax) return false;
 	}
 	return true;
@@ -75,6 +74,8 @@ struct CellState {
  * loop body every wave waited for ALL its outstanding global accesses -- the direction stores it had just
  * issued -- once per 32-step block (s_waitcnt vmcnt(0) at the merge points). */
 enum { ROLE_FIRST = 0, ROLE_RING = 1, ROLE_CHUNK = 2 };
+constexpr int kGranuleAhead = 2;                 /* hand-off granules are requested this many blocks ahead (= unroll of the block loop);
+                                                  * 4 was measured: long matrices -3 %, many-strip matrices +5 % (more lag per chunk) */
 
 /* byte t of the eight words that hold a block's 32 letter offsets */
 __device__ __forceinline__ uint32_t letter_of(const uint32_t (&lw)[kCellBlock / 4], int t) { return (lw[t >> 2] >> (8 * (t & 3))) & 0xffu; }
@@ -226,6 +227,13 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	 * loaded for it, THEN stores the direction words of the previous block and requests the next block's
 	 * data: everything a wait can see was issued a whole block (~1 us) earlier and costs nothing. */
 	uint32_t words[kCellBlock / 16] = {0, 0};
+	int known_taken = 0;
+	uint32_t pubx = 0;
+	auto publish = [&](int b) {
+		if (lane < kCellBlock)
+			__hip_atomic_store(hand_out + b * kCellBlock + lane, (unsigned long long)pubx | ((unsigned long long)(epoch << 8) << 32),
+			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	};
 	auto block = [&](int b, unsigned long long &pre) -> bool {
 		uint32_t lw[kCellBlock / 4];
 #pragma unroll
@@ -249,6 +257,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			}
 			if (lane < kCellBlock) L.inject_mine[3 + lane] = (uint32_t)v;
 		}
+		if (publishes && b > 0) publish(b - 1);
 		if (b > 0) {
 			uint32_t *d = dirs + (size_t)(b - 1) * (kCellBlock / 16) * kLanes;
 			d[0] = words[0];
@@ -258,14 +267,16 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		for (int q = 0; q < kCellBlock / 4; ++q) nx[q] = rw[(b + 1) * (kCellBlock / 4) + q];   /* rowshift is padded */
 		if (ROLE == ROLE_CHUNK) {
 			pre = 0;
-			granule_request(pre, hand_in + min((b + 2) * kCellBlock + 63 + t, last_granule));
+			granule_request(pre, hand_in + min((b + kGranuleAhead) * kCellBlock + 63 + t, last_granule));
 		}
 		const bool ringer = lane == kLanes - 1 && (feeds || publishes);
 		uint32_t *lanebuf = ringer ? L.ring_mine + (b * kCellBlock) % kRingSteps : L.scrap_mine + 4 * lane;
-		if (feeds) {
+		if (feeds && b - kRing > known_taken) {
 			/* the ring slots of this block last held block b - kRing, which the consumer reads during its
-			 * blocks b - kRing - 2 and b - kRing - 1 */
+			 * blocks b - kRing - 2 and b - kRing - 1; the consumer's progress is only looked up when the last
+			 * value seen does not cover this block */
 			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
+			known_taken = __hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		const int32_t xfirst = J.leftmul * (b * kCellBlock + 1);   /* border column: X[r][0] = leftmul * r (:967) */
 		if (b < 2) {
@@ -278,31 +289,27 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		if (feeds || publishes) {
 			if ((b * kCellBlock) % kRingSteps < 2 * kCellBlock) {  /* mirror the ring's first two blocks behind its end */
-				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-				if (lane < kCellBlock) {
+				if (lane < kCellBlock) {                            /* (no wait: the LDS runs this wave's accesses in order) */
 					const int at = (b * kCellBlock) % kRingSteps + lane;
 					L.ring_mine[kRingSteps + at] = L.ring_mine[at];
 				}
 			}
 		}
 		if (feeds) {
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          /* this block's ring stores have been executed */
+			/* no wait: the LDS executes this wave's stores in the order they were issued, so whoever sees the
+			 * counter sees the block's ring words (and the mirror copy above) */
 			if (lane == kLanes - 1) __hip_atomic_store(&L.made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		if (publishes) {
-			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-			if (lane < kCellBlock) {
-				const uint32_t x = L.ring_mine[(b * kCellBlock) % kRingSteps + lane];
-				__hip_atomic_store(hand_out + b * kCellBlock + lane, (unsigned long long)x | ((unsigned long long)(epoch << 8) << 32),
-				                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
+		/* the block's 32 values for the next chunk: read back from the ring now (in order behind the block's
+		 * stores), sent at the head of the next block, when the LDS round trip has long passed */
+		if (publishes && lane < kCellBlock) pubx = L.ring_mine[(b * kCellBlock) % kRingSteps + lane];
 		return true;
 	};
-	for (int b = 0; b < nb; b += 2) {
+	for (int b = 0; b < nb; b += kGranuleAhead) {
 		if (!block(b, preA)) return false;
 		if (b + 1 < nb && !block(b + 1, preB)) return false;
 	}
+	if (publishes) publish(nb - 1);
 	{
 		uint32_t *d = dirs + (size_t)(nb - 1) * (kCellBlock / 16) * kLanes;
 		d[0] = words[0];
