@@ -82,7 +82,7 @@ constexpr int kCkptWords = kBitCkptWords;
  * row's [32][16] tile. */
 enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
 
-template <bool RAMPIN, bool FEEDS, int OUT, int W, bool MATCHES = false>
+template <bool RAMPIN, bool FEEDS, int OUT, int W, bool MATCHES = false, bool AHEAD = false>
 __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[W], const uint32_t (&B1)[W], const uint32_t *inject,
                                            uint32_t *lanebuf, uint2 *dirs, int l0, int lane, uint32_t *matches = nullptr)
 {
@@ -94,16 +94,31 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[
 	constexpr bool ROWS = (OUT == OUT_TILE);
 	constexpr int ostride = ROWS ? 16 : kLanes;
 	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15) * W;
-	/* the word entering the row's first lane is fetched from LDS one step ahead, straight into the
-	 * register the DPP move then completes (address kept in a VGPR) */
+	/* The words entering the row's first lane come from LDS (address kept in a VGPR: broadcast reads), each
+	 * into the register the DPP move of its step then completes.  AHEAD = false: fetched one step ahead -- with
+	 * several waves per SIMD the round trip disappears behind the other waves.  AHEAD = true (the launches that
+	 * run ONE wave per SIMD): all 32 up front; a lone wave otherwise waits out an LDS round trip in every step,
+	 * 235 cycles per step where its 31 VALU instructions take 130 (tools/cellstep_microbench.hip).  Up-front
+	 * reads in the many-wave kernel cost 12 % of its throughput (measured), hence the switch. */
 	uint32_t ioff = 0;
 	asm volatile("" : "+v"(ioff));
-	uint32_t cur = inject[ioff];
+	const uint32_t *ip = reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(inject, 16)) + ioff;
+	uint32_t inj[AHEAD ? kBitBlock : 1];
+	uint32_t cur = ip[0];
+	if (AHEAD) {
+#pragma unroll
+		for (int t = 0; t < kBitBlock; ++t) inj[AHEAD ? t : 0] = ip[t];
+	}
 #pragma unroll
 	for (int t = 0; t < kBitBlock; ++t) {
-		const uint32_t nxt = inject[ioff + (t + 1 < kBitBlock ? t + 1 : t)];
-		const uint32_t in = from_left<ROWS>(cur, S.PP);
-		cur = nxt;
+		uint32_t in;
+		if (AHEAD) {
+			in = from_left<ROWS>(inj[AHEAD ? t : 0], S.PP);
+		} else {
+			const uint32_t nxt = ip[t + 1 < kBitBlock ? t + 1 : t];
+			in = from_left<ROWS>(cur, S.PP);
+			cur = nxt;
+		}
 		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 0, 1);
 		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 1, 1);
 		uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
@@ -204,15 +219,24 @@ __device__ __forceinline__ void load_state(const uint4 *ck, size_t idx, BitState
 	}
 }
 
+/* Counters in LDS that order LDS data only: the LDS executes one wave's accesses in the order they were issued
+ * and is coherent inside the compute unit, so relaxed accesses suffice (a reader that sees the counter sees the
+ * ring words stored before it; a ring word read before `taken` is stored was read before anyone can see
+ * `taken`).  The round-1 form -- acquire loads, a workgroup-scope release fence before each counter store --
+ * also drained the wave's outstanding checkpoint and mark stores (s_waitcnt vmcnt(0)) twice per 32-step block:
+ * a round trip to memory on the path between two strips. */
 __device__ __forceinline__ bool wait_at_least(const int *counter, int need)
 {
 	int spins = 0;
-	while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-		__builtin_amdgcn_s_sleep(2);
+	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
 		if (++spins > kSpinMax) return false;
 	}
 	return true;
 }
+
+/* the row planes are written before the launch (host, or nw_pack_planes in an earlier kernel) and only read here:
+ * through the constant address space they become scalar loads, counted apart from the vector memory accesses */
+typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
 
 }  // namespace
 
@@ -253,7 +277,8 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 		B0[h] = cp[(s * kLanes + lane) * W + h];
 		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
 	}
-	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
+	ConstWords rp = (ConstWords)(uintptr_t)(arena + J.rowplanes);
+	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                /* requested one block ahead */
 	uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
 	const bool feeds = s + 1 < J.nstrips;
 	/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
@@ -266,6 +291,9 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 	for (int h = 0; h < W; ++h) {
 		S.nH0[h] = ~0u;
 		S.H1[h] = S.H2[h] = 0;
+		/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
+		 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
+		asm volatile("" : "+v"(B0[h]), "+v"(B1[h]));
 	}
 	S.PP = 0;
 	for (int b = 0; b < nb; ++b) {
@@ -277,10 +305,13 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 			if (!wait_at_least(&made[s - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 			const int ps = b * kBitBlock + 63 + (lane & 31);
 			if (ps < J.steps_pad) word = ring[s - 1][ps % kRingSteps] & 0xffffff00u;
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == 0) __hip_atomic_store(&taken[s], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (lane == 0) __hip_atomic_store(&taken[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
+		const uint32_t a0 = a0n, a1 = a1n;
+		if (b + 1 < nb) {
+			a0n = rp[b + 1];
+			a1n = rp[J.rowwords + b + 1];
+		}
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[s][lane] = word;
 		uint32_t *lanebuf = !writes ? &scrap[s][lane] : (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
@@ -304,10 +335,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 			    (g == 0) ? mbuf[s][2][t] : (feeds ? ring[s][(b * kBitBlock + t) % kRingSteps] : 0u);
 			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
-		if (feeds) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == kLanes - 1) __hip_atomic_store(&made[s], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
+		if (feeds && lane == kLanes - 1) __hip_atomic_store(&made[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 }
 
@@ -362,7 +390,8 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 
 	const int nb = J.steps_pad / kBitBlock;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
-	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
+	ConstWords rp = (ConstWords)(uintptr_t)(arena + J.rowplanes);
+	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                /* requested one block ahead */
 	uint32_t B0[W], B1[W];
 #pragma unroll
 	for (int h = 0; h < W; ++h) {
@@ -383,6 +412,9 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 	for (int h = 0; h < W; ++h) {
 		S.nH0[h] = ~0u;
 		S.H1[h] = S.H2[h] = 0;
+		/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
+		 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
+		asm volatile("" : "+v"(B0[h]), "+v"(B1[h]));
 	}
 	S.PP = 0;
 	/* the previous chunk's words for block 0, requested now; inside the loop always one block ahead */
@@ -397,8 +429,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 		if (wv > 0) {
 			if (!wait_at_least(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 			if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		} else if (from_left_chunk) {
 			uint32_t v = pre;
 			int spins = 0;
@@ -412,7 +443,11 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 			if (ps + kBitBlock < J.steps_pad) pre = __hip_atomic_load(&left_marks[ps + kBitBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			if (ps < J.steps_pad) word = v & kMarkPayload;
 		}
-		const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
+		const uint32_t a0 = a0n, a1 = a1n;
+		if (b + 1 < nb) {
+			a0n = rp[b + 1];
+			a1n = rp[J.rowwords + b + 1];
+		}
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[wv][lane] = word;
 		uint32_t *lanebuf = !writes ? &scrap[wv][lane] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
@@ -421,8 +456,8 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
 			if (!wait_at_least(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
-		if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
-		else bits_block<false, true, OUT, W>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
+		if (b < 2) bits_block<true, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
+		else bits_block<false, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
 		{
 			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
 			const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
@@ -437,10 +472,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 			}
 			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
-		if (feeds) {
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-			if (lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
+		if (feeds && lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	}
 }
 
