@@ -337,10 +337,12 @@ def test_config5_mixed_lengths_sample():
             assert g["aligned"] == strs and g["score"] == st.last_score
 
 
-@pytest.mark.parametrize("nseq", [33, 40, 64])
+@pytest.mark.parametrize("nseq", [22, 23, 24, 33, 40, 64])
 def test_wide_profile_more_than_32_sequences(nseq, profile_mode):
-    """i >= 32 switches the batch to the 6-bit-count table format (csadp_device.h); 64 is the
-    reference's MAXNUMBEROFSEQS (csamsa.c:23)."""
+    """Many sequences switch a round to the 6-bit-count table format (csadp_device.h): the tiled kernel from
+    i = 32 on, nw_fill_cells from i = 22 on (its byte form folds the column's gap term into the gain bytes:
+    12 i + 1 <= 255); 22 / 23 / 24 sequences sit on that boundary.  64 is the reference's MAXNUMBEROFSEQS
+    (csamsa.c:23)."""
     r = rng(1000 + nseq)
     fam = random_family(r, nseq, 150, mut=0.08, indel=0.05)
     rots = [r.randrange(len(f)) for f in fam]
@@ -348,6 +350,23 @@ def test_wide_profile_more_than_32_sequences(nseq, profile_mode):
     got = csa_amd.align_batch([(fam, rots, None, None), (small, None, None, None)])
     for task, g in zip([(fam, rots), (small, None)], got):
         cons, strs, st = oracle_progressive(task[0], task[1])
+        assert g["status"] == 0 and g["consensus"] == cons
+        assert g["aligned"] == strs
+        assert g["score"] == st.last_score and g["fills"] == st.fills
+
+
+def test_folded_gain_bytes_at_their_bounds(profile_mode):
+    """nw_fill_cells' byte table holds 8 sv + 2 - leftc per letter.  Its extremes: 21 identical sequences
+    already aligned (sv = i, no gaps: 12 i + 1 = 253 at the last byte-form step) and columns that are almost
+    all gaps (leftc = 1, sv = 0).  Both families also cross into the 6-bit-count form at i = 22."""
+    r = rng(77)
+    base = bytes(r.choice(b"ACGT") for _ in range(300))
+    same = [base] * 24
+    # one long sequence first, then many short ones: most columns of the profile are gaps for most rows
+    gappy = [bytes(r.choice(b"ACGT") for _ in range(400))] + [bytes(r.choice(b"ACGT") for _ in range(40)) for _ in range(23)]
+    got = csa_amd.align_batch([(same, None, None, None), (gappy, None, None, None)])
+    for fam, g in zip([same, gappy], got):
+        cons, strs, st = oracle_progressive(fam, None)
         assert g["status"] == 0 and g["consensus"] == cons
         assert g["aligned"] == strs
         assert g["score"] == st.last_score and g["fills"] == st.fills
