@@ -225,10 +225,15 @@ __device__ __forceinline__ void load_state(const uint4 *ck, size_t idx, BitState
  * `taken`).  The round-1 form -- acquire loads, a workgroup-scope release fence before each counter store --
  * also drained the wave's outstanding checkpoint and mark stores (s_waitcnt vmcnt(0)) twice per 32-step block:
  * a round trip to memory on the path between two strips. */
+/* TIGHT: poll without sleeping.  Measured both ways per kernel: the one-workgroup-per-job kernel (+3 % of `value`) and the
+ * one-wave-per-SIMD launches poll tightly; the chunked launches with 2 or 4 waves per SIMD sleep between polls (config 5:
+ * 38.9 vs 40.1 ms per pass) */
+template <bool TIGHT = false>
 __device__ __forceinline__ bool wait_at_least(const int *counter, int need)
 {
 	int spins = 0;
 	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
+		if (!TIGHT) __builtin_amdgcn_s_sleep(2);
 		if (++spins > kSpinMax) return false;
 	}
 	return true;
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 		uint32_t word = 0;
 		if (s > 0) {
 			const int need = (b + 3 < nb) ? b + 3 : nb;         /* producer steps up to 32b + 94 */
-			if (!wait_at_least(&made[s - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!wait_at_least<true>(&made[s - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 			const int ps = b * kBitBlock + 63 + (lane & 31);
 			if (ps < J.steps_pad) word = ring[s - 1][ps % kRingSteps] & 0xffffff00u;
 			if (lane == 0) __hip_atomic_store(&taken[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
-			if (!wait_at_least(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!wait_at_least<true>(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
 		if (feeds || CKPT) {
 			if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 		const int ps = b * kBitBlock + 63 + (lane & 31);
 		const int need = (b + 3 < nb) ? b + 3 : nb;             /* producer steps up to 32b + 94 */
 		if (wv > 0) {
-			if (!wait_at_least(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!wait_at_least<WAVES == 4>(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 			if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
 			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		} else if (from_left_chunk) {
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
-			if (!wait_at_least(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!wait_at_least<WAVES == 4>(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
 		if (b < 2) bits_block<true, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
 		else bits_block<false, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
