@@ -438,36 +438,30 @@ __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ 
 			 * strips, whose window origins are fetched with v_readlane instead of a second LDS round trip */
 			const int wreg = lane < kTbStrips ? wlo[lane] : 0;
 			for (;;) {
-				const int ri = j - lane, ki = k - lane;
-				const int Bk = s0 - ((k - 1) >> 6);             /* strip block of lane 0's cell (wave-uniform) */
+				/* one iteration = one LDS look-up per lane, straight-line: lane i looks at cell (j - i, k - i) */
+				const int kc = k - 1;                           /* 0-based column of lane 0's cell */
+				const int Bk = s0 - (kc >> 6);                  /* its strip block (wave-uniform) */
 				if (Bk >= kTbStrips) break;
 				const int wloA = __builtin_amdgcn_readlane(wreg, Bk);
 				const int wloB = __builtin_amdgcn_readlane(wreg, Bk + 1 < kTbStrips ? Bk + 1 : Bk);
-				uint32_t code = 3;                              /* 3 = stop: border or outside the window */
-				if (ri > 0 && ki > 0) {
-					const int sc = (ki - 1) >> 6;
-					const int B = s0 - sc;
-					if (B < kTbStrips) {
-						const int l = ri + ki - 2 - 64 * sc;
-						const int u = (l >> 4) - (B == Bk ? wloA : wloB);
-						if (u >= 0 && u < kTbWords) code = (win[(B * kTbWords + u) * kLanes + ((ki - 1) & 63)] >> (2 * (l & 15))) & 3u;
-					}
-				}
-				/* a run of 'D' and the gap move that ends it are taken in ONE iteration */
+				const int ri = j - lane, kz = kc - lane;        /* row (1-based), column (0-based): outside the matrix when <= 0 / < 0 */
+				const int sc = kz >> 6;                         /* arithmetic: negative columns give a strip that fails the tests below */
+				const int B = s0 - sc;
+				const int l = ri + kz - 1 - (kz & ~63);         /* local step of the cell in its strip */
+				const int u = (l >> 4) - (sc == (kc >> 6) ? wloA : wloB);
+				const bool ok = (ri > 0) & (kz >= 0) & (B < kTbStrips) & ((unsigned)u < (unsigned)kTbWords);
+				const uint32_t w = win[ok ? (B * kTbWords + u) * kLanes + (kz & 63) : 0];
+				const uint32_t code = ok ? (w >> (2 * (l & 15))) & 3u : 3u;     /* 3 = stop: border or outside the window */
+				/* a run of 'D' and the gap move that ends it are taken in ONE iteration, written by ONE store */
 				const unsigned long long stop = __ballot(code != DIR_D);
 				const int run = stop ? __builtin_ctzll(stop) : kLanes;
 				const uint32_t c0 = run < kLanes ? (uint32_t)__builtin_amdgcn_readlane((int)code, run) : 3u;
-				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
-				n += run;
-				j -= run;
-				k -= run;
-				if (c0 == 3) {
-					if (run == 0) break;                        /* border reached or window left: the outer loop decides */
-					continue;
-				}
-				if (lane == 0) ops[n] = (uint8_t)c0;
-				++n;
-				if (c0 == DIR_L) --k; else --j;
+				const int gap = c0 != 3u;
+				if (lane < run + gap) ops[n + lane] = (uint8_t)(lane < run ? (uint32_t)DIR_D : c0);
+				n += run + gap;
+				j -= run + (gap & (c0 != DIR_L));
+				k -= run + (c0 == DIR_L);
+				if (run + gap == 0) break;                      /* border reached or window left: the outer loop decides */
 			}
 			if (lane == 0) {
 				pos[0] = j;
