@@ -14,6 +14,7 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "csadp.h"
@@ -232,9 +233,23 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	parallel_for((int)active.size(), [&](int j) {
 		const int32_t *sm = fb.summary(j);
 		/* where the device has scored its path, the host's own sum along the trace must agree */
-		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2], fb.device_scores() ? &sm[3] : nullptr);
+		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2], fb.device_scores() ? &sm[3] : nullptr, true);
 		if (a != CSADP_OK) status[active[(size_t)j]] = a;
 	});
+	/* DeleteGappedColumns of all tasks: the scoring of the candidate columns -- nearly all of its time -- as ONE flat
+	 * list of (task, chunk of columns) items over all host threads, then the reference's sequential pass per task, which
+	 * only re-scores what a slide has touched (csadp_progressive.cpp).  Per task it used to be one thread's work, and the
+	 * largest gap of a run kept every round waiting for it. */
+	{
+		std::vector<std::pair<int, int>> items;
+		for (size_t j = 0; j < active.size(); ++j) {
+			if (status[active[j]] != CSADP_OK) continue;
+			const int chunks = tasks[active[j]].refine_prepare();
+			for (int c = 0; c < chunks; ++c) items.emplace_back(active[j], c);
+		}
+		parallel_for((int)items.size(), [&](int i) { tasks[items[(size_t)i].first].refine_speculate(items[(size_t)i].second); });
+		parallel_for((int)active.size(), [&](int j) { tasks[active[(size_t)j]].refine_commit(); });
+	}
 	lap();
 	if (trace)
 		fprintf(stderr, "csadp round: %3d jobs  layout %.2f  tables %.2f  device %.2f  apply %.2f ms\n", (int)active.size(), ms[0], ms[1],

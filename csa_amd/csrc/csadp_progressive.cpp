@@ -251,7 +251,7 @@ int Progressive::score_from_trace(const uint8_t *ops, int nops, int remj, int re
 }
 
 /* Traceback application, :1033-1155, driven by the op list instead of dpdirs. */
-int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score)
+int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score, bool defer_refinement)
 {
 	if (!pending_) return CSADP_ERR_STATE;
 	const int i = step_;
@@ -361,16 +361,8 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
 	++fills_;
 	tokens_.push_back('.');                                 /* :1156 */
 	if (i > 1) {
-		static const bool trace = getenv("CSADP_TRACE_HOST") != nullptr;
-		if (trace) {
-			const auto t0 = std::chrono::steady_clock::now();
-			delete_gapped_columns(i + 1, (i + 1) / 2);
-			dgc_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-			if (step_ + 1 == nseq_ && cells_ > 100000000)
-				fprintf(stderr, "csadp task: %d sequences, %lld cells: DeleteGappedColumns %.2f ms in total\n", nseq_, cells_, dgc_ms_);
-		} else {
-			delete_gapped_columns(i + 1, (i + 1) / 2);   /* :1157 */
-		}
+		if (defer_refinement) refine_numseqs_ = i + 1;                /* :1157, run by refine_prepare / _speculate / _commit */
+		else delete_gapped_columns(i + 1, (i + 1) / 2);
 	}
 	++step_;
 	pending_ = false;
@@ -383,15 +375,263 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
  * (right first, then left), score each slide with the sum-of-pairs style column formula,
  * take the LAST slide whose gain is >= the best so far (:791), apply it, drop the all-gap
  * columns it leaves behind and re-examine from the left-most dropped column.
+ *
+ * Three parts.  refine_evaluate scores ONE candidate column and reads only; refine_commit is the
+ * reference's left-to-right pass with its side effects; refine_speculate runs refine_evaluate for a chunk
+ * of candidates on the alignment as it stands before the pass -- any number of threads at once.  Slides
+ * are rare (one candidate in hundreds), and a candidate's score depends only on the columns it reads, so the
+ * pass takes the speculated outcome of every candidate whose neighbourhood lies right of everything a slide
+ * has touched so far and scores the others afresh: same decisions, same order, but the scoring -- all of the
+ * time of this function -- spread over the caller's threads instead of one per task.
  */
-void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
+void Progressive::RefineScratch::size_for(int consensus, int nseq)
 {
-	struct Probe {                    /* state of one direction of the search */
-		std::vector<int> block;       /* postonextgap: residues from col to the next gap  */
-		std::vector<int> affected;    /* bestnposaffected                                  */
-		std::vector<int> best;        /* bestworkingsv, maxaffected x 5                    */
-		int maxaffected = 0;
-	};
+	/* sized for the widest search: no growth inside the scan */
+	codev.resize((size_t)consensus + 2);
+	vacp.resize((size_t)consensus + 3);
+	statv.resize(((size_t)consensus + 2) * kSym);
+	movv.reserve(((size_t)consensus + 2) * kSym);
+	runs.assign((size_t)nseq, Run{false, 0, 0, false, false, -1, -1});
+}
+
+void Progressive::refine_evaluate(int col, int gap, int numseqs, RefineScratch &S, RefineEval &R) const
+{
+	std::vector<int> &movers = S.movers, &block = S.block, &nextgaps = S.nextgaps, &affected = S.affected;
+	std::vector<int> &statv = S.statv, &movv = S.movv, &vacp = S.vacp;
+	std::vector<signed char> &codev = S.codev;
+	typedef RefineScratch::Run Run;
+	movers.clear();
+	for (int t = 0; t < numseqs; ++t) {
+		const int s = order_[t];
+		if (str_[s][(size_t)(col + gap) - 1] != '-') movers.push_back(s);
+	}
+	const int nmov = (int)movers.size();
+	R.nmov = nmov;
+	R.bestshift = 0;
+	R.lo = col;
+	if (nmov == 0) return;
+	int bestscore = 0, bestshift = 0;
+	block.assign(nmov, 0);
+	nextgaps.assign(nmov, 0);
+	affected.assign(nmov, 0);
+	for (int dir = +1; dir >= -1; dir -= 2) {
+		const int limit = (dir > 0) ? consensus_ + 1 : 0;
+		int farthest = 0, minnext = consensus_;
+		bool blocked = false;
+		/* column `col` itself is the head of the right segment (offset gap); the columns the leftward
+		 * search reads beyond it are in the left segment (offset 0) */
+		const int off = dir > 0 ? gap : 0;
+		for (int t = 0; t < nmov; ++t) {                          /* :699-715 */
+			/* The reference walks the residue run of the mover from `col` to its end for every candidate
+			 * column (:700-712); consecutive candidates inside one long run -- e.g. the newest, longest
+			 * sequence over a short gap: 6944 candidates x 6993 letters on the third example set -- re-walk
+			 * the same letters.  What the walk found is remembered per row: the residues known around the
+			 * last candidate, [a, b), whether a / b are the run's true ends, and the lengths of the gap
+			 * runs beyond them; a row's memory is dropped when the row changes, everybody's when columns
+			 * are deleted.  Same block / nextgaps / blocked values, one walk per run instead of one per
+			 * column. */
+			const char *row = str_[movers[t]].data() + off - 1;       /* row[j] = logical column j on this side */
+			Run &W = S.runs[(size_t)movers[t]];
+			if (!(W.valid && W.a <= col && col < W.b)) W = Run{true, col, col + 1, false, false, -1, -1};
+			if (dir > 0) {
+				if (!W.bt) {
+					int j = W.b;
+					while (j != limit && row[j] != '-') ++j;
+					W.b = j;
+					W.bt = true;
+					W.gr = -1;
+				}
+				block[t] = W.b - col;
+				if (W.b == limit) { blocked = true; break; }
+				if (W.gr < 0) {
+					int j = W.b, g = 0;
+					while (j != limit && row[j] == '-') { ++g; ++j; }
+					W.gr = g;
+				}
+				nextgaps[t] = W.gr;
+			} else {
+				if (!W.at) {
+					int j = W.a - 1;
+					while (j != limit && row[j] != '-') --j;
+					W.a = j + 1;
+					W.at = true;
+					W.gl = -1;
+				}
+				block[t] = col - W.a + 1;
+				if (W.a - 1 == limit) { blocked = true; break; }
+				if (W.gl < 0) {
+					int j = W.a - 1, g = 0;
+					while (j != limit && row[j] == '-') { ++g; --j; }
+					W.gl = g;
+				}
+				nextgaps[t] = W.gl;
+				R.lo = std::min(R.lo, W.a - 1 - W.gl);               /* the column that ended the gap run was read too */
+			}
+			farthest = std::max(farthest, block[t]);
+			minnext = std::min(minnext, nextgaps[t]);
+		}
+		if (blocked) {                                            /* :716-721 */
+			if (dir < 0) R.lo = 0;                                /* the walk went to the left end */
+			continue;
+		}
+		for (int t = 0; t < nmov; ++t) affected[t] = block[t] + minnext;
+		const int maxaff = farthest + minnext;
+		/* statv = the columns without the movers, movv = the movers' symbols, current = what the movers
+		 * score where they stand (:739-761) */
+		auto build_arrays = [&]() {
+			movv.assign((size_t)maxaff * kSym, 0);
+			for (int j = 0; j < maxaff; ++j) memcpy(&statv[(size_t)j * kSym], &sv_[(size_t)(col + dir * j + (j ? off : gap)) * kSym], kSym * sizeof(int));
+			int cur = 0;
+			for (int t = 0; t < nmov; ++t) {
+				const char *row = str_[movers[t]].data() + off - 1;
+				for (int j = 0; j < affected[t]; ++j) {
+					const int jj = col + dir * j, o = j ? off : gap;
+					const int c = code_of(row[jj + o - off]);
+					const int *svjj = &sv_[(size_t)(jj + o) * kSym];
+					movv[(size_t)j * kSym + c]++;
+					statv[(size_t)j * kSym + c]--;
+					cur += (c != kGap) ? kMatch * (svjj[c] - 1) + kMismatch * (numseqs - (svjj[c] + svjj[kGap])) + kIndel * svjj[kGap]
+					                   : kDoubleGap * (svjj[kGap] - 1) + kIndel * (numseqs - svjj[kGap]);
+				}
+			}
+			return cur;
+		};
+		if (nmov == 1) {
+			/*
+			 * One mover (most candidates: a long insertion of one sequence): the same sums without the
+			 * per-column count vectors.  Relative column q holds the mover's letter for q < B and one of its
+			 * gaps for B <= q < B + G.  After a slide by sh the vacated columns [0, sh) and the columns
+			 * [B + sh, B + G) that keep one of the mover's gaps score vac(q) (a prefix sum), and letter q
+			 * scores against column q + sh without the mover's own symbol there.
+			 */
+			const int B = block[0], G = minnext, n = B + G;
+			const char *row = str_[movers[0]].data() + off - 1;
+			vacp[0] = 0;
+			int current = 0;
+			for (int q = 0; q < n; ++q) {
+				const int o = q ? off : gap;
+				const int *sq = &sv_[(size_t)(col + dir * q + o) * kSym];
+				int wg;                                               /* gaps of the column once the mover has a gap there */
+				if (q < B) {
+					const int c = code_of(row[col + dir * q + o - off]);
+					codev[(size_t)q] = (signed char)c;
+					current += kMatch * (sq[c] - 1) + kMismatch * (numseqs - (sq[c] + sq[kGap])) + kIndel * sq[kGap];
+					wg = sq[kGap] + 1;
+				} else {
+					codev[(size_t)q] = kGap;
+					current += kDoubleGap * (sq[kGap] - 1) + kIndel * (numseqs - sq[kGap]);
+					wg = sq[kGap];
+				}
+				vacp[(size_t)q + 1] = vacp[(size_t)q] + (wg == numseqs ? 0 : kDoubleGap * (wg - 1) + kIndel * (numseqs - wg));
+			}
+			for (int sh = 1; sh <= G; ++sh) {
+				int shifted = vacp[(size_t)sh] + vacp[(size_t)n] - vacp[(size_t)B + sh];
+				for (int q = 0; q < B; ++q) {
+					const int j = q + sh, c = codev[(size_t)q], cj = codev[(size_t)j];
+					const int *sj = &sv_[(size_t)(col + dir * j + off) * kSym];
+					const int wc = sj[c] + 1 - (cj == c), wg = sj[kGap] - (cj == kGap);
+					if (wg == numseqs) continue;
+					shifted += kMatch * (wc - 1) + kMismatch * (numseqs - (wc + wg)) + kIndel * wg;
+				}
+				shifted -= current;
+				if (shifted >= bestscore) {                           /* :791 */
+					bestshift = dir * sh;
+					bestscore = shifted;
+				}
+			}
+			if (bestshift != 0 && bestshift * dir > 0) {              /* the arrays the winner is applied from */
+				build_arrays();
+				for (int y = 0; y < G; ++y) movv[(size_t)(B + y) * kSym + kGap]--;
+			}
+		} else {
+			const int current = build_arrays();
+			/* the columns a slide vacates hold the movers' gaps only: a prefix sum over the slide length */
+			vacp[0] = 0;
+			for (int j = 0; j < minnext; ++j) {
+				const int wg = statv[(size_t)j * kSym + kGap] + nmov;
+				vacp[(size_t)j + 1] = vacp[(size_t)j] + (wg == numseqs ? 0 : nmov * (kDoubleGap * (wg - 1) + kIndel * (numseqs - wg)));
+			}
+			for (int sh = 1; sh <= minnext; ++sh) {               /* :762-795 (workingsv is not kept: only its score is used) */
+				for (int t = 0; t < nmov; ++t) {
+					movv[(size_t)(affected[t] - 1) * kSym + kGap]--;
+					affected[t]--;
+				}
+				int shifted = vacp[(size_t)sh];
+				for (int j = sh; j < maxaff; ++j) {
+					const int *mvp = &movv[(size_t)(j - sh) * kSym];
+					const int *st = &statv[(size_t)j * kSym];
+					const int wg = st[kGap] + mvp[kGap];
+					if (wg == numseqs) continue;
+					int colscore = 0;
+					for (int y = 0; y < kGap; ++y)
+						if (mvp[y] != 0) {
+							const int wy = st[y] + mvp[y];
+							colscore += mvp[y] * (kMatch * (wy - 1) + kMismatch * (numseqs - (wy + wg)) + kIndel * wg);
+						}
+					if (mvp[kGap] != 0) colscore += mvp[kGap] * (kDoubleGap * (wg - 1) + kIndel * (numseqs - wg));
+					shifted += colscore;
+				}
+				shifted -= current;
+				if (shifted >= bestscore) {                       /* :791 */
+					bestshift = dir * sh;
+					bestscore = shifted;
+				}
+			}
+		}
+		if (bestshift != 0 && bestshift * dir > 0) {              /* :796-818 */
+			const int sh = bestshift * dir;
+			const int back = minnext - sh;
+			S.keep_maxaffected = maxaff;
+			S.keep_affected.assign(nmov, 0);
+			for (int t = 0; t < nmov; ++t) {
+				for (int y = 0; y < back; ++y) movv[(size_t)(block[t] + y) * kSym + kGap]++;
+				S.keep_affected[t] = block[t] + sh;
+			}
+			S.keep_best.assign((size_t)maxaff * kSym, 0);
+			for (int j = 0; j < maxaff; ++j) {
+				for (int y = 0; y < kSym; ++y) {
+					int v = statv[(size_t)j * kSym + y];
+					if (j >= sh) v += movv[(size_t)(j - sh) * kSym + y];
+					S.keep_best[(size_t)j * kSym + y] = v;
+				}
+				if (j < sh) S.keep_best[(size_t)j * kSym + kGap] += nmov;
+			}
+		}
+	}
+	R.bestshift = bestshift;
+}
+
+int Progressive::refine_prepare()
+{
+	if (refine_numseqs_ == 0) return 0;
+	spec_state_.assign((size_t)consensus_ + 2, 0);
+	spec_lo_.assign((size_t)consensus_ + 2, 0);
+	return (consensus_ + kRefineChunk - 1) / kRefineChunk;
+}
+
+void Progressive::refine_speculate(int chunk)
+{
+	const int numseqs = refine_numseqs_, mingaps = numseqs - numseqs / 2;
+	const int first = chunk * kRefineChunk + 1, last = std::min(consensus_, first + kRefineChunk - 1);
+	RefineScratch S;
+	bool sized = false;
+	RefineEval R;
+	for (int col = first; col <= last; ++col) {
+		if (sv_[(size_t)col * kSym + kGap] < mingaps) continue;      /* :678 */
+		if (!sized) { S.size_for(consensus_, nseq_); sized = true; }
+		refine_evaluate(col, 0, numseqs, S, R);
+		spec_state_[(size_t)col] = R.nmov == 0 ? 1 : R.bestshift == 0 ? 2 : 3;
+		spec_lo_[(size_t)col] = R.lo;
+	}
+}
+
+void Progressive::refine_commit()
+{
+	const int numseqs = refine_numseqs_, maxnongaps = numseqs / 2;
+	if (numseqs == 0) return;
+	refine_numseqs_ = 0;
+	static const bool trace = getenv("CSADP_TRACE_HOST") != nullptr;
+	const auto t0 = std::chrono::steady_clock::now();
 	/*
 	 * Storage during the pass: a gap buffer.  The reference deletes a run of all-gap columns by moving
 	 * every later column of the profile and of every string down (:865-887), O(consensus x numseqs) per
@@ -421,15 +661,15 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		split = to;
 	};
 	const int mingaps = numseqs - maxnongaps;
-	struct Run { bool valid; int a, b; bool at, bt; int gl, gr; };
-	std::vector<Run> runs((size_t)nseq_, Run{false, 0, 0, false, false, -1, -1});
-	std::vector<int> movers;          /* seqstoshift */
-	std::vector<int> block, nextgaps, affected, statv, movv, vacp;
-	std::vector<signed char> codev((size_t)consensus_ + 2);      /* scratch sized for the widest search: no growth inside the scan */
-	vacp.resize((size_t)consensus_ + 3);
-	statv.resize(((size_t)consensus_ + 2) * kSym);
-	movv.reserve(((size_t)consensus_ + 2) * kSym);
-	Probe keep;
+	RefineScratch S;
+	S.size_for(consensus_, nseq_);
+	RefineEval R;
+	/* speculation bookkeeping, in the column numbers of the alignment before the pass: `deleted` columns are gone so
+	 * far, and nothing right of `dirty` has been read or written by a slide.  A logical column c was column
+	 * <= c + deleted then, exactly so when it lies right of `dirty`. */
+	const bool speculated = !spec_state_.empty();
+	const int spec_n = speculated ? (int)spec_state_.size() - 2 : 0;
+	int deleted = 0, dirty = 0;
 
 	for (int col = 1; col <= consensus_; ++col) {
 		if (SV(col, kGap) < mingaps) continue;                       /* :678 */
@@ -437,206 +677,25 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		 * index + gap), everything left of it in the left one, so each direction below reads its side
 		 * with ONE fixed offset instead of a comparison per access */
 		move_split(col - 1);
-		movers.clear();
-		for (int t = 0; t < numseqs; ++t) {
-			const int s = order_[t];
-			if (CH(s, col) != '-') movers.push_back(s);
+		const int then = col + deleted;
+		if (speculated && then <= spec_n && spec_state_[(size_t)then] != 0 && spec_lo_[(size_t)then] > dirty) {
+			const int st = spec_state_[(size_t)then];
+			if (st == 1) { tokens_.push_back('!'); continue; }        /* :688-690 */
+			if (st == 2) continue;                                    /* :823 */
 		}
-		const int nmov = (int)movers.size();
-		if (nmov == 0) { tokens_.push_back('!'); continue; }          /* :688-690 */
-		int bestscore = 0, bestshift = 0;
-		block.assign(nmov, 0);
-		nextgaps.assign(nmov, 0);
-		affected.assign(nmov, 0);
-		for (int dir = +1; dir >= -1; dir -= 2) {
-			const int limit = (dir > 0) ? consensus_ + 1 : 0;
-			int farthest = 0, minnext = consensus_;
-			bool blocked = false;
-			/* column `col` itself is the head of the right segment (offset gap); the columns the leftward
-			 * search reads beyond it are in the left segment (offset 0) */
-			const int off = dir > 0 ? gap : 0;
-			for (int t = 0; t < nmov; ++t) {                          /* :699-715 */
-				/* The reference walks the residue run of the mover from `col` to its end for every candidate
-				 * column (:700-712); consecutive candidates inside one long run -- e.g. the newest, longest
-				 * sequence over a short gap: 6944 candidates x 6993 letters on the third example set -- re-walk
-				 * the same letters.  What the walk found is remembered per row: the residues known around the
-				 * last candidate, [a, b), whether a / b are the run's true ends, and the lengths of the gap
-				 * runs beyond them; a row's memory is dropped when the row changes, everybody's when columns
-				 * are deleted.  Same block / nextgaps / blocked values, one walk per run instead of one per
-				 * column. */
-				const char *row = seqp[(size_t)movers[t]] + off - 1;       /* row[j] = logical column j on this side */
-				Run &R = runs[(size_t)movers[t]];
-				if (!(R.valid && R.a <= col && col < R.b)) R = Run{true, col, col + 1, false, false, -1, -1};
-				if (dir > 0) {
-					if (!R.bt) {
-						int j = R.b;
-						while (j != limit && row[j] != '-') ++j;
-						R.b = j;
-						R.bt = true;
-						R.gr = -1;
-					}
-					block[t] = R.b - col;
-					if (R.b == limit) { blocked = true; break; }
-					if (R.gr < 0) {
-						int j = R.b, g = 0;
-						while (j != limit && row[j] == '-') { ++g; ++j; }
-						R.gr = g;
-					}
-					nextgaps[t] = R.gr;
-				} else {
-					if (!R.at) {
-						int j = R.a - 1;
-						while (j != limit && row[j] != '-') --j;
-						R.a = j + 1;
-						R.at = true;
-						R.gl = -1;
-					}
-					block[t] = col - R.a + 1;
-					if (R.a - 1 == limit) { blocked = true; break; }
-					if (R.gl < 0) {
-						int j = R.a - 1, g = 0;
-						while (j != limit && row[j] == '-') { ++g; --j; }
-						R.gl = g;
-					}
-					nextgaps[t] = R.gl;
-				}
-				farthest = std::max(farthest, block[t]);
-				minnext = std::min(minnext, nextgaps[t]);
-			}
-			if (blocked) continue;                                    /* :716-721 */
-			for (int t = 0; t < nmov; ++t) affected[t] = block[t] + minnext;
-			const int maxaff = farthest + minnext;
-			/* statv = the columns without the movers, movv = the movers' symbols, current = what the movers
-			 * score where they stand (:739-761) */
-			auto build_arrays = [&]() {
-				movv.assign((size_t)maxaff * kSym, 0);
-				for (int j = 0; j < maxaff; ++j) memcpy(&statv[(size_t)j * kSym], &sv_[(size_t)(col + dir * j + (j ? off : gap)) * kSym], kSym * sizeof(int));
-				int cur = 0;
-				for (int t = 0; t < nmov; ++t) {
-					const char *row = seqp[(size_t)movers[t]] + off - 1;
-					for (int j = 0; j < affected[t]; ++j) {
-						const int jj = col + dir * j, o = j ? off : gap;
-						const int c = code_of(row[jj + o - off]);
-						const int *svjj = &sv_[(size_t)(jj + o) * kSym];
-						movv[(size_t)j * kSym + c]++;
-						statv[(size_t)j * kSym + c]--;
-						cur += (c != kGap) ? kMatch * (svjj[c] - 1) + kMismatch * (numseqs - (svjj[c] + svjj[kGap])) + kIndel * svjj[kGap]
-						                   : kDoubleGap * (svjj[kGap] - 1) + kIndel * (numseqs - svjj[kGap]);
-					}
-				}
-				return cur;
-			};
-			if (nmov == 1) {
-				/*
-				 * One mover (most candidates: a long insertion of one sequence): the same sums without the
-				 * per-column count vectors.  Relative column q holds the mover's letter for q < B and one of its
-				 * gaps for B <= q < B + G.  After a slide by sh the vacated columns [0, sh) and the columns
-				 * [B + sh, B + G) that keep one of the mover's gaps score vac(q) (a prefix sum), and letter q
-				 * scores against column q + sh without the mover's own symbol there.
-				 */
-				const int B = block[0], G = minnext, n = B + G;
-				const char *row = seqp[(size_t)movers[0]] + off - 1;
-				vacp[0] = 0;
-				int current = 0;
-				for (int q = 0; q < n; ++q) {
-					const int o = q ? off : gap;
-					const int *sq = &sv_[(size_t)(col + dir * q + o) * kSym];
-					int wg;                                               /* gaps of the column once the mover has a gap there */
-					if (q < B) {
-						const int c = code_of(row[col + dir * q + o - off]);
-						codev[(size_t)q] = (signed char)c;
-						current += kMatch * (sq[c] - 1) + kMismatch * (numseqs - (sq[c] + sq[kGap])) + kIndel * sq[kGap];
-						wg = sq[kGap] + 1;
-					} else {
-						codev[(size_t)q] = kGap;
-						current += kDoubleGap * (sq[kGap] - 1) + kIndel * (numseqs - sq[kGap]);
-						wg = sq[kGap];
-					}
-					vacp[(size_t)q + 1] = vacp[(size_t)q] + (wg == numseqs ? 0 : kDoubleGap * (wg - 1) + kIndel * (numseqs - wg));
-				}
-				for (int sh = 1; sh <= G; ++sh) {
-					int shifted = vacp[(size_t)sh] + vacp[(size_t)n] - vacp[(size_t)B + sh];
-					for (int q = 0; q < B; ++q) {
-						const int j = q + sh, c = codev[(size_t)q], cj = codev[(size_t)j];
-						const int *sj = &sv_[(size_t)(col + dir * j + off) * kSym];
-						const int wc = sj[c] + 1 - (cj == c), wg = sj[kGap] - (cj == kGap);
-						if (wg == numseqs) continue;
-						shifted += kMatch * (wc - 1) + kMismatch * (numseqs - (wc + wg)) + kIndel * wg;
-					}
-					shifted -= current;
-					if (shifted >= bestscore) {                           /* :791 */
-						bestshift = dir * sh;
-						bestscore = shifted;
-					}
-				}
-				if (bestshift != 0 && bestshift * dir > 0) {              /* the arrays the winner is applied from */
-					build_arrays();
-					for (int y = 0; y < G; ++y) movv[(size_t)(B + y) * kSym + kGap]--;
-				}
-			} else {
-				const int current = build_arrays();
-				/* the columns a slide vacates hold the movers' gaps only: a prefix sum over the slide length */
-				vacp[0] = 0;
-				for (int j = 0; j < minnext; ++j) {
-					const int wg = statv[(size_t)j * kSym + kGap] + nmov;
-					vacp[(size_t)j + 1] = vacp[(size_t)j] + (wg == numseqs ? 0 : nmov * (kDoubleGap * (wg - 1) + kIndel * (numseqs - wg)));
-				}
-				for (int sh = 1; sh <= minnext; ++sh) {               /* :762-795 (workingsv is not kept: only its score is used) */
-					for (int t = 0; t < nmov; ++t) {
-						movv[(size_t)(affected[t] - 1) * kSym + kGap]--;
-						affected[t]--;
-					}
-					int shifted = vacp[(size_t)sh];
-					for (int j = sh; j < maxaff; ++j) {
-						const int *mvp = &movv[(size_t)(j - sh) * kSym];
-						const int *st = &statv[(size_t)j * kSym];
-						const int wg = st[kGap] + mvp[kGap];
-						if (wg == numseqs) continue;
-						int colscore = 0;
-						for (int y = 0; y < kGap; ++y)
-							if (mvp[y] != 0) {
-								const int wy = st[y] + mvp[y];
-								colscore += mvp[y] * (kMatch * (wy - 1) + kMismatch * (numseqs - (wy + wg)) + kIndel * wg);
-							}
-						if (mvp[kGap] != 0) colscore += mvp[kGap] * (kDoubleGap * (wg - 1) + kIndel * (numseqs - wg));
-						shifted += colscore;
-					}
-					shifted -= current;
-					if (shifted >= bestscore) {                       /* :791 */
-						bestshift = dir * sh;
-						bestscore = shifted;
-					}
-				}
-			}
-			if (bestshift != 0 && bestshift * dir > 0) {              /* :796-818 */
-				const int sh = bestshift * dir;
-				const int back = minnext - sh;
-				keep.maxaffected = maxaff;
-				keep.affected.assign(nmov, 0);
-				for (int t = 0; t < nmov; ++t) {
-					for (int y = 0; y < back; ++y) movv[(size_t)(block[t] + y) * kSym + kGap]++;
-					keep.affected[t] = block[t] + sh;
-				}
-				keep.best.assign((size_t)maxaff * kSym, 0);
-				for (int j = 0; j < maxaff; ++j) {
-					for (int y = 0; y < kSym; ++y) {
-						int v = statv[(size_t)j * kSym + y];
-						if (j >= sh) v += movv[(size_t)(j - sh) * kSym + y];
-						keep.best[(size_t)j * kSym + y] = v;
-					}
-					if (j < sh) keep.best[(size_t)j * kSym + kGap] += nmov;
-				}
-			}
-		}
+		refine_evaluate(col, gap, numseqs, S, R);
+		if (R.nmov == 0) { tokens_.push_back('!'); continue; }        /* :688-690 */
+		const int bestshift = R.bestshift;
 		if (bestshift == 0) continue;                                 /* :823 */
+		const int nmov = R.nmov;
 		const int dir = (bestshift < 0) ? -1 : +1;
 		const int sh = (bestshift < 0) ? -bestshift : bestshift;
-		for (int j = 0; j < keep.maxaffected; ++j)                    /* :837-840 */
-			for (int y = 0; y < kSym; ++y) SV(col + dir * j, y) = keep.best[(size_t)j * kSym + y];
+		for (int j = 0; j < S.keep_maxaffected; ++j)                  /* :837-840 */
+			for (int y = 0; y < kSym; ++y) SV(col + dir * j, y) = S.keep_best[(size_t)j * kSym + y];
 		for (int t = 0; t < nmov; ++t) {                              /* :841-852 */
-			const int sq = movers[t];
-			runs[(size_t)sq].valid = false;
-			for (int j = keep.affected[t] - 1; j >= 0; --j) {
+			const int sq = S.movers[t];
+			S.runs[(size_t)sq].valid = false;
+			for (int j = S.keep_affected[t] - 1; j >= 0; --j) {
 				const int c = col + dir * j;
 				CH(sq, c) = (j < sh) ? '-' : CH(sq, c - dir * sh);
 			}
@@ -646,11 +705,13 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 		for (int j = col - 1; j >= 1; --j) { if (SV(j, kGap) != numseqs) break; ++left; }
 		const int drop = right + left;
 		if (drop > 0) {                                               /* :865-887 */
-			for (Run &R : runs) R.valid = false;
+			for (auto &W : S.runs) W.valid = false;
 			move_split(col - left - 1);                               /* the run becomes the head of the right segment */
 			gap += drop;
 			consensus_ -= drop;
+			deleted += drop;
 		}
+		dirty = std::max(dirty, col + deleted + S.keep_maxaffected + right + 1);
 		col -= left + 1;                                              /* :888 */
 	}
 	if (gap > 0) {                                                    /* compact: the right segment moves down by `gap` */
@@ -663,6 +724,27 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 			r.resize((size_t)consensus_);
 		}
 	}
+	spec_state_.clear();
+	spec_lo_.clear();
+	if (trace) {
+		dgc_ms_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+		if (step_ + (pending_ ? 1 : 0) == nseq_ && cells_ > 100000000)
+			fprintf(stderr, "csadp task: %d sequences, %lld cells: DeleteGappedColumns (commit pass) %.2f ms in total\n", nseq_, cells_, dgc_ms_);
+	}
+}
+
+/* the whole refinement in one call (callers with one task at a time).  CSADP_REFINE_SPECULATE=1 runs the speculation
+ * too, on this thread: the tests use it to hold the speculated pass against the plain one. */
+void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
+{
+	(void)maxnongaps;                                                 /* = numseqs / 2 (:1157) */
+	refine_numseqs_ = numseqs;
+	static const bool speculate = getenv("CSADP_REFINE_SPECULATE") != nullptr && atoi(getenv("CSADP_REFINE_SPECULATE")) != 0;
+	if (speculate) {
+		const int chunks = refine_prepare();
+		for (int c = 0; c < chunks; ++c) refine_speculate(c);
+	}
+	refine_commit();
 }
 
 int Progressive::finish(csadp_result *res)

@@ -54,7 +54,18 @@ public:
 	 * (nrows,ncols) backwards), remj/remk = rows/columns left when the walk hit a border.
 	 * The DP score H[nrows][ncols] is re-derived on the way as border value + sum of the move
 	 * scores along the path; if expect_score is given it must agree (test seam). */
-	int apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score = nullptr);
+	int apply_trace(const uint8_t *ops, int nops, int remj, int remk, const int *expect_score = nullptr, bool defer_refinement = false);
+
+	/* DeleteGappedColumns (:643-899) of a step applied with defer_refinement, in three parts so that a caller
+	 * with many tasks can spread the second one over all of its threads:
+	 *   refine_prepare()      number of independent chunks of candidate columns (0: nothing to refine)
+	 *   refine_speculate(c)   scores the candidates of chunk c on the alignment as it stands -- read-only, any
+	 *                         number of threads at once
+	 *   refine_commit()       the reference's left-to-right pass; a candidate whose neighbourhood no slide has
+	 *                         touched takes its score from the speculation, every other one is scored afresh */
+	int refine_prepare();
+	void refine_speculate(int chunk);
+	void refine_commit();
 
 	/* DP score H[nrows][ncols] of the pending fill from its traced path (border value + sum of
 	 * move scores, as apply_trace derives it) without touching the strings or the profile. */
@@ -75,6 +86,20 @@ public:
 private:
 	char char_at(int pos, int seq) const;
 	void delete_gapped_columns(int numseqs, int maxnongaps);
+
+	/* scratch of one candidate evaluation (one per thread) */
+	struct RefineScratch {
+		struct Run { bool valid; int a, b; bool at, bt; int gl, gr; };
+		std::vector<int> movers, block, nextgaps, affected, statv, movv, vacp;
+		std::vector<signed char> codev;
+		std::vector<Run> runs;                   /* per row: what the last walk found around the last candidate */
+		std::vector<int> keep_affected, keep_best;   /* the winning slide: bestnposaffected, bestworkingsv */
+		int keep_maxaffected = 0;
+		void size_for(int consensus, int nseq);
+	};
+	struct RefineEval { int nmov = 0, bestshift = 0, lo = 0; };
+	/* scores candidate column `col` (split of the gap buffer at col - 1, columns >= col live `gap` higher) */
+	void refine_evaluate(int col, int gap, int numseqs, RefineScratch &S, RefineEval &R) const;
 
 	int nseq_ = 0;
 	/* private copy of the task's small arrays; the sequence texts themselves are borrowed
@@ -100,6 +125,11 @@ private:
 	int fills_ = 0;
 	double dgc_ms_ = 0;                          /* CSADP_TRACE_HOST: time spent in delete_gapped_columns */
 	std::string tokens_;                         /* '.' per fill (:1156), '!' per all-gap column met (:689) */
+	/* a refinement that was deferred / speculated on */
+	int refine_numseqs_ = 0;                     /* 0: none pending */
+	std::vector<unsigned char> spec_state_;      /* per original column: 0 unknown, 1 no movers, 2 no slide, 3 slides */
+	std::vector<int> spec_lo_;                   /* leftmost column the evaluation read */
+	static constexpr int kRefineChunk = 512;     /* columns per speculation chunk */
 };
 
 }  // namespace csadp
