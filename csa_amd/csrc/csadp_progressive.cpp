@@ -3,6 +3,7 @@
  * Line numbers cite /root/reference/source/dynamicprogramming.c unless stated otherwise.
  */
 #include "csadp_progressive.h"
+#include "csadp_hostpar.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -734,15 +735,18 @@ void Progressive::refine_commit()
 }
 
 /* the whole refinement in one call (callers with one task at a time).  CSADP_REFINE_SPECULATE=1 runs the speculation
- * too, on this thread: the tests use it to hold the speculated pass against the plain one. */
+ * too, on this thread, =2 on several: the tests use it to hold the speculated pass against the plain one (and run it
+ * under the thread sanitizer). */
 void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 {
 	(void)maxnongaps;                                                 /* = numseqs / 2 (:1157) */
 	refine_numseqs_ = numseqs;
-	static const bool speculate = getenv("CSADP_REFINE_SPECULATE") != nullptr && atoi(getenv("CSADP_REFINE_SPECULATE")) != 0;
+	const char *env = getenv("CSADP_REFINE_SPECULATE");           /* read per call: the tests switch it */
+	const int speculate = env ? atoi(env) : 0;                    /* 1: on this thread, 2: chunks over short-lived threads */
 	if (speculate) {
 		const int chunks = refine_prepare();
-		for (int c = 0; c < chunks; ++c) refine_speculate(c);
+		if (speculate >= 2) host_parallel_for(chunks, [this](int c) { refine_speculate(c); });
+		else for (int c = 0; c < chunks; ++c) refine_speculate(c);
 	}
 	refine_commit();
 }

@@ -51,8 +51,17 @@ def test_no_cpu_fallback_without_device():
         csa_amd.PairBatch([([b"ACGT", b"ACGT"], None, None, None)])
 
 
+# DeleteGappedColumns runs either as the reference's plain pass or with its candidate scores speculated first (what the
+# round driver does over all tasks and threads); CSADP_REFINE_SPECULATE=1 makes the one-task entry points speculate too.
+@pytest.fixture(params=["plain", "speculated", "speculated-threads"])
+def refine_mode(request, monkeypatch):
+    if request.param != "plain":
+        monkeypatch.setenv("CSADP_REFINE_SPECULATE", "1" if request.param == "speculated" else "2")
+    return request.param
+
+
 @pytest.mark.parametrize("name", ["tiny_pairs.json", "tiny_families.json"])
-def test_host_logic_matches_golden(name):
+def test_host_logic_matches_golden(name, refine_mode):
     """Ordering, seeding, stale-border rule, traceback application, DeleteGappedColumns and the
     path-derived DP score of the product's host code, fills supplied by the oracle."""
     fill = oracle_filler()
@@ -64,10 +73,10 @@ def test_host_logic_matches_golden(name):
         assert got["aligned"] == (exp if exp[0] is not None else None)
 
 
-def test_host_logic_medium_families_vs_oracle():
+def test_host_logic_medium_families_vs_oracle(refine_mode):
     fill = oracle_filler()
     r = rng(123)
-    for n, length in [(4, 120), (7, 90), (12, 60), (3, 200)]:
+    for n, length in [(4, 120), (7, 90), (12, 60), (3, 200), (9, 700)]:
         fam = random_family(r, n, length, mut=0.12, indel=0.08)
         rots = [r.randrange(len(f)) for f in fam]
         got = csa_amd.debug_align_with_filler((fam, rots, None, None), fill)
@@ -145,7 +154,7 @@ def test_rotated_fasta_wire_format(tmp_path):
         assert csa_amd.read_rotations(out) == rot[name]
 
 
-def test_progress_tokens_equal_the_reference_log():
+def test_progress_tokens_equal_the_reference_log(refine_mode):
     """csadp_result.progress restates the reference's stdout tokens between "[(min-max)" and "->":
     one '.' per fill (dynamicprogramming.c:1156) and one '!' per all-gap column DeleteGappedColumns
     meets (:689).  pipeline.json holds the unmodified program's log lines; the Mammals gaps (42 calls,

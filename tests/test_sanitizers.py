@@ -20,9 +20,11 @@ def test_host_code_under_sanitizers(kind, tmp_path):
     assert make.returncode == 0, make.stdout.decode()[-3000:]
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
                TSAN_OPTIONS="halt_on_error=1")
-    run = subprocess.run([os.path.join(ROOT, "build", "host_" + kind), os.path.join(GOLDEN, "data", "Primates.txt"), str(tmp_path)],
-                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=env)
-    out = run.stdout.decode(errors="replace")
-    assert run.returncode == 0, out[-4000:]
-    assert "host_sanitize ok" in out
-    assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out and "WARNING: ThreadSanitizer" not in out
+    # twice: DeleteGappedColumns as the plain pass, and with its candidate scores speculated on several threads first
+    for refine in ("0", "2"):
+        run = subprocess.run([os.path.join(ROOT, "build", "host_" + kind), os.path.join(GOLDEN, "data", "Primates.txt"), str(tmp_path)],
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600, env=dict(env, CSADP_REFINE_SPECULATE=refine))
+        out = run.stdout.decode(errors="replace")
+        assert run.returncode == 0, out[-4000:]
+        assert "host_sanitize ok" in out
+        assert "ERROR: AddressSanitizer" not in out and "runtime error:" not in out and "WARNING: ThreadSanitizer" not in out
