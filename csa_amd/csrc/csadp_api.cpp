@@ -202,7 +202,7 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 {
 	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
 	auto tick = std::chrono::steady_clock::now();
-	double ms[5] = {0, 0, 0, 0, 0};
+	double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int phase = 0;
 	auto lap = [&]() {
 		const auto now = std::chrono::steady_clock::now();
@@ -240,6 +240,7 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	 * list of (task, chunk of columns) items over all host threads, then the reference's sequential pass per task, which
 	 * only re-scores what a slide has touched (csadp_progressive.cpp).  Per task it used to be one thread's work, and the
 	 * largest gap of a run kept every round waiting for it. */
+	lap();
 	{
 		std::vector<std::pair<int, int>> items;
 		for (size_t j = 0; j < active.size(); ++j) {
@@ -248,12 +249,13 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 			for (int c = 0; c < chunks; ++c) items.emplace_back(active[j], c);
 		}
 		parallel_for((int)items.size(), [&](int i) { tasks[items[(size_t)i].first].refine_speculate(items[(size_t)i].second); });
+		lap();
 		parallel_for((int)active.size(), [&](int j) { tasks[active[(size_t)j]].refine_commit(); });
 	}
 	lap();
 	if (trace)
-		fprintf(stderr, "csadp round: %3d jobs  layout %.2f  tables %.2f  device %.2f  apply %.2f ms\n", (int)active.size(), ms[0], ms[1],
-		        ms[2], ms[3]);
+		fprintf(stderr, "csadp round: %3d jobs  layout %.2f  tables %.2f  device %.2f  apply %.2f  refine: speculate %.2f  commit %.2f ms\n",
+		        (int)active.size(), ms[0], ms[1], ms[2], ms[3], ms[4], ms[5]);
 	return CSADP_OK;
 }
 

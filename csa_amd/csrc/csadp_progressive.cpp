@@ -674,16 +674,16 @@ void Progressive::refine_commit()
 
 	for (int col = 1; col <= consensus_; ++col) {
 		if (SV(col, kGap) < mingaps) continue;                       /* :678 */
-		/* the split follows the scan: everything at or right of `col` is in the right segment (physical
-		 * index + gap), everything left of it in the left one, so each direction below reads its side
-		 * with ONE fixed offset instead of a comparison per access */
-		move_split(col - 1);
 		const int then = col + deleted;
 		if (speculated && then <= spec_n && spec_state_[(size_t)then] != 0 && spec_lo_[(size_t)then] > dirty) {
 			const int st = spec_state_[(size_t)then];
 			if (st == 1) { tokens_.push_back('!'); continue; }        /* :688-690 */
 			if (st == 2) continue;                                    /* :823 */
 		}
+		/* the split follows the columns that are scored here: everything at or right of `col` is in the right
+		 * segment (physical index + gap), everything left of it in the left one, so each direction of the
+		 * search reads its side with ONE fixed offset instead of a comparison per access */
+		move_split(col - 1);
 		refine_evaluate(col, gap, numseqs, S, R);
 		if (R.nmov == 0) { tokens_.push_back('!'); continue; }        /* :688-690 */
 		const int bestshift = R.bestshift;
@@ -712,7 +712,9 @@ void Progressive::refine_commit()
 			consensus_ -= drop;
 			deleted += drop;
 		}
-		dirty = std::max(dirty, col + deleted + S.keep_maxaffected + right + 1);
+		/* columns touched: col .. col + maxaffected - 1 (a slide to the right) or col - maxaffected + 1 .. col (to the
+		 * left), and the deleted run from col on; with `deleted` after the drop this bounds their old numbers */
+		dirty = std::max(dirty, col + deleted + std::max(dir > 0 ? S.keep_maxaffected : 1, right));
 		col -= left + 1;                                              /* :888 */
 	}
 	if (gap > 0) {                                                    /* compact: the right segment moves down by `gap` */
