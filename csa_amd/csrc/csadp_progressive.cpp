@@ -387,12 +387,18 @@ int Progressive::apply_trace(const uint8_t *ops, int nops, int remj, int remk, c
  */
 void Progressive::RefineScratch::size_for(int consensus, int nseq)
 {
-	/* sized for the widest search: no growth inside the scan */
-	codev.resize((size_t)consensus + 2);
-	vacp.resize((size_t)consensus + 3);
-	statv.resize(((size_t)consensus + 2) * kSym);
-	movv.reserve(((size_t)consensus + 2) * kSym);
+	(void)consensus;                                                  /* the column arrays grow with the widest search met (reserve) */
 	runs.assign((size_t)nseq, Run{false, 0, 0, false, false, -1, -1});
+}
+
+void Progressive::RefineScratch::reserve(int columns)
+{
+	if ((int)codev.size() >= columns + 2) return;
+	const size_t n = (size_t)std::max(columns + 2, 2 * (int)codev.size());
+	codev.resize(n);
+	vacp.resize(n + 1);
+	statv.resize(n * kSym);
+	movv.reserve(n * kSym);
 }
 
 void Progressive::refine_evaluate(int col, int gap, int numseqs, RefineScratch &S, RefineEval &R) const
@@ -477,6 +483,7 @@ void Progressive::refine_evaluate(int col, int gap, int numseqs, RefineScratch &
 		}
 		for (int t = 0; t < nmov; ++t) affected[t] = block[t] + minnext;
 		const int maxaff = farthest + minnext;
+		S.reserve(maxaff);
 		/* statv = the columns without the movers, movv = the movers' symbols, current = what the movers
 		 * score where they stand (:739-761) */
 		auto build_arrays = [&]() {
@@ -614,7 +621,7 @@ void Progressive::refine_speculate(int chunk)
 {
 	const int numseqs = refine_numseqs_, mingaps = numseqs - numseqs / 2;
 	const int first = chunk * kRefineChunk + 1, last = std::min(consensus_, first + kRefineChunk - 1);
-	RefineScratch S;
+	static thread_local RefineScratch S;                             /* its column arrays are kept from chunk to chunk */
 	bool sized = false;
 	RefineEval R;
 	for (int col = first; col <= last; ++col) {

@@ -96,6 +96,7 @@ private:
 		std::vector<int> keep_affected, keep_best;   /* the winning slide: bestnposaffected, bestworkingsv */
 		int keep_maxaffected = 0;
 		void size_for(int consensus, int nseq);
+		void reserve(int columns);
 	};
 	struct RefineEval { int nmov = 0, bestshift = 0, lo = 0; };
 	/* scores candidate column `col` (split of the gap buffer at col - 1, columns >= col live `gap` higher) */
