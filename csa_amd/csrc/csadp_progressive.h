@@ -130,7 +130,7 @@ private:
 	int refine_numseqs_ = 0;                     /* 0: none pending */
 	std::vector<unsigned char> spec_state_;      /* per original column: 0 unknown, 1 no movers, 2 no slide, 3 slides */
 	std::vector<int> spec_lo_;                   /* leftmost column the evaluation read */
-	static constexpr int kRefineChunk = 512;     /* columns per speculation chunk */
+	static constexpr int kRefineChunk = 256;     /* columns per speculation chunk */
 };
 
 }  // namespace csadp
