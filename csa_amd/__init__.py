@@ -76,7 +76,7 @@ class Timing(ctypes.Structure):
 # symbols declared in include/csadp.h and include/csadp_debug.h
 EXPORTS = [
     "csadp_init", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
-    "csadp_align_batch", "csadp_free_result", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
+    "csadp_align_batch", "csadp_free_result", "csadp_free_results", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
     "csadp_align_batch_multi", "csadp_pairs_create_on",
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_flush", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
@@ -108,6 +108,7 @@ def lib():
         L.csadp_init.argtypes = [ctypes.POINTER(Config)]
         L.csadp_align_batch.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(Result)]
         L.csadp_free_result.argtypes = [ctypes.POINTER(Result), ctypes.c_int]
+        L.csadp_free_results.argtypes = [ctypes.POINTER(Result), ctypes.c_int, ctypes.c_int]
         L.csadp_pairs_create.argtypes = [ctypes.POINTER(Task), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         for name in ("csadp_pairs_run", "csadp_pairs_sync", "csadp_pairs_flush"):
             getattr(L, name).argtypes = [ctypes.c_void_p]

@@ -182,6 +182,17 @@ void csadp_free_result(csadp_result *r, int nseq)
 	r->progress = NULL;
 }
 
+int csadp_free_results(csadp_result *results, int count, int nseq)
+{
+	if (!results) return 0;
+	int failed = 0;
+	for (int t = 0; t < count; ++t) {
+		failed += results[t].status != CSADP_OK;
+		csadp_free_result(&results[t], nseq);
+	}
+	return failed;
+}
+
 }  // extern "C"
 
 namespace {

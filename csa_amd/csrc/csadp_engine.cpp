@@ -47,6 +47,11 @@ Engine *g_primary = nullptr;
 Engine *Engine::open(int device, const csadp_config *cfg, int *rc)
 {
 	std::lock_guard<std::mutex> lock(g_registry_mutex);
+	/* An engine runs two fill streams, their side streams and a copy stream; the HIP runtime multiplexes all streams of a
+	 * process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run in order -- a fill
+	 * behind somebody else's traceback (rocprofv3 trace of tools/stream_probe2.py).  Ask for 8 unless the caller has
+	 * chosen; without effect when the process has initialised HIP before (then the caller sets it, as bench.py does). */
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
 		fprintf(stderr, "csadp: no HIP device available (this library has no CPU fallback)\n");
@@ -129,6 +134,7 @@ int Engine::init(int dev, const csadp_config *cfg)
 	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
 	nstreams_ = 2 * main_streams();
 	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
 	C_ = env_int("CSADP_COLS_PER_LANE", 16);
 	R_ = env_int("CSADP_ROWS_PER_STEP", 2);
 	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 64);
@@ -229,6 +235,11 @@ void Engine::shutdown()
 		(void)hipStreamDestroy(streams_[i]);
 		streams_[i] = nullptr;
 	}
+	if (copy_stream_) {
+		(void)hipStreamSynchronize(copy_stream_);
+		(void)hipStreamDestroy(copy_stream_);
+		copy_stream_ = nullptr;
+	}
 	ready_ = false;
 }
 
@@ -238,13 +249,14 @@ FillBatch::~FillBatch()
 {
 	(void)E_->bind();
 	/* the arena and the pinned mirrors go back to the engine's pools: nothing may still be using them */
-	if (laid_out_)
-		for (int sl = 0; sl < E_->nstreams(); ++sl)
-			if (!bits_ || (used_streams_ >> sl) & 1u) (void)hipStreamSynchronize(E_->stream(sl));
+	if (laid_out_ && bits_) {
+		(void)wait_batch();
+	} else if (laid_out_) {
+		for (int sl = 0; sl < E_->nstreams(); ++sl) (void)hipStreamSynchronize(E_->stream(sl));
+	}
 	if (arena_) E_->give_arena(arena_, arena_cap_);
 	if (h_in_) E_->give_pinned(h_in_, h_in_cap_);
 	if (h_res_) E_->give_pinned(h_res_, h_res_cap_);
-	if (h_abort_) (void)hipHostFree(h_abort_);
 	if (ev_up_) (void)hipEventDestroy(ev_up_);
 	for (auto &slot : ev_)
 		for (auto &e : slot)
@@ -586,7 +598,6 @@ int FillBatch::layout_cells()
 	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
 	memcpy(h_in_ + serial_off_, serial_tiles_.data(), serial_tiles_.size() * sizeof(TileRef));
 	cjobs_ = slot_jobs[0];
-	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
 	return CSADP_OK;
 }
 
@@ -771,7 +782,6 @@ int FillBatch::layout_pk()
 		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)np * sizeof(PairJob));
 	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
 	memcpy(h_in_ + strips_off_, strips.data(), strips.size() * sizeof(TileRef));
-	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
 	pjobs_ = slot_jobs[0];
 	laid_out_ = true;
 	ran_ = false;
@@ -1023,8 +1033,8 @@ int FillBatch::layout_bits()
 	 * pass, several in flight) overlap instead of queueing behind each other */
 	base_stream_ = E.rotate_stream() % E.main_streams();
 	used_streams_ = 0;
+	issued_ = 0;
 	bjobs_ = slot_jobs[0];
-	if (!h_abort_) HIP_TRY(hipHostMalloc((void **)&h_abort_, 64, hipHostMallocDefault));
 	return CSADP_OK;
 }
 
@@ -1051,14 +1061,19 @@ int FillBatch::alloc_buffers()
 		HIP_TRY(hipMalloc((void **)&arena_, total_bytes_));
 		arena_cap_ = total_bytes_;
 	}
-	if (in_bytes_ > h_in_cap_) {
+	/* the last 64 bytes of the upload staging receive the abort word (a pinned allocation of its own per batch cost a
+	 * hipHostMalloc / hipHostFree pair, and hipHostFree waits for the whole device: 1.6 ms per destroyed batch while the
+	 * next ones were running) */
+	const size_t need_in = align_up(in_bytes_, 64) + 64;
+	if (need_in > h_in_cap_) {
 		if (h_in_) E.give_pinned(h_in_, h_in_cap_);
-		h_in_ = E.take_pinned(in_bytes_, &h_in_cap_);
+		h_in_ = E.take_pinned(need_in, &h_in_cap_);
 		if (!h_in_) {
-			HIP_TRY(hipHostMalloc((void **)&h_in_, in_bytes_, hipHostMallocDefault));
-			h_in_cap_ = in_bytes_;
+			HIP_TRY(hipHostMalloc((void **)&h_in_, need_in, hipHostMallocDefault));
+			h_in_cap_ = need_in;
 		}
 	}
+	h_abort_ = reinterpret_cast<int *>(h_in_ + h_in_cap_ - 64);
 	if (res_bytes_ > h_res_cap_) {
 		if (h_res_) E.give_pinned(h_res_, h_res_cap_);
 		h_res_ = E.take_pinned(res_bytes_, &h_res_cap_);
@@ -1228,6 +1243,7 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
 	HIP_TRY(hipEventRecord(ev[2], side));
 	slot_used_[first] = true;
+	issued_ |= 1ull << first;
 	return CSADP_OK;
 }
 
@@ -1257,10 +1273,11 @@ int FillBatch::check_abort()
 		}
 		return CSADP_OK;
 	}
-	hipStream_t st = E_->stream(last_stream_);
-	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(hipStreamSynchronize(st));
+	/* the callers have waited for the batch's launches: read the word on the copy stream, not behind later batches */
+	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, E_->copy_stream()));
+	HIP_TRY(hipStreamSynchronize(E_->copy_stream()));
 	if (*h_abort_ == 0) return CSADP_OK;
+	hipStream_t st = E_->stream(last_stream_);
 	if (!bits_wide_) {
 		fprintf(stderr, "csadp: a wait inside the bit-parallel fill kernel timed out\n");
 		return CSADP_ERR_HIP;
@@ -1353,10 +1370,25 @@ int FillBatch::sync()
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	const int rc = flush();
 	if (rc != CSADP_OK) return rc;
-	/* bit-parallel batches wait for the streams THEY used: other batches of the engine keep running */
-	for (int sl = 0; sl < E_->nstreams(); ++sl)
-		if (bits_ ? ((used_streams_ >> sl) & 1u) != 0 : sl < E_->main_streams()) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
+	/* bit-parallel batches wait for THEIR launches (the event behind each one's traceback), not for the streams
+	 * they ran on: batches of one engine share a few streams, and a streaming caller's later batches are queued
+	 * on them long before an earlier one is fetched -- waiting for the streams made every fetch wait for all of
+	 * them, the device then idled through the host's part of the fetch (trace: one batch on the device at a time) */
+	if (bits_) {
+		const int wrc = wait_batch();
+		if (wrc != CSADP_OK) return wrc;
+	} else {
+		for (int sl = 0; sl < E_->main_streams(); ++sl) HIP_TRY(hipStreamSynchronize(E_->stream(sl)));
+	}
 	return ran_ ? check_abort() : CSADP_OK;
+}
+
+int FillBatch::wait_batch()
+{
+	if (ev_up_) HIP_TRY(hipEventSynchronize(ev_up_));             /* the upload (a batch may never have run) */
+	for (int first = 0; first < Engine::kMaxSlots && first < 64; ++first)
+		if ((issued_ >> first) & 1ull) HIP_TRY(hipEventSynchronize(ev_[first][2]));
+	return CSADP_OK;
 }
 
 int FillBatch::download()
@@ -1381,6 +1413,7 @@ int FillBatch::download()
 		}
 	}
 	const size_t want = (io_ && !want_strings_) ? sum_bytes_ : res_bytes_;
+	if (bits_) st = E_->copy_stream();            /* sync() has waited for the batch: nothing to order the copy behind */
 	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], want, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
 	return CSADP_OK;

@@ -47,6 +47,9 @@ public:
 	 * the traceback of a bit-parallel launch runs there, so the next fill of stream q need not wait for it */
 	int main_streams() const { return slots_ < 2 ? 2 : slots_; }
 	int nstreams() const { return nstreams_; }
+	/* result downloads and abort-word reads of batches that have finished: a stream of its own, so that they never
+	 * queue behind what LATER batches have put on the compute streams */
+	hipStream_t copy_stream() const { return copy_stream_; }
 	int C() const { return C_; }
 	int R() const { return R_; }
 	int TR() const { return TR_; }
@@ -77,6 +80,7 @@ private:
 	char name_[256] = {0};
 	int slots_ = 2, nstreams_ = 0;
 	hipStream_t streams_[2 * kMaxSlots] = {};
+	hipStream_t copy_stream_ = nullptr;
 	std::atomic<int> stream_rr_{0};
 	std::mutex pool_mutex_;
 	std::vector<std::pair<uint8_t *, size_t>> arena_pool_, pinned_pool_;
@@ -188,6 +192,8 @@ private:
 	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0;
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	unsigned used_streams_ = 0;
+	unsigned long long issued_ = 0;             /* bit-parallel path: slot ranges (by first slot) with a launch on record */
+	int wait_batch();                           /* ... and the wait for exactly those launches (events, not streams) */
 	size_t abort_off_ = 0, serial_off_ = 0;
 	std::vector<TileRef> serial_tiles_;
 	std::vector<size_t> chunk_first_;

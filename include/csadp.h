@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CSADP_VERSION 200
+#define CSADP_VERSION 201
 
 /* only the C-ABI below is exported from libcsadp.so */
 #define CSADP_API __attribute__((visibility("default")))
@@ -112,6 +112,9 @@ typedef struct csadp_result {
  * progressive profile update.  results[t].status carries per-task errors. */
 CSADP_API int csadp_align_batch(const csadp_task *tasks, int ntasks, csadp_result *results);
 CSADP_API void csadp_free_result(csadp_result *r, int nseq);
+/* csadp_free_result on count results of tasks with nseq sequences each (a batch of pairs: nseq = 2); returns how
+ * many of them carried a status other than CSADP_OK -- one call per batch for callers that stream batches. */
+CSADP_API int csadp_free_results(csadp_result *results, int count, int nseq);
 
 /* ---- more than one GPU (independent tasks, no collective inside a matrix) -------- */
 
