@@ -1031,7 +1031,11 @@ int FillBatch::layout_bits()
 	launch_no_ = 0;
 	/* batches of one engine start on different streams, so that a streaming caller's batches (each one
 	 * pass, several in flight) overlap instead of queueing behind each other */
-	base_stream_ = E.rotate_stream() % E.main_streams();
+	/* ... unless ONE pass of the batch already covers the chip: then batches take turns on the same stream (first in,
+	 * first out, each traceback under the next batch's fill).  Side by side, three such batches progress at equal rates,
+	 * all complete late and together, and the caller's pipeline runs dry in between: 4.9 vs 4.25 ms per 512-pair batch. */
+	const bool rotate = env_int("CSADP_STREAM_ROTATE", nj < E.compute_units() ? 1 : 0) != 0;
+	base_stream_ = rotate ? E.rotate_stream() % E.main_streams() : 0;
 	used_streams_ = 0;
 	issued_ = 0;
 	bjobs_ = slot_jobs[0];
