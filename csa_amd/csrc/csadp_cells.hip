@@ -9,23 +9,22 @@
  * Why this shape.  The reference's own use of the DP (mode N) is a handful of wide gaps, each a chain
  * of up to 63 strictly sequential profile fills: what counts is the LATENCY of one fill, and a fill's
  * critical path is its nrows + ncols anti-diagonals.  The tiled kernel (csadp_kernels.hip) gives a
- * lane 16 columns x 2 rows per step -- ~200 dependent-issue-bound instructions -- and needs
- * nrows/2 + ncols/16 such steps; here a step is ONE cell (8 VALU instructions: two DPP moves, the
- * table lookup, two additions, max3, the direction shift, the tag mask; the compiler adds a ninth, a
- * register copy that pairs value and letter offset for the 64-bit hand-off store) and a matrix takes
- * nrows + ncols of them, on one wave per SIMD so that nothing else competes for the issue slot.
+ * lane 16 columns x 2 rows per step -- ~200 instructions -- and needs nrows/2 + ncols/16 such steps
+ * and a launch per tile anti-diagonal; here a step is ONE cell (7 VALU instructions in the
+ * hand-scheduled blocks, see cell_block_fast) and a matrix takes nrows + ncols of them, on one wave
+ * per SIMD so that nothing else competes for the issue slot.
  * Gain form and tie-break as in csadp_device.h: X = 4*H + 4*i*r, candidates tagged U 0 / L 1 / D 2,
  * one v_max3_i32 yields the reference's H and the reference's direction (D >= L >= U, :1014-1025).
  *
  * Data flow.  At local step l lane L of a strip works on row l - L + 1; the value and the letter
- * offset of that row come from lane L-1 (v_mov_b32_dpp wave_shr:1), which had the row one step
- * earlier.  Lane 0 takes them from LDS (`inject`, prepared per block of 32 steps): the border column
- * and the row letters for the first strip of a job, else the words the previous strip's lane 63
- * left in the LDS ring 63 steps earlier (same workgroup) or in `hand` in HBM (previous chunk: 8-byte
- * granules tagged with the launch's epoch, written through by one store each and requested one block
- * ahead by the consumer -- no counter, no fence).  Directions: 16 steps of 2-bit tags per
- * word and lane, one coalesced 256-byte store per wave every 16 steps = 0.25 B/cell, the algorithmic
- * figure of SURVEY 8(d).
+ * offset of that row come from lane L-1 (DPP wave_shr:1), which had the row one step earlier.  Lane 0
+ * takes the VALUE per block of 32 steps from the border column (first strip of a job), from the words
+ * the previous strip's lane 63 left in the LDS ring 63 steps earlier (same workgroup), or from `hand`
+ * in HBM (previous chunk: 8-byte granules tagged with the launch's epoch, written through by one store
+ * each and requested two blocks ahead by the consumer -- no counter, no fence); the LETTER offsets of a
+ * block's rows it reads from the row table itself (scalar loads), whatever the strip.  Directions:
+ * 16 steps of 2-bit tags per word and lane, one coalesced 256-byte store per wave every 16 steps =
+ * 0.25 B/cell, the algorithmic figure of SURVEY 8(d).
  *
  * Waits.  Inside a workgroup all waves are resident, so ring waits always end.  Across workgroups the
  * launch relies on the work list (a job's chunks in ascending order) being dispatched in order -- for
