@@ -59,11 +59,18 @@ __device__ __forceinline__ bool wait_lds(const int *counter, int need)
 	return true;
 }
 
-struct CellState {
+/* per lane: two adjacent columns, A (even) and B (odd) */
+struct CellColumn {
+	uint32_t tab;       /* gain table of the column (bytes 8*sv + 2, or 6-bit counts)                   */
+	uint32_t tabf;      /* the same for the hand-scheduled blocks: bytes reduced by leftc               */
+	int32_t leftc;      /* 4*(gaps - i) + 1                                                             */
 	int32_t hup;        /* X of the cell above (this column, previous row)                              */
-	int32_t diag;       /* X of the cell above-left = what came from the left last step (ramp blocks);
-	                     * the hand-scheduled blocks keep D = that value + leftc instead                */
-	int32_t outv;       /* this lane's X of the current row, tag cleared                                */
+	int32_t diag;       /* X of the cell above-left (ramp blocks); the hand-scheduled blocks keep
+	                     * D = that value + leftc instead                                               */
+	int32_t outv;       /* X of the column's cell in the current row, tag cleared                       */
+};
+struct CellState {
+	CellColumn A, B;
 	uint32_t outs;      /* the letter offset of the row this lane has just worked on                    */
 };
 
@@ -85,9 +92,26 @@ __device__ __forceinline__ uint32_t letter_of(const uint32_t (&lw)[kCellBlock / 
  * column), lw = the block's letter offsets, lanebuf[t] = where this lane's value of step t goes (the ring
  * for lane 63, a scrap area for all others: no EXEC change).
  */
+template <bool WIDE>
+__device__ __forceinline__ int32_t cell_ramp(CellColumn &C, int32_t in, uint32_t sh, uint32_t &acc, bool live)
+{
+	int32_t dg;
+	if (WIDE) dg = C.diag + 2 + (int32_t)(__builtin_amdgcn_ubfe(C.tab, sh, 6) << 3);    /* 6-bit counts: gain = 8*sv + 2 */
+	else dg = C.diag + (int32_t)__builtin_amdgcn_ubfe(C.tab, sh, 8);                    /* pre-scaled byte 8*sv + 2      */
+	const int32_t lf = in + C.leftc;
+	int32_t h = max(max(dg, C.hup), lf);
+	acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
+	h &= ~3;
+	/* rows above the matrix: the lane keeps its border values until its first row arrives */
+	C.diag = live ? in : C.diag;
+	C.hup = live ? h : C.hup;
+	C.outv = C.hup;
+	return C.outv;
+}
+
 template <bool WIDE, int ROLE>
-__device__ __forceinline__ void cell_block_ramp(CellState &S, uint32_t tab, int32_t leftc, const uint32_t *xin, int32_t xfirst, int32_t leftmul,
-                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[kCellBlock / 16],
+__device__ __forceinline__ void cell_block_ramp(CellState &S, const uint32_t *xin, int32_t xfirst, int32_t leftmul,
+                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
                                                 int l0, int lane)
 {
 	uint32_t ioff = 0;
@@ -95,26 +119,21 @@ __device__ __forceinline__ void cell_block_ramp(CellState &S, uint32_t tab, int3
 	uint32_t inx[kCellBlock];
 #pragma unroll
 	for (int t = 0; t < kCellBlock; ++t) inx[t] = ROLE == ROLE_FIRST ? (uint32_t)(xfirst + leftmul * t) : xin[ioff + t];
-	uint32_t acc = 0;
+	uint32_t accA = 0, accB = 0;
 #pragma unroll
 	for (int t = 0; t < kCellBlock; ++t) {
-		const int32_t in = __builtin_amdgcn_update_dpp((int)inx[t], S.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
+		/* column A's left neighbour is the left lane's column B of the same row; column B's is column A */
+		const int32_t in = __builtin_amdgcn_update_dpp((int)inx[t], S.B.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
 		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)letter_of(lw, t), (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		int32_t dg;
-		if (WIDE) dg = S.diag + 2 + (int32_t)(__builtin_amdgcn_ubfe(tab, sh, 6) << 3);    /* 6-bit counts: gain = 8*sv + 2 */
-		else dg = S.diag + (int32_t)__builtin_amdgcn_ubfe(tab, sh, 8);                    /* pre-scaled byte 8*sv + 2      */
-		const int32_t lf = in + leftc;
-		int32_t h = max(max(dg, S.hup), lf);
-		acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
-		h &= ~3;
-		/* rows above the matrix: the lane keeps its border values until its first row arrives */
 		const bool live = l0 + t >= lane;
-		S.diag = live ? in : S.diag;
-		S.hup = live ? h : S.hup;
-		S.outv = S.hup;
+		const int32_t a = cell_ramp<WIDE>(S.A, in, sh, accA, live);
+		const int32_t bval = cell_ramp<WIDE>(S.B, a, sh, accB, live);
 		S.outs = sh;
-		lanebuf[t] = (uint32_t)S.outv;
-		if ((t & 15) == 15) words[t >> 4] = acc;
+		lanebuf[t] = (uint32_t)bval;
+		if ((t & 15) == 15) {
+			words[0][t >> 4] = accA;
+			words[1][t >> 4] = accB;
+		}
 	}
 }
 
@@ -137,31 +156,35 @@ __device__ __forceinline__ void cell_block_ramp(CellState &S, uint32_t tab, int3
 #include "csadp_cells_block.inc"
 
 template <bool WIDE, int ROLE>
-__device__ __forceinline__ void cell_block_fast(CellState &S, uint32_t tabf, int32_t leftc, const uint32_t *window, int32_t xfirst, int32_t leftmul,
-                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[kCellBlock / 16])
+__device__ __forceinline__ void cell_block_fast(CellState &S, const uint32_t *window, int32_t xfirst, int32_t leftmul,
+                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16])
 {
-	int32_t outv = S.outv, dg = S.diag;
-	uint32_t sh = S.outs, w0, w1;
+	int32_t outvA = S.A.outv, outvB = S.B.outv, dgA = S.A.diag, dgB = S.B.diag;
+	uint32_t sh = S.outs, w0A, w1A, w0B, w1B;
 	const uint32_t waddr = (uint32_t)(uintptr_t)lanebuf;       /* LDS byte address = low half of the generic pointer */
 	const uint32_t raddr = (uint32_t)(uintptr_t)window;
-	const int32_t c2 = 2 - leftc;
+	const int32_t c2A = 2 - S.A.leftc, c2B = 2 - S.B.leftc;
 #define CELLS_BLOCK_OPERANDS                                                                                                   \
-	: [outv] "+v"(outv), [dg] "+v"(dg), [sh] "+v"(sh), [w0] "=&v"(w0), [w1] "=&v"(w1)                                         \
-	: [tab] "v"(tabf), [leftc] "v"(leftc), [c2] "v"(c2), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst),            \
-	  [lm] "v"(leftmul), [l0] "s"(lw[0]), [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]),                 \
-	  [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7])                                                                       \
+	: [outvA] "+v"(outvA), [outvB] "+v"(outvB), [dgA] "+v"(dgA), [dgB] "+v"(dgB), [sh] "+v"(sh), [w0A] "=&v"(w0A),             \
+	  [w1A] "=&v"(w1A), [w0B] "=&v"(w0B), [w1B] "=&v"(w1B)                                                                    \
+	: [tabA] "v"(S.A.tabf), [tabB] "v"(S.B.tabf), [leftcA] "v"(S.A.leftc), [leftcB] "v"(S.B.leftc), [c2A] "v"(c2A),           \
+	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [l0] "s"(lw[0]),            \
+	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7])   \
 	: CELLS_BLOCK_CLOBBERS
 	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
 	else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
 	else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
 	else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
 #undef CELLS_BLOCK_OPERANDS
-	S.outv = outv;
-	S.hup = outv;
-	S.diag = dg;
+	S.A.outv = S.A.hup = outvA;
+	S.B.outv = S.B.hup = outvB;
+	S.A.diag = dgA;
+	S.B.diag = dgB;
 	S.outs = sh;
-	words[0] = w0;
-	words[1] = w1;
+	words[0][0] = w0A;
+	words[0][1] = w1A;
+	words[1][0] = w0B;
+	words[1][1] = w1B;
 }
 
 constexpr int kRingWords = kRingSteps + 2 * kCellBlock;    /* the ring + the mirror of its first two blocks */
@@ -195,7 +218,7 @@ struct StripShared {
 };
 
 template <bool WIDE, int ROLE>
-__device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, CellState &S, uint32_t tab, uint32_t tabf, int32_t leftc, uint32_t *dirs,
+__device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, CellState &S, uint32_t *dirs, size_t dirs_half,
                                           const StripShared &L, unsigned long long *hand_out, const unsigned long long *hand_in, int wv,
                                           int lane, int nb, bool feeds, bool publishes, uint32_t epoch)
 {
@@ -225,7 +248,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	 * s_waitcnt vmcnt(0): it also waits for every store issued since.  So a block first consumes what was
 	 * loaded for it, THEN stores the direction words of the previous block and requests the next block's
 	 * data: everything a wait can see was issued a whole block (~1 us) earlier and costs nothing. */
-	uint32_t words[kCellBlock / 16] = {0, 0};
+	uint32_t words[2][kCellBlock / 16] = {{0, 0}, {0, 0}};        /* [column A / B][half of the block] */
 	int known_taken = 0;
 	uint32_t pubx = 0;
 	auto publish = [&](int b) {
@@ -259,8 +282,10 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		if (publishes && b > 0) publish(b - 1);
 		if (b > 0) {
 			uint32_t *d = dirs + (size_t)(b - 1) * (kCellBlock / 16) * kLanes;
-			d[0] = words[0];
-			d[kLanes] = words[1];
+			d[0] = words[0][0];
+			d[kLanes] = words[0][1];
+			d[dirs_half] = words[1][0];
+			d[dirs_half + kLanes] = words[1][1];
 		}
 #pragma unroll
 		for (int q = 0; q < kCellBlock / 4; ++q) nx[q] = rw[(b + 1) * (kCellBlock / 4) + q];   /* rowshift is padded */
@@ -279,10 +304,13 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		}
 		const int32_t xfirst = J.leftmul * (b * kCellBlock + 1);   /* border column: X[r][0] = leftmul * r (:967) */
 		if (b < 2) {
-			cell_block_ramp<WIDE, ROLE>(S, tab, leftc, window + 3, xfirst, J.leftmul, lw, lanebuf, words, b * kCellBlock, lane);
-			if (b == 1) S.diag += leftc;                        /* the hand-scheduled blocks keep D = diag + leftc */
+			cell_block_ramp<WIDE, ROLE>(S, window + 3, xfirst, J.leftmul, lw, lanebuf, words, b * kCellBlock, lane);
+			if (b == 1) {                                       /* the hand-scheduled blocks keep D = diag + leftc */
+				S.A.diag += S.A.leftc;
+				S.B.diag += S.B.leftc;
+			}
 		} else {
-			cell_block_fast<WIDE, ROLE>(S, tabf, leftc, window, xfirst + leftc, J.leftmul, lw, lanebuf, words);
+			cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, J.leftmul, lw, lanebuf, words);
 		}
 		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers */
 			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -311,8 +339,10 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	if (publishes) publish(nb - 1);
 	{
 		uint32_t *d = dirs + (size_t)(nb - 1) * (kCellBlock / 16) * kLanes;
-		d[0] = words[0];
-		d[kLanes] = words[1];
+		d[0] = words[0][0];
+		d[kLanes] = words[0][1];
+		d[dirs_half] = words[1][0];
+		d[dirs_half + kLanes] = words[1][1];
 	}
 	return true;
 }
@@ -344,12 +374,14 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	if (s >= J.nstrips) return;
 
 	const int nb = J.steps_pad / kCellBlock;
-	const int col = s * kLanes + lane;                         /* 0-based column of this lane */
-	const uint32_t tab = reinterpret_cast<const uint32_t *>(arena + J.coltab)[col];
-	const int32_t leftc = reinterpret_cast<const int32_t *>(arena + J.leftc)[col];
+	const int col = s * kCellStripCols + kCellCols * lane;     /* 0-based column A of this lane; B = col + 1 */
+	const uint32_t *coltab = reinterpret_cast<const uint32_t *>(arena + J.coltab);
+	const int32_t *leftcs = reinterpret_cast<const int32_t *>(arena + J.leftc);
 	const int32_t *top = reinterpret_cast<const int32_t *>(arena + J.top);
 	const uint8_t *rsh = arena + J.rowshift;
-	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + (size_t)s * (J.steps_pad / 16) * kLanes + lane;
+	/* directions: the columns A of a strip form "virtual strip" 2s, the columns B 2s + 1, each [steps_pad / 16][64 lanes] */
+	const size_t dirs_half = (size_t)(J.steps_pad / 16) * kLanes;
+	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + (size_t)s * kCellCols * dirs_half + lane;
 	unsigned long long *hand_out = reinterpret_cast<unsigned long long *>(arena + J.hand) + (size_t)chunk * J.steps_pad;
 	const unsigned long long *hand_in =
 	    reinterpret_cast<const unsigned long long *>(arena + J.hand) + (size_t)(chunk > 0 ? chunk - 1 : 0) * J.steps_pad;
@@ -357,9 +389,15 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	const bool publishes = wv + 1 == kCellWaves && s + 1 < J.nstrips;   /* the next chunk reads my hand-off words  */
 
 	CellState S;
-	S.hup = top[col + 1];
-	S.diag = top[col];
-	S.outv = S.hup;
+	S.A.tab = coltab[col];
+	S.B.tab = coltab[col + 1];
+	S.A.leftc = leftcs[col];
+	S.B.leftc = leftcs[col + 1];
+	S.A.diag = top[col];
+	S.A.hup = S.B.diag = top[col + 1];
+	S.B.hup = top[col + 2];
+	S.A.outv = S.A.hup;
+	S.B.outv = S.B.hup;
 	S.outs = 0;
 	StripShared L;
 	L.ring_mine = ring[wv];
@@ -370,36 +408,41 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	L.taken = taken;
 	/* table of the hand-scheduled blocks: gain bytes reduced by leftc (8*sv + 2 - leftc = 8*sv + 4*(i - gaps) + 1 <= 12*i + 1:
 	 * the host takes the WIDE form from i = 22 on); WIDE keeps the counts and adds 2 - leftc in the step */
-	uint32_t tabf = tab;
+	S.A.tabf = S.A.tab;
+	S.B.tabf = S.B.tab;
 	if (!WIDE) {
-		tabf = 0;
+		S.A.tabf = S.B.tabf = 0;
 #pragma unroll
-		for (int y = 0; y < 4; ++y) tabf |= ((((tab >> (8 * y)) & 255u) - (uint32_t)leftc) & 255u) << (8 * y);
+		for (int y = 0; y < 4; ++y) {
+			S.A.tabf |= ((((S.A.tab >> (8 * y)) & 255u) - (uint32_t)S.A.leftc) & 255u) << (8 * y);
+			S.B.tabf |= ((((S.B.tab >> (8 * y)) & 255u) - (uint32_t)S.B.leftc) & 255u) << (8 * y);
+		}
 	}
 	bool ok;
-	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, tab, tabf, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
-	else if (wv > 0) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, tab, tabf, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
-	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, tab, tabf, leftc, dirs, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	else if (wv > 0) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
 	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }
 
 /*
- * K2d.  Cell (j, k), 1-based, lives in strip s = (k-1)/64, lane (k-1)%64, at local step
- * l = (j-1) + lane, i.e. at "global step" g = l + 64*s = j + k - 2, its anti-diagonal.  Word
- * l/16 of (strip, lane) holds its tag at bits 2*(l%16).  A diagonal move lowers g by 2, a left or up
- * move by 1, so while the path crosses one strip (64 columns) g falls by ~128 = 8 words: the LDS window
- * holds, for each of the kTbStrips strips left of the current cell, the kTbWords words around the
- * expected crossing -- 16 x 16 x 64 words = 64 KiB, loaded as whole 256-byte rows by the four waves.
- * Wave 0 then walks run-batched (lane i looks at cell (j-i, k-i), a ballot finds the end of the
- * run of 'D'); leaving the window just reloads it around the current cell.
+ * K2d.  Cell (j, k), 1-based: column c = k - 1 lives in strip S = c / 128, lane (c % 128) / 2, half h = c % 2
+ * (column A or B of the lane), at local step l = (j - 1) + lane.  Word l / 16 of "virtual strip" 2S + h holds its
+ * tag at bits 2 * (l % 16).  Along a diagonal move the row falls by one and the lane by one every second column, so
+ * while the path crosses one strip (128 columns) l falls by ~192 = 12 words: the LDS window holds, for each of the
+ * kTbStrips strips left of the current cell and both halves, the kTbWords words around the expected crossing --
+ * 8 x 2 x 16 x 64 words = 64 KiB, loaded as whole 256-byte rows by the four waves.  Wave 0 then walks run-batched
+ * (lane i looks at cell (j-i, k-i), a ballot finds the end of the run of 'D'); leaving the window just reloads it
+ * around the current cell.
  */
-constexpr int kTbStrips = 16;
-constexpr int kTbWords = 16;
-constexpr int kTbSlack = 3;          /* words above the expected entry point of a strip */
+static_assert(kCellStripCols == 128, "the walk's shifts assume 128 columns per strip");
+constexpr int kTbStrips = 4;
+constexpr int kTbWords = 32;
+constexpr int kTbSlack = 8;          /* words above the expected entry point of a strip */
 
 __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs)
 {
-	__shared__ __attribute__((aligned(16))) uint32_t win[kTbStrips * kTbWords * kLanes];
+	__shared__ __attribute__((aligned(16))) uint32_t win[kTbStrips * kCellCols * kTbWords * kLanes];
 	__shared__ int wlo[kTbStrips];
 	__shared__ int pos[3];
 
@@ -408,27 +451,27 @@ __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ 
 	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
 	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int wpitch = J.steps_pad / 16;                      /* words per (strip, lane) */
+	const int wpitch = J.steps_pad / 16;                      /* words per (virtual strip, lane) */
 	int j = J.nrows, k = J.ncols;
 	int n = 0;
 
 	while (j > 0 && k > 0) {
-		const int s0 = (k - 1) >> 6;
-		const int g0 = j + k - 2;
+		const int s0 = (k - 1) >> 7;                              /* kCellStripCols = 128 */
 		if (tid < kTbStrips) {
-			/* strip s0 - tid: the path is expected at its right edge (column 64*s + 64) on anti-diagonal
-			 * g0 - 2*(k - 64*s - 64); for the current strip that point is extrapolated to the right */
+			/* strip s0 - tid: the path is expected at its right edge (column 128*s + 127, lane 63) in row
+			 * j - (k - 1 - that column); for the current strip that point is extrapolated to the right */
 			const int sB = s0 - tid;
-			const int gedge = g0 - 2 * (k - 64 * sB - 64);
-			wlo[tid] = ((gedge - 64 * sB) >> 4) + kTbSlack - (kTbWords - 1);
+			const int jedge = j - ((k - 1) - (kCellStripCols * sB + kCellStripCols - 1));
+			wlo[tid] = ((jedge - 1 + (kLanes - 1)) >> 4) + kTbSlack - (kTbWords - 1);
 		}
 		__syncthreads();
-		/* kTbStrips * kTbWords rows of 256 bytes = 16 uint4 per row */
-		for (int e = tid; e < kTbStrips * kTbWords * 16; e += 256) {
-			const int B = e / (kTbWords * 16), u = (e / 16) % kTbWords, q = e % 16;
-			const int sB = s0 - B, w = wlo[B] + u;
+		/* kTbStrips * 2 * kTbWords rows of 256 bytes = 16 uint4 per row; slot = strip block * 2 + half */
+		for (int e = tid; e < kTbStrips * kCellCols * kTbWords * 16; e += 256) {
+			const int slot = e / (kTbWords * 16), u = (e / 16) % kTbWords, q = e % 16;
+			const int sB = s0 - slot / kCellCols, w = wlo[slot / kCellCols] + u;
 			uint4 v = make_uint4(0, 0, 0, 0);
-			if (sB >= 0 && w >= 0 && w < wpitch) v = *reinterpret_cast<const uint4 *>(dirs + ((size_t)sB * wpitch + w) * kLanes + 4 * q);
+			if (sB >= 0 && w >= 0 && w < wpitch)
+				v = *reinterpret_cast<const uint4 *>(dirs + ((size_t)(sB * kCellCols + slot % kCellCols) * wpitch + w) * kLanes + 4 * q);
 			reinterpret_cast<uint4 *>(win)[e] = v;
 		}
 		__syncthreads();
@@ -439,17 +482,18 @@ __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ 
 			for (;;) {
 				/* one iteration = one LDS look-up per lane, straight-line: lane i looks at cell (j - i, k - i) */
 				const int kc = k - 1;                           /* 0-based column of lane 0's cell */
-				const int Bk = s0 - (kc >> 6);                  /* its strip block (wave-uniform) */
+				const int Bk = s0 - (kc >> 7);                  /* its strip block (wave-uniform) */
 				if (Bk >= kTbStrips) break;
 				const int wloA = __builtin_amdgcn_readlane(wreg, Bk);
 				const int wloB = __builtin_amdgcn_readlane(wreg, Bk + 1 < kTbStrips ? Bk + 1 : Bk);
 				const int ri = j - lane, kz = kc - lane;        /* row (1-based), column (0-based): outside the matrix when <= 0 / < 0 */
-				const int sc = kz >> 6;                         /* arithmetic: negative columns give a strip that fails the tests below */
+				const int sc = kz >> 7;                         /* arithmetic: negative columns give a strip that fails the tests below */
 				const int B = s0 - sc;
-				const int l = ri + kz - 1 - (kz & ~63);         /* local step of the cell in its strip */
-				const int u = (l >> 4) - (sc == (kc >> 6) ? wloA : wloB);
+				const int ln = (kz & (kCellStripCols - 1)) >> 1;   /* the lane that owns the column */
+				const int l = ri - 1 + ln;                      /* local step of the cell in its strip */
+				const int u = (l >> 4) - (sc == (kc >> 7) ? wloA : wloB);
 				const bool ok = (ri > 0) & (kz >= 0) & (B < kTbStrips) & ((unsigned)u < (unsigned)kTbWords);
-				const uint32_t w = win[ok ? (B * kTbWords + u) * kLanes + (kz & 63) : 0];
+				const uint32_t w = win[ok ? ((B * kCellCols + (kz & 1)) * kTbWords + u) * kLanes + ln : 0];
 				const uint32_t code = ok ? (w >> (2 * (l & 15))) & 3u : 3u;     /* 3 = stop: border or outside the window */
 				/* a run of 'D' and the gap move that ends it are taken in ONE iteration, written by ONE store */
 				const unsigned long long stop = __ballot(code != DIR_D);

@@ -162,6 +162,8 @@ struct BitJob {
  */
 constexpr int kCellWaves = 4;        /* strips per workgroup: one wave per SIMD of a compute unit      */
 constexpr int kCellBlock = 32;       /* steps per hand-off block                                       */
+constexpr int kCellCols = 2;         /* adjacent columns per lane                                      */
+constexpr int kCellStripCols = kLanes * kCellCols;   /* columns per strip (wave)                     */
 
 struct CellJob {
 	uint64_t coltab;          /* u32 [ncols_pad] diag gains per row letter (narrow bytes / wide 6-bit counts, as FillJob) */
@@ -176,7 +178,7 @@ struct CellJob {
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;
-	int32_t nstrips;          /* ceil(ncols / 64)                                                                          */
+	int32_t nstrips;          /* ceil(ncols / 128)                                                                         */
 	int32_t nchunks;          /* ceil(nstrips / kCellWaves)                                                                */
 	int32_t steps_pad;        /* local steps per strip, multiple of kCellBlock, >= nrows + 64                              */
 	int32_t nprev;            /* i                                                                                          */

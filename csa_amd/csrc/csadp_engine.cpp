@@ -498,15 +498,15 @@ int FillBatch::layout_cells()
 		C.ncols = J.ncols;
 		C.nprev = J.nprev;
 		C.leftmul = J.leftmul;
-		C.nstrips = (J.ncols + kLanes - 1) / kLanes;
+		C.nstrips = (J.ncols + kCellStripCols - 1) / kCellStripCols;
 		C.nchunks = (C.nstrips + kCellWaves - 1) / kCellWaves;
 		C.steps_pad = (int)align_up((size_t)J.nrows + 64, kCellBlock);
 		J.nstrips = C.nstrips;
 		J.steps_pad = C.steps_pad;
 		J.padl = 0;
-		extra_[(size_t)j].ncols_pad = C.nstrips * kLanes;
+		extra_[(size_t)j].ncols_pad = C.nstrips * kCellStripCols;
 		cells_ += (long long)J.nrows * J.ncols;
-		dir_bytes_ += (long long)C.nstrips * (C.steps_pad / 16) * kLanes * 4;
+		dir_bytes_ += (long long)C.nstrips * kCellCols * (C.steps_pad / 16) * kLanes * 4;
 		border_bytes_ += (long long)std::max(C.nchunks - 1, 0) * C.steps_pad * 8 * 2;      /* written once, read once */
 	}
 	{
@@ -514,7 +514,7 @@ int FillBatch::layout_cells()
 		for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
 		std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
 			const CellJob &A = cjobs_[(size_t)a], &B = cjobs_[(size_t)b];
-			return (long long)A.steps_pad + 64LL * A.nstrips > (long long)B.steps_pad + 64LL * B.nstrips;   /* wavefront length */
+			return (long long)A.steps_pad + 96LL * A.nstrips > (long long)B.steps_pad + 96LL * B.nstrips;   /* wavefront length */
 		});
 		for (int j : order)
 			for (int c = 0; c < cjobs_[(size_t)j].nchunks; ++c) {
@@ -580,7 +580,7 @@ int FillBatch::layout_cells()
 		for (int j = 0; j < nj; ++j) {
 			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
 			C.dirs = off;
-			off = align_up(off + (size_t)C.nstrips * (C.steps_pad / 16) * kLanes * 4, 256);
+			off = align_up(off + (size_t)C.nstrips * kCellCols * (C.steps_pad / 16) * kLanes * 4, 256);
 		}
 		hand_off_[sl] = off;                          /* the hand-off granules of all jobs, contiguous: zeroed by upload() */
 		for (int j = 0; j < nj; ++j) {

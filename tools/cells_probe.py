@@ -20,7 +20,7 @@ def seq(n):
     return bytes(rnd.choice(b"ACGT") for _ in range(n))
 
 
-SHAPES = [(32768, 64), (32768, 256), (32768, 512), (32768, 1024), (64, 16384), (64, 32768), (5000, 6187), (16384, 16384)]
+SHAPES = [(32768, 128), (32768, 512), (32768, 1024), (32768, 2048), (64, 16384), (64, 32768), (5000, 6187), (16384, 16384)]
 for nrows, ncols in SHAPES:
     # the column sequence is the first of the pair, the row sequence the second
     task = ([seq(ncols), seq(nrows)], [0, 0], None, None)
@@ -34,7 +34,7 @@ for nrows, ncols in SHAPES:
             best = t
     if os.environ.get('CSADP_CELL_STATS'): pb.fetch()
     pb.close()
-    strips = (ncols + 63) // 64
+    strips = (ncols + 127) // 128
     steps96 = strips * 96 + nrows
     steps64 = strips * 64 + nrows
     cyc = best["fill_ms"] * 2.4e6
