@@ -3,21 +3,22 @@
  * stale borders included) as a persistent cell-per-lane wavefront, and its direction walk
  * (dynamicprogramming.c:1037-1047).  gfx950, wave64.
  *
- *   nw_fill_cells<WIDE>    K1c: a lane owns one column, a wave 64 columns, a workgroup kCellWaves strips
+ *   nw_fill_cells<WIDE>    K1c: a lane owns two adjacent columns, a wave 128, a workgroup kCellWaves strips
  *   nw_traceback_cells     K2d: the run-batched walk over K1c's direction words
  *
  * Why this shape.  The reference's own use of the DP (mode N) is a handful of wide gaps, each a chain
  * of up to 63 strictly sequential profile fills: what counts is the LATENCY of one fill, and a fill's
  * critical path is its nrows + ncols anti-diagonals.  The tiled kernel (csadp_kernels.hip) gives a
  * lane 16 columns x 2 rows per step -- ~200 instructions -- and needs nrows/2 + ncols/16 such steps
- * and a launch per tile anti-diagonal; here a step is ONE cell (7 VALU instructions in the
- * hand-scheduled blocks, see cell_block_fast) and a matrix takes nrows + ncols of them, on one wave
- * per SIMD so that nothing else competes for the issue slot.
+ * and a launch per tile anti-diagonal; here a step is ONE row of the lane's two columns (13 VALU
+ * instructions in the hand-scheduled blocks, see cell_block_fast) and a matrix takes nrows + ncols / 2 of
+ * them, on one wave per SIMD so that nothing else competes for the issue slot.
  * Gain form and tie-break as in csadp_device.h: X = 4*H + 4*i*r, candidates tagged U 0 / L 1 / D 2,
  * one v_max3_i32 yields the reference's H and the reference's direction (D >= L >= U, :1014-1025).
  *
- * Data flow.  At local step l lane L of a strip works on row l - L + 1; the value and the letter
- * offset of that row come from lane L-1 (DPP wave_shr:1), which had the row one step earlier.  Lane 0
+ * Data flow.  At local step l lane L of a strip works on row l - L + 1 of its columns A (even) and B
+ * (odd); A's left neighbour and the letter offset of that row come from lane L-1 (its column B; DPP
+ * wave_shr:1), which had the row one step earlier, B's left neighbour is A's fresh value.  Lane 0
  * takes the VALUE per block of 32 steps from the border column (first strip of a job), from the words
  * the previous strip's lane 63 left in the LDS ring 63 steps earlier (same workgroup), or from `hand`
  * in HBM (previous chunk: 8-byte granules tagged with the launch's epoch, written through by one store

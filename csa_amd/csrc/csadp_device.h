@@ -152,13 +152,14 @@ struct BitJob {
 
 /*
  * Cell-per-lane job (csadp_cells.hip): ONE matrix fill of any progressive step (any i, stale borders
- * included) as a persistent wavefront.  A lane owns ONE column, a wave a strip of 64 columns, a
- * workgroup a chunk of kCellWaves strips; lane L of a strip computes row (l - L + 1) at its local step
- * l, so the whole matrix takes nrows + ncols steps of ~8 VALU instructions instead of the tiled
- * kernel's 16 columns x 2 rows per lane-step: the latency of a single large matrix -- what the
- * reference's own use (mode N: a few wide gaps, up to 63 sequential profile steps each) is bound by --
- * drops by an order of magnitude.  Waves of a workgroup hand the right edge over through an LDS ring,
- * workgroups of a job through `hand` in HBM + a published block counter (as nw_fill_bits_wide).
+ * included) as a persistent wavefront.  A lane owns kCellCols adjacent columns, a wave a strip of 128, a
+ * workgroup a chunk of kCellWaves strips; lane L of a strip computes row (l - L + 1) of its columns at its
+ * local step l, so the whole matrix takes nrows + ncols / 2 steps of 13 VALU instructions instead of the
+ * tiled kernel's 16 columns x 2 rows per lane-step and a launch per tile anti-diagonal: the latency of a
+ * single large matrix -- what the reference's own use (mode N: a few wide gaps, up to 63 sequential profile
+ * steps each) is bound by.  Waves of a workgroup hand the right edge over through an LDS ring, workgroups of
+ * a job through epoch-tagged granules in `hand` in HBM.  Directions: the columns A (even) of strip s are
+ * "virtual strip" 2s, the columns B 2s + 1; a virtual strip is [steps_pad / 16][64 lanes] words of 16 tags.
  */
 constexpr int kCellWaves = 4;        /* strips per workgroup: one wave per SIMD of a compute unit      */
 constexpr int kCellBlock = 32;       /* steps per hand-off block                                       */
@@ -168,12 +169,13 @@ constexpr int kCellStripCols = kLanes * kCellCols;   /* columns per strip (wave)
 struct CellJob {
 	uint64_t coltab;          /* u32 [ncols_pad] diag gains per row letter (narrow bytes / wide 6-bit counts, as FillJob) */
 	uint64_t leftc;           /* i32 [ncols_pad] left gain 4*(sv[4]-i) + 1                                                */
-	uint64_t rowshift;        /* u8  [steps_pad + 64] bfe offset of the letter of row j at index j-1, zero padded          */
+	uint64_t rowshift;        /* u8  [steps_pad + 576] bfe offset of the letter of row j at index j-1, zero padded         */
 	uint64_t top;             /* i32 [ncols_pad + 1] X of border row 0 (possibly stale, survey Q1)                        */
-	uint64_t dirs;            /* u32 [nstrips][steps_pad/16][64]: the 2-bit tags of 16 consecutive local steps of one      */
-	                          /*     column; local step l of the column with lane L is row l - L + 1; first step in bits 1:0 */
-	uint64_t hand;            /* u64 [nchunks-1][steps_pad] granules {X, letter offset | epoch << 8} leaving the last lane of   */
-	                          /*     each chunk but the last: valid when they carry the launch's epoch                       */
+	uint64_t dirs;            /* u32 [nstrips][2][steps_pad/16][64]: the 2-bit tags of 16 consecutive local steps of one   */
+	                          /*     column (half 0: the lane's column A, half 1: B); local step l of lane L is row l - L + 1; */
+	                          /*     first step in bits 1:0                                                                 */
+	uint64_t hand;            /* u64 [nchunks-1][steps_pad] granules {X, epoch << 8} leaving the last column of each chunk   */
+	                          /*     but the last: valid when they carry the launch's epoch                                  */
 	uint64_t progress;        /* unused (kept for layout stability)                                                          */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
