@@ -151,8 +151,10 @@ __device__ __forceinline__ void cell_block_ramp(CellState &S, const uint32_t *xi
  *     pre-reduced by leftc (gain' = 8*sv + 2 - leftc), which makes lf + gain' = in + gain;
  *   - only X is handed to the next strip (its lane 0 takes the letters from the row sequence, like every first
  *     strip): lane 63's 32 values stay in registers and leave in 8 x ds_write_b128, 9 x ds_read_b128 bring the
- *     next strip's in -- 17 LDS instructions per block where the plain form has 48.
- * 7 VALU per step + 2 per step at the block's head (lane-0 presets of X and letter offset).
+ *     next strip's in -- 17 LDS instructions per block where the plain form has 48;
+ *   - a lane works on two adjacent columns per step: B's left neighbour is A's fresh value (a plain v_add), so the
+ *     cross-lane move, the letter move and every hand-off serve two cells.
+ * 13 VALU per step (two cells) + 2 per step at the block's head (lane-0 presets of X and letter offset).
  */
 #include "csadp_cells_block.inc"
 
