@@ -85,6 +85,25 @@ def test_host_logic_medium_families_vs_oracle(refine_mode):
         assert got["score"] == st.last_score and got["cells"] == st.cells and got["fills"] == st.fills
 
 
+def test_free_results_counts_failures_and_frees_everything():
+    """csadp_free_results (one call per batch for streaming callers): frees every result, reports how many carried an
+    error; results of the test seam serve as input (one of them fails on its alphabet)."""
+    import ctypes
+    fill = oracle_filler()
+    L = csa_amd.lib()
+    res = (csa_amd.Result * 3)()
+    tasks = [([b"ACGTACGT", b"ACGAACGT"], None, None, None), ([b"ACGT", b"ACXT"], None, None, None), ([b"AC", b"AC"], None, None, None)]
+    cb = csa_amd.DEBUG_FILL_FN(fill)
+    for i, t in enumerate(tasks):
+        ta = csa_amd.TaskArray([t])
+        L.csadp_debug_align_with_filler(ta.arr, cb, None, ctypes.byref(res[i]))
+    assert [r.status for r in res] == [0, csa_amd.ERR_ALPHABET, 0]
+    assert L.csadp_free_results(res, 3, 2) == 1
+    assert all(not r.aligned and not r.progress for r in res)
+    assert L.csadp_free_results(res, 3, 2) == 1            # idempotent on freed results
+    assert L.csadp_free_results(None, 0, 2) == 0
+
+
 def test_host_logic_rejects_bad_input():
     fill = oracle_filler()
     assert csa_amd.debug_align_with_filler(([b"ACGT", b"ACXT"], None, None, None), fill)["status"] == csa_amd.ERR_ALPHABET
