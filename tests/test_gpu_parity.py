@@ -490,3 +490,37 @@ def test_whole_config5_in_one_batch():
         want = list(ex.map(lambda i: oracle_pair_score_linear(tasks[i][0], tasks[i][1]), sample))
     assert [got[i]["score"] for i in sample] == want
     assert max(len(tasks[i][0][0]) for i in sample) > 190000
+
+
+def test_batches_in_flight_are_independent():
+    """A streaming caller keeps several pair batches in flight on one engine (create + run + flush, fetch later).  A
+    batch waits for ITS launches only (events, not the streams it shares with later batches) and its results come down
+    on a copy stream: fetching the batches newest first, while older ones are still queued or running, must still
+    return every batch's own results.  Small batches (side by side on rotating streams) and batches that fill the
+    chip (first in, first out on one stream) take different paths through the engine."""
+    r = rng(4242)
+    for npairs, length in ((6, 900), (300, 700)):
+        sets = []
+        for b in range(4):
+            tasks = []
+            for i in range(npairs):
+                a, c, ra, rc = synth_pair(100000 + 1000 * b + i + 17 * length, length=length)
+                tasks.append(([a, c], [ra, rc], None, None))
+            sets.append(tasks)
+        batches = []
+        for tasks in sets:
+            pb = csa_amd.PairBatch(tasks)
+            pb.run()
+            pb.flush()
+            batches.append(pb)
+        for b in (3, 1, 2, 0):                      # newest first, then out of order
+            got = batches[b].fetch()
+            for t, g in zip(sets[b][:8] + sets[b][-2:], got[:8] + got[-2:]):
+                cons, strs, st = oracle_progressive(t[0], t[1])
+                assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score
+            for t, g in zip(sets[b], got):          # every pair: the rows spell the rotated inputs, SP = score
+                assert degap(g["aligned"][0]) == rotated(t[0][0], t[1][0])
+                assert degap(g["aligned"][1]) == rotated(t[0][1], t[1][1])
+                assert sp_score(g["aligned"]) == g["score"]
+        for pb in batches:
+            pb.close()
