@@ -442,6 +442,7 @@ static_assert(kCellStripCols == 128, "the walk's shifts assume 128 columns per s
 constexpr int kTbStrips = 4;
 constexpr int kTbWords = 32;
 constexpr int kTbSlack = 8;          /* words above the expected entry point of a strip */
+constexpr int kTbExtra = 2;          /* rounds taken from the fetched words after a look-up's own */
 
 __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs)
 {
@@ -508,6 +509,35 @@ __global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ 
 				j -= run + (gap & (c0 != DIR_L));
 				k -= run + (c0 == DIR_L);
 				if (run + gap == 0) break;                      /* border reached or window left: the outer loop decides */
+				/* More rounds out of the SAME words: after a gap move the cells of the new diagonal are the fetched
+				 * columns one row up (after U) or down (after L) -- in the same word 15 times out of 16, since a word
+				 * holds 16 consecutive rows of its column.  Lane q >= p looks at its column again, p = columns consumed,
+				 * delta = rows the diagonal has drifted.  No look-up, ~1/3 of an iteration's cost; kTbExtra rounds at
+				 * most (every further one finds fewer of its tags in the fetched words). */
+				int p = run + (c0 == DIR_L), delta = 0;
+				uint32_t last = c0;
+				bool more = gap != 0;
+#pragma unroll
+				for (int extra = 0; extra < kTbExtra; ++extra) {
+					if (!more || p >= kLanes) break;
+					delta += last == DIR_L ? 1 : -1;
+					const int l2 = l + delta;
+					const bool ok2 = ok & (lane >= p) & (ri + delta > 0) & ((l2 >> 4) == (l >> 4));
+					const uint32_t code2 = ok2 ? (w >> (2 * (l2 & 15))) & 3u : 3u;
+					const unsigned long long stop2 = __ballot(code2 != DIR_D) >> p;
+					const int left = kLanes - p;
+					const int run2 = stop2 ? __builtin_ctzll(stop2) : left;
+					const uint32_t c2 = run2 < left ? (uint32_t)__builtin_amdgcn_readlane((int)code2, p + run2) : 3u;
+					const int gap2 = c2 != 3u;
+					const int i2 = lane - p;
+					if (i2 >= 0 && i2 < run2 + gap2) ops[n + i2] = (uint8_t)(i2 < run2 ? (uint32_t)DIR_D : c2);
+					n += run2 + gap2;
+					j -= run2 + (gap2 & (c2 != DIR_L));
+					k -= run2 + (c2 == DIR_L);
+					p += run2 + (c2 == DIR_L);
+					last = c2;
+					more = gap2 != 0;
+				}
 			}
 			if (lane == 0) {
 				pos[0] = j;
