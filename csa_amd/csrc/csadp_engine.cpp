@@ -1399,6 +1399,23 @@ int FillBatch::download()
 {
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!ran_) return CSADP_ERR_STATE;
+	if (cells_mode_ && nslots_ == 1) {
+		/* the lock-step rounds of N-sequence tasks: ONE wait per round.  Abort word and results are queued behind
+		 * the traceback and waited for together (sync() + check_abort() + the copy were three round trips to the
+		 * device, ~20 us each, 15 times per alignment) */
+		const int frc = flush();
+		if (frc != CSADP_OK) return frc;
+		hipStream_t st = E_->stream(last_slot_);
+		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], res_bytes_, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		if (*h_abort_ == 0) return CSADP_OK;
+		const int arc = check_abort();                 /* repeats the pass chunk by chunk */
+		if (arc != CSADP_OK) return arc;
+		HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], res_bytes_, hipMemcpyDeviceToHost, st));
+		HIP_TRY(hipStreamSynchronize(st));
+		return CSADP_OK;
+	}
 	{
 		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
 		if (rc != CSADP_OK) return rc;
