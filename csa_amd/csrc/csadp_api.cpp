@@ -253,15 +253,27 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	 * largest gap of a run kept every round waiting for it. */
 	lap();
 	{
+		/* items: (task, chunk >= 0) = speculate that chunk of a LARGE task; (task, -1) = the whole refinement of a small
+		 * one, plain.  The passes of the large tasks follow -- there are a handful at most, so that loop usually runs on
+		 * this thread without waking the pool a third time. */
+		constexpr int kLargeColumns = 1024;
 		std::vector<std::pair<int, int>> items;
+		std::vector<int> large;
 		for (size_t j = 0; j < active.size(); ++j) {
-			if (status[active[j]] != CSADP_OK) continue;
-			const int chunks = tasks[active[j]].refine_prepare();
-			for (int c = 0; c < chunks; ++c) items.emplace_back(active[j], c);
+			const int t = active[j];
+			if (status[t] != CSADP_OK) continue;
+			if (tasks[t].ncols() < kLargeColumns) { items.emplace_back(t, -1); continue; }
+			const int chunks = tasks[t].refine_prepare();
+			for (int c = 0; c < chunks; ++c) items.emplace_back(t, c);
+			if (chunks > 0) large.push_back(t);
 		}
-		parallel_for((int)items.size(), [&](int i) { tasks[items[(size_t)i].first].refine_speculate(items[(size_t)i].second); });
+		parallel_for((int)items.size(), [&](int i) {
+			Progressive &p = tasks[items[(size_t)i].first];
+			if (items[(size_t)i].second >= 0) p.refine_speculate(items[(size_t)i].second);
+			else p.refine_commit();
+		});
 		lap();
-		parallel_for((int)active.size(), [&](int j) { tasks[active[(size_t)j]].refine_commit(); });
+		parallel_for((int)large.size(), [&](int i) { tasks[large[(size_t)i]].refine_commit(); });
 	}
 	lap();
 	if (trace)
