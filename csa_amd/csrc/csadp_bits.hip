@@ -28,8 +28,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <type_traits>
-
 #include "csadp_device.h"
 #include "csadp_kernels.h"
 
@@ -37,9 +35,8 @@ namespace csadp {
 
 namespace {
 
-static_assert(kBitCkptWords == 1, "the carry-mask step holds one word of 32 columns per lane");
-
 constexpr int kRing = 8;                 /* hand-off blocks (of 32 steps) buffered per strip boundary */
+constexpr int kRingSteps = kRing * kBitBlock;
 constexpr int kSpinMax = 1 << 22;        /* bound of every wait (~0.5 s) */
 
 /* v_bitop3_b32: any boolean function of three words in one instruction; the table is the function
@@ -47,161 +44,179 @@ constexpr int kSpinMax = 1 << 22;        /* bound of every wait (~0.5 s) */
 constexpr uint32_t LA = 0xF0, LB = 0xCC, LC = 0xAA;
 #define BITOP3(a, b, c, expr) ((uint32_t)__builtin_amdgcn_bitop3_b32((a), (b), (c), (unsigned char)((expr) & 0xff)))
 
-/* per lane: the horizontal steps of the row above its 32 columns: NOT ">= 0", ">= 1", ">= 2" */
-struct BitState {
-	uint32_t nH0, H1, H2;
-};
+/* value of lane-1: over the whole wave (lane 0 keeps `old`), or inside each row of 16 lanes (the
+ * first lane of every row keeps `old`) */
+template <bool ROWS>
+__device__ __forceinline__ uint32_t from_left(uint32_t old, uint32_t src)
+{
+	/* written as the instruction itself so that the register holding `old` IS the destination
+	 * (the builtin costs a v_mov plus two wait states per step) */
+	if (ROWS) asm("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+	else asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
+	return old;
+}
 
 /*
- * What crosses from a lane to its right neighbour is one bit per plane and step -- the vertical step
- * at the word's right edge -- and that bit IS the carry out of the word's addition: the ">= 2" and
- * ">= 1" planes are carry chains resolved by s = propagate + generate + carry_in (generate is a subset
- * of propagate, so the carry out of bit k is generate | propagate & carry, the chain itself), and the
- * ">= 0" plane's (O0 << 1) | bit is O0 + O0 + carry_in with carry out = O0's top bit.  v_addc_co_u32
- * takes the carry-in of every lane from an SGPR pair and leaves the carry-outs in one: three lane masks
- * per wave, moved one lane to the right by the SCALAR unit between two steps.  The round-2 form carried
- * them in a VGPR hand-off word (one DPP move, two v_perm, four v_bfe, two v_add3 and two v_bitop3 for the
- * outgoing planes per step, and an LDS store of that word): 31 VALU instructions per step against 22
- * here, and nothing per step in LDS.
- *
- * Carries: the carry-OUT masks of the step before (bit L = lane L).  Feed: what enters lane 0 and
- * what leaves lane 63 -- in: one word per plane and block, consumed from the top bit (step t of the
- * block takes bit 31 - t); acc: the bits leaving lane 63, shifted in from below.  One chain per plane
- * and step does all of it through SCC:  in += in (top bit -> SCC);  lo = 2 lo + SCC;  hi = 2 hi + carry;
- * acc = 2 acc + carry.  The shift at the head of step t moves the carry-outs of step t - 1, so after
- * the 32 steps of block b an accumulator holds the bits that left lane 63 in steps 32b - 1 .. 32b + 30
- * (first at the top), which is exactly what lane 0 of the strip to the right consumes in ITS block
- * b - 2: its row t is lane 63's row at step t + 63.
+ * The word a lane hands to its right neighbour after every step (one DPP move per step):
+ *   bit 31 / 23 / 15  top bit of the outgoing vertical-step planes ">= 0" / ">= 1" / ">= 2"
+ *   bits 1..0          letter of the row both lanes are working on (the right lane is one step behind)
  */
-struct Carries {
-	uint32_t l2, h2, l1, h1, l0, h0;
-};
-struct Feed {
-	uint32_t in2, in1, in0;
-	uint32_t acc2, acc1, acc0;
+template <int W>            /* W words of 32 columns per lane */
+struct BitState {
+	uint32_t nH0[W], H1[W], H2[W];   /* horizontal steps of the row above: NOT ">= 0", ">= 1", ">= 2" */
+	uint32_t PP;                     /* hand-off word of the previous step */
 };
 
-__device__ __forceinline__ void shift_carries(Carries &C, Feed &F)
-{
-	asm("s_add_u32 %[i2], %[i2], %[i2]\n\ts_addc_u32 %[l2], %[l2], %[l2]\n\ts_addc_u32 %[h2], %[h2], %[h2]\n\ts_addc_u32 %[a2], %[a2], %[a2]\n\t"
-	    "s_add_u32 %[i1], %[i1], %[i1]\n\ts_addc_u32 %[l1], %[l1], %[l1]\n\ts_addc_u32 %[h1], %[h1], %[h1]\n\ts_addc_u32 %[a1], %[a1], %[a1]\n\t"
-	    "s_add_u32 %[i0], %[i0], %[i0]\n\ts_addc_u32 %[l0], %[l0], %[l0]\n\ts_addc_u32 %[h0], %[h0], %[h0]\n\ts_addc_u32 %[a0], %[a0], %[a0]"
-	    : [i2] "+s"(F.in2), [l2] "+s"(C.l2), [h2] "+s"(C.h2), [a2] "+s"(F.acc2), [i1] "+s"(F.in1), [l1] "+s"(C.l1), [h1] "+s"(C.h1),
-	      [a1] "+s"(F.acc1), [i0] "+s"(F.in0), [l0] "+s"(C.l0), [h0] "+s"(C.h0), [a0] "+s"(F.acc0)
-	    :
-	    : "scc");
-}
+/* words per lane in checkpoint mode (csadp_device.h); always 1 with direction planes in HBM */
+constexpr int kCkptWords = kBitCkptWords;
 
-/* a + b + carry-in of each lane from the mask {hi, lo}; the carry-outs replace the mask */
-__device__ __forceinline__ uint32_t add_carry(uint32_t a, uint32_t b, uint32_t &lo, uint32_t &hi)
-{
-	const uint64_t cin = ((uint64_t)hi << 32) | lo;
-	uint64_t cout;
-	uint32_t s;
-	asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s), "=s"(cout) : "v"(a), "v"(b), "s"(cin));
-	lo = (uint32_t)cout;
-	hi = (uint32_t)(cout >> 32);
-	return s;
-}
-
-/* 32 steps.  win0 / win1: the lane's own window of the two row planes, bit t = the letter bit of the row the
- * lane works on at step t of the block (csadp_bits.hip computes it once per block: no letter travels with the
- * carries).  RAMPIN: lanes whose row index is still negative keep an empty row above.
- * OUT_GLOBAL: out = this lane's slot of the strip's direction planes in HBM (step pitch 64).  OUT_TILE
- * (replay): out = the lane's slot of a [32][16] tile in LDS, written by the lanes with `store` set. */
+/* 32 steps.  inject[t] is the hand-off word entering lane 0 at step t; ringout (lane 63 of a strip
+ * that has a right neighbour) receives the word leaving the strip.  RAMPIN: lanes whose row index
+ * is still negative keep an empty row above.
+ * FEEDS: every lane stores its hand-off word of step t to lanebuf[t] (LDS; a per-lane pointer
+ * that is the ring / the marks buffer for the lanes that matter and a shared scrap row for the
+ * rest -- no EXEC juggling in the step).
+ * OUT_GLOBAL: dirs = this strip's direction planes in HBM.  OUT_TILE (replay): the wave is four
+ * independent 16-lane pieces of strips (DPP stays inside a row, `inject` is per lane and only
+ * the first lane of a row uses it, `lane` is the lane's index in its strip) and dirs = the
+ * row's [32][16] tile. */
 enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
 
-template <bool RAMPIN, int OUT, bool MATCHES = false>
-__device__ __forceinline__ void bits_block(BitState &S, const uint32_t B0, const uint32_t B1, const uint32_t win0, const uint32_t win1,
-                                           Carries &C, Feed &F, uint2 *out, bool store, int l0, int lane, uint32_t *outm = nullptr)
+template <bool RAMPIN, bool FEEDS, int OUT, int W, bool MATCHES = false, bool AHEAD = false>
+__device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[W], const uint32_t (&B1)[W], const uint32_t *inject,
+                                           uint32_t *lanebuf, uint2 *dirs, int l0, int lane, uint32_t *matches = nullptr)
 {
-	constexpr int ostride = (OUT == OUT_TILE) ? 16 : kLanes;
+	/* MATCHES (replay with scoring): `matches` is an LDS tile like dirs and receives the match masks.
+	 * It must stay an LDS-typed pointer: merged with nullptr it would become a flat pointer, and
+	 * flat accesses do not reach LDS beyond 64 KB. */
+	[[maybe_unused]] uint32_t *outm = MATCHES ? matches + (lane & 15) * W : nullptr;
+	static_assert(OUT != OUT_GLOBAL || W == 1, "direction planes in HBM are laid out for one word per lane");
+	constexpr bool ROWS = (OUT == OUT_TILE);
+	constexpr int ostride = ROWS ? 16 : kLanes;
+	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15) * W;
+	/* The words entering the row's first lane come from LDS (address kept in a VGPR: broadcast reads), each
+	 * into the register the DPP move of its step then completes.  AHEAD = false: fetched one step ahead -- with
+	 * several waves per SIMD the round trip disappears behind the other waves.  AHEAD = true (the launches that
+	 * run ONE wave per SIMD): all 32 up front; a lone wave otherwise waits out an LDS round trip in every step,
+	 * 235 cycles per step where its 31 VALU instructions take 130 (tools/cellstep_microbench.hip).  Up-front
+	 * reads in the many-wave kernel cost 12 % of its throughput (measured), hence the switch. */
+	uint32_t ioff = 0;
+	asm volatile("" : "+v"(ioff));
+	const uint32_t *ip = reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(inject, 16)) + ioff;
+	uint32_t inj[AHEAD ? kBitBlock : 1];
+	uint32_t cur = ip[0];
+	if (AHEAD) {
+#pragma unroll
+		for (int t = 0; t < kBitBlock; ++t) inj[AHEAD ? t : 0] = ip[t];
+	}
 #pragma unroll
 	for (int t = 0; t < kBitBlock; ++t) {
-		shift_carries(C, F);
-		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)win0, t, 1);
-		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)win1, t, 1);
+		uint32_t in;
+		if (AHEAD) {
+			in = from_left<ROWS>(inj[AHEAD ? t : 0], S.PP);
+		} else {
+			const uint32_t nxt = ip[t + 1 < kBitBlock ? t + 1 : t];
+			in = from_left<ROWS>(cur, S.PP);
+			cur = nxt;
+		}
+		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 0, 1);
+		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 1, 1);
+		uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
+		uint32_t c1 = __builtin_amdgcn_ubfe(in, 23, 1);
+		uint32_t below = in;                                  /* its bit 31 enters the ">= 0" plane */
+		uint32_t O0 = 0, O1 = 0, O2 = 0;
 		[[maybe_unused]] const uint32_t live = RAMPIN ? ((l0 + t >= lane) ? ~0u : 0u) : ~0u;
-		const uint32_t nH0 = S.nH0, H1 = S.H1, H2 = S.H2;
-		const uint32_t x0 = B0 ^ R0;
-		const uint32_t nE = BITOP3(x0, B1, R1, LA | (LB ^ LC));          /* 1 = mismatch */
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			const uint32_t nH0 = S.nH0[h], H1 = S.H1[h], H2 = S.H2[h];
+			const uint32_t x0 = B0[h] ^ R0;
+			const uint32_t nE = BITOP3(x0, B1[h], R1, LA | (LB ^ LC));          /* 1 = mismatch */
 
-		/* vertical step >= 2: generated by a match over w = -1, carried through mismatches over w = -1 */
-		const uint32_t g2 = BITOP3(nE, nH0, nH0, ~LA & LB);
-		const uint32_t s2 = add_carry(nH0, g2, C.l2, C.h2);
-		const uint32_t G2 = BITOP3(s2, nH0, g2, LA ^ LB ^ LC);             /* incoming: u >= 2 */
+			/* vertical step >= 2: generated by a match over w = -1, carried through mismatches over w = -1 */
+			const uint32_t g2 = BITOP3(nE, nH0, nH0, ~LA & LB);
+			const uint32_t s2 = nH0 + g2 + c2;
+			const uint32_t G2 = BITOP3(s2, nH0, g2, LA ^ LB ^ LC);             /* incoming: u >= 2 */
+			O2 = BITOP3(g2, nH0, G2, LA | (LB & LC));                         /* outgoing */
 
-		/* >= 1: match over w <= 0, or mismatch over w = 0 with u >= 2; carried over w = -1 */
-		const uint32_t t1 = BITOP3(nE, nH0, G2, ~LA | (~LB & LC));
-		const uint32_t g1 = BITOP3(t1, H1, H1, LA & ~LB);
-		const uint32_t A1 = BITOP3(g1, nE, nH0, LA | (LB & LC));
-		const uint32_t s1 = add_carry(A1, g1, C.l1, C.h1);
-		const uint32_t G1 = BITOP3(s1, A1, g1, LA ^ LB ^ LC);
+			/* >= 1: match over w <= 0, or mismatch over w = 0 with u >= 2; carried over w = -1 */
+			const uint32_t t1 = BITOP3(nE, nH0, G2, ~LA | (~LB & LC));
+			const uint32_t g1 = BITOP3(t1, H1, H1, LA & ~LB);
+			const uint32_t A1 = BITOP3(g1, nE, nH0, LA | (LB & LC));
+			const uint32_t s1 = A1 + g1 + c1;
+			const uint32_t G1 = BITOP3(s1, A1, g1, LA ^ LB ^ LC);
+			O1 = BITOP3(g1, A1, G1, LA | (LB & LC));
 
-		/* >= 0: no chain.  match: w <= 1; mismatch: w = -1, or w = 0 and u >= 1, or w = 1 and u >= 2 */
-		const uint32_t v = BITOP3(H1, G2, G1, (LA & LB) | (~LA & LC));
-		const uint32_t w = BITOP3(nE, v, H2, ~LC & (~LA | LB));
-		const uint32_t O0 = BITOP3(w, nE, nH0, LA | (LB & LC));
-		const uint32_t G0 = add_carry(O0, O0, C.l0, C.h0);                 /* (O0 << 1) | the bit from the left */
+			/* >= 0: no chain.  match: w <= 1; mismatch: w = -1, or w = 0 and u >= 1, or w = 1 and u >= 2 */
+			const uint32_t v = BITOP3(H1, G2, G1, (LA & LB) | (~LA & LC));
+			const uint32_t w = BITOP3(nE, v, H2, ~LC & (~LA | LB));
+			O0 = BITOP3(w, nE, nH0, LA | (LB & LC));
+			const uint32_t G0 = __builtin_amdgcn_alignbit(O0, below, 31);        /* (O0 << 1) | carry */
+			if (h == W - 1) {
+				/* hand-off word for the right neighbour (top bits of the last word's outgoing planes),
+				 * early: the rest of the step lies between this write and the next step's DPP read */
+				const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);      /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
+				const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);      /* byte 3 <- O0 byte 3 */
+				S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
+				if (FEEDS) lanebuf[t] = S.PP;                       /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks, all others -> a scrap row */
+			}
 
-		/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
-		const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
-		const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
-		uint32_t T2 = BITOP3(C1, G0, G0, LA & ~LB);
-		const uint32_t a1 = BITOP3(C1, G1, G1, LA & ~LB);
-		uint32_t T1 = BITOP3(G0, a1, C0, (LA & LB) | (~LA & LC));
-		const uint32_t b0 = BITOP3(C0, G1, G0, LC & (~LA | LB));
-		uint32_t nT0 = BITOP3(b0, C1, G2, LA & (~LB | LC));
-		if (OUT != OUT_NONE) {
-			const uint32_t notdiag = C0 & nE;
-			const uint32_t left = notdiag & nT0;
-			if (OUT == OUT_GLOBAL || store) {
-				out[t * ostride] = make_uint2(notdiag, left);
-				if (MATCHES) outm[t * ostride] = ~nE;           /* match mask: the walk scores its path */
+			/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
+			const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
+			const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
+			uint32_t T2 = BITOP3(C1, G0, G0, LA & ~LB);
+			const uint32_t a1 = BITOP3(C1, G1, G1, LA & ~LB);
+			uint32_t T1 = BITOP3(G0, a1, C0, (LA & LB) | (~LA & LC));
+			const uint32_t b0 = BITOP3(C0, G1, G0, LC & (~LA | LB));
+			uint32_t nT0 = BITOP3(b0, C1, G2, LA & (~LB | LC));
+			if (OUT != OUT_NONE) {
+				const uint32_t notdiag = C0 & nE;
+				const uint32_t left = notdiag & nT0;
+				out[t * ostride * W + h] = make_uint2(notdiag, left);
+				if (MATCHES) outm[t * ostride * W + h] = ~nE;       /* match mask: the walk scores its path */
+			}
+			if (RAMPIN) {
+				nT0 |= ~live;
+				T1 &= live;
+				T2 &= live;
+			}
+			S.nH0[h] = nT0;
+			S.H1[h] = T1;
+			S.H2[h] = T2;
+			if (h + 1 < W) {                                       /* carries into the lane's next word */
+				c2 = O2 >> 31;
+				c1 = O1 >> 31;
+				below = O0;
 			}
 		}
-		if (RAMPIN) {
-			nT0 |= ~live;
-			T1 &= live;
-			T2 &= live;
-		}
-		S.nH0 = nT0;
-		S.H1 = T1;
-		S.H2 = T2;
 	}
 }
 
-/* the lane's window of a row plane for the block whose lane-0 rows are word `wb`: lane L starts the block at row
- * 32 b - L, i.e. at bit (-L) & 31 of word b - 1 (L = 1..32) or b - 2 (L = 33..63) */
-__device__ __forceinline__ uint32_t row_window(uint32_t wb, uint32_t wp, uint32_t wpp, int lane)
+/* lane state in the checkpoint array: W = 1: one uint4 (3 planes + hand-off word); W = 2: two */
+template <int W>
+__device__ __forceinline__ void save_state(uint4 *ck, size_t idx, const BitState<W> &S)
 {
-	const uint32_t lo = lane == 0 ? wb : (lane <= 32 ? wp : wpp);
-	const uint32_t hi = lane <= 32 ? wb : wp;
-	return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(-lane) & 31u);
+	if (W == 1) {
+		ck[idx] = make_uint4(S.nH0[0], S.H1[0], S.H2[0], S.PP);
+	} else {
+		ck[idx * 2] = make_uint4(S.nH0[0], S.H1[0], S.H2[0], S.PP);
+		ck[idx * 2 + 1] = make_uint4(S.nH0[W - 1], S.H1[W - 1], S.H2[W - 1], 0u);
+	}
 }
 
-/* lane state in the checkpoint array: one uint4 per lane and block: 3 planes + the lane's bits of the three
- * carry-out masks (bit 0 ">= 2", bit 1 ">= 1", bit 2 ">= 0") */
-__device__ __forceinline__ void save_state(uint4 *ck, size_t idx, const BitState &S, const Carries &C, int lane)
+template <int W>
+__device__ __forceinline__ void load_state(const uint4 *ck, size_t idx, BitState<W> &S)
 {
-	const uint64_t c2 = ((uint64_t)C.h2 << 32) | C.l2, c1 = ((uint64_t)C.h1 << 32) | C.l1, c0 = ((uint64_t)C.h0 << 32) | C.l0;
-	const uint32_t bits = (uint32_t)((c2 >> lane) & 1u) | ((uint32_t)((c1 >> lane) & 1u) << 1) | ((uint32_t)((c0 >> lane) & 1u) << 2);
-	ck[idx] = make_uint4(S.nH0, S.H1, S.H2, bits);
-}
-
-__device__ __forceinline__ void load_state(const uint4 *ck, size_t idx, BitState &S, Carries &C)
-{
-	const uint4 v = ck[idx];
-	S.nH0 = v.x;
-	S.H1 = v.y;
-	S.H2 = v.z;
-	const uint64_t c2 = __ballot((v.w & 1u) != 0), c1 = __ballot((v.w & 2u) != 0), c0 = __ballot((v.w & 4u) != 0);
-	C.l2 = (uint32_t)c2;
-	C.h2 = (uint32_t)(c2 >> 32);
-	C.l1 = (uint32_t)c1;
-	C.h1 = (uint32_t)(c1 >> 32);
-	C.l0 = (uint32_t)c0;
-	C.h0 = (uint32_t)(c0 >> 32);
+	const uint4 v = ck[idx * W];
+	S.nH0[0] = v.x;
+	S.H1[0] = v.y;
+	S.H2[0] = v.z;
+	S.PP = v.w;
+	if (W > 1) {
+		const uint4 u = ck[idx * W + 1];
+		S.nH0[W - 1] = u.x;
+		S.H1[W - 1] = u.y;
+		S.H2[W - 1] = u.z;
+	}
 }
 
 /* Counters in LDS that order LDS data only: the LDS executes one wave's accesses in the order they were issued
@@ -217,8 +232,7 @@ template <bool TIGHT = false>
 __device__ __forceinline__ bool wait_at_least(const int *counter, int need)
 {
 	int spins = 0;
-	/* the value is the same in every lane; saying so keeps the callers' control flow -- and with it the carry masks -- scalar */
-	while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
+	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
 		if (!TIGHT) __builtin_amdgcn_s_sleep(2);
 		if (++spins > kSpinMax) return false;
 	}
@@ -229,35 +243,14 @@ __device__ __forceinline__ bool wait_at_least(const int *counter, int need)
  * through the constant address space they become scalar loads, counted apart from the vector memory accesses */
 typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
 
-/* the words a strip's lane 63 hands on, per block: ring slot in LDS, and (checkpoint mode) a 32-byte mark in HBM:
- * u32 {">= 2" bits, tag, ">= 1" bits, tag, ">= 0" bits, tag, 0, 0} -- three 8-byte granules {data, tag} */
-constexpr int kMarkWords = 8;
-
-__device__ __forceinline__ void feed_from(Feed &F, uint32_t w2, uint32_t w1, uint32_t w0)
-{
-	F.in2 = __builtin_amdgcn_readfirstlane(w2);
-	F.in1 = __builtin_amdgcn_readfirstlane(w1);
-	F.in0 = __builtin_amdgcn_readfirstlane(w0);
-}
-
-/* the accumulator of plane (2 - lane) in lanes 0..2.  Written with the three words pinned in vector registers first: a
- * plain `lane == 0 ? F.acc2 : ...` is compiled into ONE load through a selected address, which keeps the whole Feed
- * in scratch memory -- and what is loaded from there no longer counts as wave-uniform */
-__device__ __forceinline__ uint32_t acc_of_lane(const Feed &F, int lane)
-{
-	uint32_t x2 = F.acc2, x1 = F.acc1, x0 = F.acc0;
-	asm volatile("" : "+v"(x2), "+v"(x1), "+v"(x0));
-	return lane == 0 ? x2 : lane == 1 ? x1 : x0;
-}
-
 }  // namespace
 
 /*
- * K1b.  One workgroup per job, one wave per strip.  Strip s consumes, for every row, the three carry bits
- * that leave lane 63 of strip s-1 (the producer's lane 63 works on row r at its step r + 63); they travel
- * as three words per block of 32 steps through an LDS ring (`made` = blocks the producer has finished,
- * `taken` = blocks whose words the consumer has fetched, for back-pressure): block b of the consumer needs
- * the words of the producer's block b + 2.  All waves of a workgroup are resident, so the waits always end;
+ * K1b.  One workgroup per job, one wave per strip.  Strip s consumes, for every row, the hand-off
+ * word that leaves lane 63 of strip s-1 (the producer's lane 63 works on row r at its step r + 63);
+ * the words travel through an LDS ring of kRingSteps steps, synchronised per block of 32 steps
+ * (`made` = blocks the producer has finished, `taken` = blocks whose inputs the consumer has
+ * fetched, for back-pressure).  All waves of a workgroup are resident, so the waits always end;
  * each is bounded all the same and a timeout raises *abort_word.
  */
 template <bool CKPT>
@@ -266,7 +259,11 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
                                                                       int *__restrict__ abort_word)
 {
 	constexpr int OUT = CKPT ? OUT_NONE : OUT_GLOBAL;
-	__shared__ __attribute__((aligned(16))) uint4 ring[kBitMaxStrips][kRing];
+	constexpr int W = CKPT ? kCkptWords : 1;
+	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
+	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
+	__shared__ uint32_t scrap[kBitMaxStrips][kLanes + kBitBlock];   /* lane l, step t -> word l + t: 64 different banks per store */
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	const BitJob &J = jobs[blockIdx.x];
 	const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -279,64 +276,72 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 
 	const int nb = J.steps_pad / kBitBlock;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
-	uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
+	uint32_t B0[W], B1[W];
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		B0[h] = cp[(s * kLanes + lane) * W + h];
+		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
+	}
 	ConstWords rp = (ConstWords)(uintptr_t)(arena + J.rowplanes);
 	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                /* requested one block ahead */
-	uint32_t a0p = 0, a1p = 0, a0pp = 0, a1pp = 0;             /* the words of the two blocks before */
-	uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes + lane;
+	uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
 	const bool feeds = s + 1 < J.nstrips;
-	uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * nb * kMarkWords : nullptr;
+	/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
+	 * LDS and copied out once per block as four streams [4][steps_pad] per strip */
+	uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad : nullptr;
+	const bool writes = (lane == kLanes - 1) ? feeds : (CKPT && (lane & 15) == 15);
 
-	BitState S{~0u, 0u, 0u};
-	Carries C{0, 0, 0, 0, 0, 0};
-	Feed F{0, 0, 0, 0, 0, 0};
-	/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
-	 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
-	asm volatile("" : "+v"(B0), "+v"(B1));
-	/* one block; false = a bounded wait ran out.  Two loops call it (the first two blocks of a strip keep the lanes
-	 * above the matrix idle): one loop with a branch on b < 2 merges the scalar carry masks of both forms in phi
-	 * nodes the compiler then places in vector registers ("illegal VGPR to SGPR copy") */
-	auto block = [&](int b, auto ramp) -> bool {
-		constexpr bool RAMP = decltype(ramp)::value;
-		/* the bits entering lane 0 during this block left the producer's lane 63 in its steps 32b + 63 .. 32b + 94 */
-		uint4 w = make_uint4(0u, 0u, 0u, 0u);
+	BitState<W> S;
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		S.nH0[h] = ~0u;
+		S.H1[h] = S.H2[h] = 0;
+		/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
+		 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
+		asm volatile("" : "+v"(B0[h]), "+v"(B1[h]));
+	}
+	S.PP = 0;
+	for (int b = 0; b < nb; ++b) {
+		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
+		 * the producer's step 32b + t + 63, row letter of row 32b + t */
+		uint32_t word = 0;
 		if (s > 0) {
-			const int need = (b + 3 < nb) ? b + 3 : nb;
-			if (!wait_at_least<true>(&made[s - 1], need)) return false;
-			if (b + 2 < nb) w = ring[s - 1][(b + 2) % kRing];
+			const int need = (b + 3 < nb) ? b + 3 : nb;         /* producer steps up to 32b + 94 */
+			if (!wait_at_least<true>(&made[s - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			const int ps = b * kBitBlock + 63 + (lane & 31);
+			if (ps < J.steps_pad) word = ring[s - 1][ps % kRingSteps] & 0xffffff00u;
 			if (lane == 0) __hip_atomic_store(&taken[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		feed_from(F, w.x, w.y, w.z);
 		const uint32_t a0 = a0n, a1 = a1n;
 		if (b + 1 < nb) {
 			a0n = rp[b + 1];
 			a1n = rp[J.rowwords + b + 1];
 		}
-		const uint32_t win0 = row_window(a0, a0p, a0pp, lane), win1 = row_window(a1, a1p, a1pp, lane);
-		a0pp = a0p;
-		a0p = a0;
-		a1pp = a1p;
-		a1p = a1;
-		bits_block<RAMP, OUT>(S, B0, B1, win0, win1, C, F, dirs + (size_t)b * kBitBlock * kLanes, true, b * kBitBlock, lane);
+		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
+		if (lane < kBitBlock) inject[s][lane] = word;
+		uint32_t *lanebuf = !writes ? &scrap[s][lane] : (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
 		if (feeds) {
-			/* ring slot b % kRing last held block b - kRing, which the consumer fetches for its block b - kRing - 2 */
-			if (!wait_at_least<true>(&taken[s + 1], b - kRing - 1)) return false;
-			if (lane == 0) {
-				ring[s][b % kRing] = make_uint4(F.acc2, F.acc1, F.acc0, 0u);
-				__hip_atomic_store(&made[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
+			/* the ring slots of this block last held block b - kRing, whose words the consumer
+			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
+			if (!wait_at_least<true>(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+		}
+		if (feeds || CKPT) {
+			if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
+			else bits_block<false, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
+		} else {
+			if (b < 2) bits_block<true, false, OUT, W>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
+			else bits_block<false, false, OUT, W>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
 		}
 		if (CKPT) {
-			const uint32_t d = acc_of_lane(F, lane);
-			if (feeds && lane < 3) marks[(size_t)b * kMarkWords + 2 * lane] = d;
-			save_state(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S, C, lane);
+			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring (strips that feed) */
+			const int g = lane >> 4 >> 1, t = lane & 31;          /* lanes 0..31 -> stream 0, 32..63 -> stream 1 */
+			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[s][g][t];
+			marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
+			    (g == 0) ? mbuf[s][2][t] : (feeds ? ring[s][(b * kBitBlock + t) % kRingSteps] : 0u);
+			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
-		return true;
-	};
-	bool ok = true;
-	for (int b = 0; ok && b < 2 && b < nb; ++b) ok = block(b, std::true_type());
-	for (int b = 2; ok && b < nb; ++b) ok = block(b, std::false_type());
-	if (!ok && lane == 0) atomicExch(abort_word, 1);
+		if (feeds && lane == kLanes - 1) __hip_atomic_store(&made[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
 }
 
 /*
@@ -346,21 +351,35 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
  * whole-genome profile alignment, config 5's 200 kbp pairs -- whose strips are spread over compute
  * units at ONE wave per SIMD (WAVES = 4) or two (WAVES = 8) instead of sharing one unit's SIMDs: a step's
  * latency is what bounds such a launch.
- * The first strip of chunk c takes the words that left the last strip of chunk c-1 from that strip's marks in
- * HBM: three 8-byte granules {bits, tag} per block, each written by one write-through store and valid exactly
- * when its tag is this launch's epoch; the consumer requests a block's granules one block ahead and re-reads
- * (bounded) only what had not arrived -- no counter, no fence (MI355X_MICROARCH.md, data-tagged granules).
- * The marks are zeroed when the batch is laid out and epochs are unique per process and never 0.  The work
- * list puts a job's chunks in ascending order, so the chunk a workgroup waits for was dispatched before it --
- * for speed only: every wait is bounded, a time-out raises the abort word and the host repeats the pass chunk
+ * The first strip of chunk c takes the hand-off words that left the last strip of chunk c-1 from stream 3 of
+ * that strip's marks in HBM.  Only bits 31 / 23 / 15 of those words are ever used (the outgoing planes'
+ * top bits; the row letter comes from the row planes), so the other bits of bytes 1..3 carry the launch's
+ * epoch: a word is valid exactly when it holds this launch's epoch, each is written by one write-through
+ * store, and the consumer requests a block's 32 words one block ahead and re-reads (bounded) only what
+ * had not arrived -- no counter, no fence (MI355X_MICROARCH.md, data-tagged granules; the round-1 form
+ * published a counter behind an agent-scope release per block, which stalls a lone wave for microseconds).
+ * The marks are zeroed when the batch is laid out and epochs are unique per process.  The work list puts
+ * a job's chunks in ascending order, so the chunk a workgroup waits for was dispatched before it -- for
+ * speed only: every wait is bounded, a time-out raises the abort word and the host repeats the pass chunk
  * by chunk.  The launch reserves enough LDS for ONE workgroup per compute unit.
  */
+constexpr uint32_t kMarkPayload = 0x80808000u;            /* bits 31, 23, 15 */
+__device__ __forceinline__ uint32_t mark_tag(uint32_t epoch)   /* 21 bits of epoch into bits 30..24, 22..16, 14..8 */
+{
+	return ((epoch & 0x7fu) << 8) | (((epoch >> 7) & 0x7fu) << 16) | (((epoch >> 14) & 0x7fu) << 24);
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs, int njobs,
                                                                    const TileRef *__restrict__ work, uint32_t epoch,
                                                                    int *__restrict__ abort_word)
 {
-	__shared__ __attribute__((aligned(16))) uint4 ring[WAVES][kRing];
+	constexpr int OUT = OUT_NONE;
+	constexpr int W = kCkptWords;
+	__shared__ uint32_t ring[WAVES][kRingSteps];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[WAVES][kBitBlock];
+	__shared__ uint32_t mbuf[WAVES][3][kBitBlock];
+	__shared__ uint32_t scrap[WAVES][kLanes + kBitBlock];
 	__shared__ int made[WAVES], taken[WAVES];
 	const TileRef item = work[blockIdx.x];                      /* x: the work list of one pass, y: the pass */
 	const BitJob &J = jobs[(size_t)blockIdx.y * njobs + item.job];
@@ -378,110 +397,117 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
 	ConstWords rp = (ConstWords)(uintptr_t)(arena + J.rowplanes);
 	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                /* requested one block ahead */
-	uint32_t a0p = 0, a1p = 0, a0pp = 0, a1pp = 0;
-	uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
+	uint32_t B0[W], B1[W];
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		B0[h] = cp[(s * kLanes + lane) * W + h];
+		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
+	}
 	const bool feeds = wv + 1 < WAVES && s + 1 < J.nstrips;          /* a wave of this workgroup reads my ring */
 	const bool publishes = wv + 1 == WAVES && s + 1 < J.nstrips;     /* the next chunk reads my marks */
-	uint32_t *marks = reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * nb * kMarkWords;
+	uint32_t *marks = reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad;
 	const bool from_left_chunk = wv == 0 && chunk > 0;
-	const uint64_t *left_marks = from_left_chunk ? reinterpret_cast<const uint64_t *>(arena + J.hand) + (size_t)(s - 1) * nb * (kMarkWords / 2) : nullptr;
+	const uint32_t *left_marks = from_left_chunk ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
+	const bool writes = (lane == kLanes - 1) ? (feeds || publishes) : ((lane & 15) == 15);
+	const uint32_t tag = mark_tag(epoch);
+	constexpr uint32_t kTagMask = ~kMarkPayload & 0xffffff00u;
 
-	BitState S{~0u, 0u, 0u};
-	Carries C{0, 0, 0, 0, 0, 0};
-	Feed F{0, 0, 0, 0, 0, 0};
-	asm volatile("" : "+v"(B0), "+v"(B1));
-	/* the previous chunk's granules for block 0 (its block 2), requested now; inside the loop always one block ahead */
-	const int gl = lane < 3 ? lane : 0;
-	uint64_t pre = 0;
-	if (from_left_chunk && 2 < nb) pre = __hip_atomic_load(&left_marks[(size_t)2 * (kMarkWords / 2) + gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	auto block = [&](int b, auto ramp) -> bool {
-		constexpr bool RAMP = decltype(ramp)::value;
-		uint4 w = make_uint4(0u, 0u, 0u, 0u);              /* lanes 0..2 of the first wave of a chunk: .x = the three words */
+	BitState<W> S;
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		S.nH0[h] = ~0u;
+		S.H1[h] = S.H2[h] = 0;
+		/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
+		 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
+		asm volatile("" : "+v"(B0[h]), "+v"(B1[h]));
+	}
+	S.PP = 0;
+	/* the previous chunk's words for block 0, requested now; inside the loop always one block ahead */
+	uint32_t pre = 0;
+	if (from_left_chunk && 63 + (lane & 31) < J.steps_pad) pre = __hip_atomic_load(&left_marks[63 + (lane & 31)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	for (int b = 0; b < nb; ++b) {
+		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
+		 * the producer's step 32b + t + 63, row letter of row 32b + t */
+		uint32_t word = 0;
+		const int ps = b * kBitBlock + 63 + (lane & 31);
+		const int need = (b + 3 < nb) ? b + 3 : nb;             /* producer steps up to 32b + 94 */
 		if (wv > 0) {
-			const int need = (b + 3 < nb) ? b + 3 : nb;
-			if (!wait_at_least<WAVES == 4>(&made[wv - 1], need)) return false;
-			if (b + 2 < nb) w = ring[wv - 1][(b + 2) % kRing];
+			if (!wait_at_least<WAVES == 4>(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
 			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		} else if (from_left_chunk && b + 2 < nb) {
-			uint64_t v = pre;
+		} else if (from_left_chunk) {
+			uint32_t v = pre;
 			int spins = 0;
 			for (;;) {
-				const bool ok = (uint32_t)(v >> 32) == epoch;
-				if (__builtin_amdgcn_readfirstlane((int)(__ballot(!ok) == 0ull))) break;       /* uniform, and known to be */
+				const bool ok = ps >= J.steps_pad || (v & kTagMask) == tag;
+				if (__all(ok)) break;
 				__builtin_amdgcn_s_sleep(2);
-				if (++spins > kSpinMax) return false;
-				/* every lane re-reads (a branch on `ok` would make the loop's exit look divergent to the compiler) */
-				v = __hip_atomic_load(&left_marks[(size_t)(b + 2) * (kMarkWords / 2) + gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (++spins > kSpinMax) { if (lane == 0) atomicExch(abort_word, 1); return; }
+				if (!ok) v = __hip_atomic_load(&left_marks[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-			if (b + 3 < nb) pre = __hip_atomic_load(&left_marks[(size_t)(b + 3) * (kMarkWords / 2) + gl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t d = (uint32_t)v;
-			w.x = (uint32_t)__builtin_amdgcn_readlane((int)d, 0);
-			w.y = (uint32_t)__builtin_amdgcn_readlane((int)d, 1);
-			w.z = (uint32_t)__builtin_amdgcn_readlane((int)d, 2);
+			if (ps + kBitBlock < J.steps_pad) pre = __hip_atomic_load(&left_marks[ps + kBitBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			if (ps < J.steps_pad) word = v & kMarkPayload;
 		}
-		feed_from(F, w.x, w.y, w.z);
 		const uint32_t a0 = a0n, a1 = a1n;
 		if (b + 1 < nb) {
 			a0n = rp[b + 1];
 			a1n = rp[J.rowwords + b + 1];
 		}
-		const uint32_t win0 = row_window(a0, a0p, a0pp, lane), win1 = row_window(a1, a1p, a1pp, lane);
-		a0pp = a0p;
-		a0p = a0;
-		a1pp = a1p;
-		a1p = a1;
-		bits_block<RAMP, OUT_NONE>(S, B0, B1, win0, win1, C, F, nullptr, false, b * kBitBlock, lane);
+		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
+		if (lane < kBitBlock) inject[wv][lane] = word;
+		uint32_t *lanebuf = !writes ? &scrap[wv][lane] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
 		if (feeds) {
-			if (!wait_at_least<WAVES == 4>(&taken[wv + 1], b - kRing - 1)) return false;
-			if (lane == 0) {
-				ring[wv][b % kRing] = make_uint4(F.acc2, F.acc1, F.acc0, 0u);
-				__hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-			}
+			/* the ring slots of this block last held block b - kRing, whose words the consumer
+			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
+			if (!wait_at_least<WAVES == 4>(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 		}
-		const uint32_t d = acc_of_lane(F, lane);
-		if (lane < 3) {
-			if (publishes) {                                      /* for another compute unit: tagged, written through */
-				__hip_atomic_store(reinterpret_cast<uint64_t *>(marks) + (size_t)b * (kMarkWords / 2) + lane, ((uint64_t)epoch << 32) | d,
-				                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			} else if (feeds) {
-				marks[(size_t)b * kMarkWords + 2 * lane] = d;
+		if (b < 2) bits_block<true, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
+		else bits_block<false, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
+		{
+			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
+			const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
+			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
+			if (g == 0) {
+				marks[(size_t)2 * J.steps_pad + b * kBitBlock + t] = mbuf[wv][2][t];
+			} else if (publishes) {                             /* for another compute unit: tagged, written through */
+				const uint32_t v = (ring[wv][(b * kBitBlock + t) % kRingSteps] & kMarkPayload) | tag;
+				__hip_atomic_store(&marks[(size_t)3 * J.steps_pad + b * kBitBlock + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			} else {
+				marks[(size_t)3 * J.steps_pad + b * kBitBlock + t] = feeds ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u;
 			}
+			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
-		save_state(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S, C, lane);
-		return true;
-	};
-	bool ok = true;
-	for (int b = 0; ok && b < 2 && b < nb; ++b) ok = block(b, std::true_type());
-	for (int b = 2; ok && b < nb; ++b) ok = block(b, std::false_type());
-	if (!ok && lane == 0) atomicExch(abort_word, 1);
+		if (feeds && lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
 }
 
 /*
  * K2c.  Traceback in checkpoint mode: no direction planes exist in HBM.  A round starts at the
  * current cell, in block `btop` (32 steps) of strip s, lane L.  Going up its diagonal the path
- * reaches block btop-d around lane L-d, so piece d = block btop-d of the strip is replayed with the
- * fill's own step function: lane state and carry masks from the checkpoint before the block, the bits
- * entering lane 0 from the marks of the strip to the left, and the directions of the 16-lane group
- * holding lane L-d kept in an LDS tile.  One wave per piece, 16 waves = 16 pieces = ~500 path cells per
- * round; wave 0 then walks inside the 16 tiles (run-batched like K2b) until the path leaves them.
- * Replay work: ~(nrows + ncols) / 31 blocks of a strip, 13 % of the fill's work for square matrices
- * (the round-2 form restarted at 16-lane boundaries from hand-off words the fill stored every step:
- * 3 %, paid for by 9 instructions in every step of the fill).
+ * reaches block btop-d around lane L-d, so piece d = (block btop-d, the 16-lane group holding lane
+ * L-d) is replayed with the fill's own step function: lane state from the checkpoint before the
+ * block, the words entering the group's first lane from the fill's marks (or, for group 0, from the
+ * strip to the left).  A wave replays 4 pieces at once (one per DPP row), 4 waves = 16 pieces =
+ * ~500 path cells per round; wave 0 then walks inside the 16 LDS tiles (run-batched like K2b)
+ * until the path leaves them.  Replay work: ~(nrows + ncols) / 31 pieces of 16 lanes x 32 steps,
+ * 3 % of the fill's work for square matrices.
  */
-constexpr int kReplay = 16;          /* waves = pieces per round: 64 KB of LDS tiles */
-constexpr int kPieces = kReplay;
+constexpr int kReplay = kBitCkptWords == 1 ? 4 : 2;   /* waves: 64 KB of LDS tiles either way */
+constexpr int kPieces = 4 * kReplay;
 
 __device__ __forceinline__ int piece_group(int lane0, int d)
 {
-	const int l = lane0 - d;
+	const int l = lane0 - d / kCkptWords;                  /* a lane holds 32 * W columns: W blocks per lane on a diagonal */
 	return (l < 0 ? 0 : l) >> 4;
 }
 
 template <bool SCORE>       /* SCORE: also sum the move scores of the path (score-only callers skip the host walk) */
 __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
-	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16];
-	__shared__ uint32_t mtile[SCORE ? kPieces : 1][SCORE ? kBitBlock * 16 : 1];    /* match masks of the same cells */
+	constexpr int W = kCkptWords;
+	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16 * W];
+	__shared__ uint32_t mtile[SCORE ? kPieces : 1][SCORE ? kBitBlock * 16 * W : 1];    /* match masks of the same cells */
+	__shared__ __attribute__((aligned(16))) uint32_t inject[kPieces][kBitBlock];
 	__shared__ int pos[4];
 
 	const BitJob &J = jobs[blockIdx.x];
@@ -498,35 +524,52 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	int score = 0;                                             /* sum of the move scores along the path (:993-998 for i = 1) */
 
 	while (r > 0 && k > 0) {
-		const int w0 = (k - 1) / 32;                         /* lane column of the current cell */
-		const int s = __builtin_amdgcn_readfirstlane(w0 >> 6);
+		const int w0 = (k - 1) / (32 * W);                   /* lane column of the current cell */
+		const int s = w0 >> 6;
 		const int lane0 = w0 & 63;
 		const int btop = ((r - 1) + lane0) / kBitBlock;
 		{
-			/* this wave's piece */
-			const int d = wv;
-			/* wave-uniform by construction; said so, because the carry masks live in scalar registers */
-			const int b = __builtin_amdgcn_readfirstlane(btop - d < 0 ? 0 : btop - d);   /* pieces above block 0 replay block 0 and are never read */
+			/* this lane's piece */
+			const int d = 4 * wv + (lane >> 4);
+			const int b = btop - d < 0 ? 0 : btop - d;       /* pieces above block 0 replay block 0 and are never read */
 			const int g = piece_group(lane0, d);
-			BitState S{~0u, 0u, 0u};
-			Carries C{0, 0, 0, 0, 0, 0};
-			Feed F{0, 0, 0, 0, 0, 0};
-			if (b > 0) load_state(ck, ((size_t)s * nb + (b - 1)) * kLanes + lane, S, C);
-			const uint32_t B0 = cp[s * kLanes + lane], B1 = cp[J.nwords_pad + s * kLanes + lane];
-			if (s > 0 && b + 2 < nb) {
-				const uint32_t *m = marks + ((size_t)(s - 1) * nb + (b + 2)) * kMarkWords;
-				feed_from(F, m[0], m[2], m[4]);
+			const int sl = 16 * g + (lane & 15);               /* lane index in the strip */
+			BitState<W> S;
+			if (b > 0) {
+				load_state<W>(ck, ((size_t)s * nb + (b - 1)) * kLanes + sl, S);
+			} else {
+#pragma unroll
+				for (int h = 0; h < W; ++h) {
+					S.nH0[h] = ~0u;
+					S.H1[h] = S.H2[h] = 0;
+				}
+				S.PP = 0;
 			}
-			/* the lane's rows of this block start at row 32 b - lane */
-			const int base = b * kBitBlock - lane;
-			const int q = base >> 5;
-			const uint32_t sh = (uint32_t)base & 31u;
-			const uint32_t lo0 = q >= 0 ? rp[q] : 0u, hi0 = q + 1 >= 0 ? rp[q + 1] : 0u;
-			const uint32_t lo1 = q >= 0 ? rp[J.rowwords + q] : 0u, hi1 = q + 1 >= 0 ? rp[J.rowwords + q + 1] : 0u;
-			const uint32_t win0 = __builtin_amdgcn_alignbit(hi0, lo0, sh), win1 = __builtin_amdgcn_alignbit(hi1, lo1, sh);
-			const bool store = (lane >> 4) == g;
-			/* always the ramp form (3 more instructions per step): one call site, see nw_fill_bits */
-			bits_block<true, OUT_TILE, SCORE>(S, B0, B1, win0, win1, C, F, tile[d] + (lane & 15), store, b * kBitBlock, lane, mtile[SCORE ? d : 0] + (lane & 15));
+			uint32_t B0[W], B1[W];
+#pragma unroll
+			for (int h = 0; h < W; ++h) {
+				B0[h] = cp[(s * kLanes + sl) * W + h];
+				B1[h] = cp[J.nwords_pad + (s * kLanes + sl) * W + h];
+			}
+			/* words entering the piece's first lane: lane j of the row prepares steps j and j + 16 */
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				const int t = (lane & 15) + 16 * h;
+				uint32_t word = 0;
+				if (g == 0) {
+					const int ps = b * kBitBlock + 63 + t;     /* lane 63 of the strip to the left is 63 steps ahead */
+					if (s > 0 && ps < J.steps_pad) word = marks[((size_t)(s - 1) * 4 + 3) * J.steps_pad + ps] & 0xffffff00u;
+					const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
+					word |= ((a0 >> t) & 1u) | (((a1 >> t) & 1u) << 1);
+				} else {
+					const int ps = b * kBitBlock + t - 1;      /* lane 16g-1 after the previous step */
+					if (ps >= 0) word = marks[((size_t)s * 4 + (g - 1)) * J.steps_pad + ps];
+				}
+				inject[d][t] = word;
+			}
+			const bool ramp = btop - 4 * wv - 3 < 2;            /* wave-uniform: some piece of this wave is in block 0 or 1 */
+			if (ramp) bits_block<true, false, OUT_TILE, W, SCORE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl, mtile[SCORE ? d : 0]);
+			else bits_block<false, false, OUT_TILE, W, SCORE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl, mtile[SCORE ? d : 0]);
 		}
 		__syncthreads();
 		if (wv == 0) {
@@ -536,12 +579,12 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 				bool match = false;
 				if (ri > 0 && ki > 0) {
 					const int kc = ki - 1;
-					const int wi = kc / 32;
+					const int wi = kc / (32 * W);
 					const int sl = wi & 63;
 					const int l = (ri - 1) + sl;
 					const int d = btop - l / kBitBlock;
 					if ((wi >> 6) == s && d >= 0 && d < kPieces && d <= btop && (sl >> 4) == piece_group(lane0, d)) {
-						const int at = (l % kBitBlock) * 16 + (sl & 15);
+						const int at = ((l % kBitBlock) * 16 + (sl & 15)) * W + ((kc >> 5) % W);
 						const uint2 dd = tile[d][at];
 						const uint32_t bit = 1u << (kc & 31);
 						code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;

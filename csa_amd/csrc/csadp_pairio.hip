@@ -41,10 +41,16 @@ __device__ __forceinline__ int wrap_index(int first, int p, int size)
 }  // namespace
 
 /*
- * grid (jobs, 2): y = 0 packs the column sequence into colplanes[2][nwords_pad], y = 1 the row sequence
- * into rowplanes[2][rowwords].  A wave takes 64 consecutive letters per iteration: one coalesced byte load,
- * two ballots, one 16-byte store by lane 0.  Words beyond the region are zero (the fill needs no bounds).
+ * grid (jobs, 2, kPackSlices): y = 0 packs the column sequence into colplanes[2][nwords_pad], y = 1 the row
+ * sequence into rowplanes[2][rowwords].  A wave takes 64 consecutive letters per group: one coalesced byte load,
+ * two ballots, one 16-byte store by lane 0; it requests the letters of four groups before it uses the first.
+ * Words beyond the region are zero (the fill needs no bounds).  The kernel sits between two fills of its
+ * stream, on a chip full of fill waves: as 2 workgroups of 64 dependent loads per wave it took 0.13-0.18 ms there
+ * (45 us alone) with the stream's next fill waiting behind it -- hence many short waves (rocprofv3 kernel trace).
  */
+constexpr int kPackSlices = 8;
+constexpr int kPackAhead = 4;
+
 __global__ __launch_bounds__(256) void nw_pack_planes(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
 	const BitJob &J = jobs[blockIdx.x];
@@ -56,21 +62,32 @@ __global__ __launch_bounds__(256) void nw_pack_planes(uint8_t *__restrict__ aren
 	const uint8_t *text = arena + J.text[which];
 	const int size = J.size[which], first = J.first[which];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+	const int stride = nwaves * gridDim.z;
 	bool bad = false;
-	for (int g = wave; 2 * g < nwords; g += nwaves) {
-		const int p = 64 * g + lane;
-		int code = 0;
-		if (p < n) {
-			code = letter_code(text[wrap_index(first, p, size)]);
-			if (code < 0) { bad = true; code = 0; }
+	for (int g0 = blockIdx.z * nwaves + wave; 2 * g0 < nwords; g0 += kPackAhead * stride) {
+		uint32_t c[kPackAhead];
+#pragma unroll
+		for (int u = 0; u < kPackAhead; ++u) {
+			const int p = 64 * (g0 + u * stride) + lane;
+			c[u] = p < n ? text[wrap_index(first, p, size)] : 0u;     /* p < n <= 32 * nwords: inside the region */
 		}
-		const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code & 2);
-		if (lane == 0) {
-			planes[2 * g] = (uint32_t)b0;
-			planes[nwords + 2 * g] = (uint32_t)b1;
-			if (2 * g + 1 < nwords) {
-				planes[2 * g + 1] = (uint32_t)(b0 >> 32);
-				planes[nwords + 2 * g + 1] = (uint32_t)(b1 >> 32);
+#pragma unroll
+		for (int u = 0; u < kPackAhead; ++u) {
+			const int g = g0 + u * stride;
+			if (2 * g >= nwords) break;
+			int code = 0;
+			if (64 * g + lane < n) {
+				code = letter_code(c[u]);
+				if (code < 0) { bad = true; code = 0; }
+			}
+			const unsigned long long b0 = __ballot(code & 1), b1 = __ballot(code & 2);
+			if (lane == 0) {
+				planes[2 * g] = (uint32_t)b0;
+				planes[nwords + 2 * g] = (uint32_t)b1;
+				if (2 * g + 1 < nwords) {
+					planes[2 * g + 1] = (uint32_t)(b0 >> 32);
+					planes[nwords + 2 * g + 1] = (uint32_t)(b1 >> 32);
+				}
 			}
 		}
 	}
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(256) void nw_expand_rows(uint8_t *__restrict__ aren
 hipError_t launch_pack_planes(uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	hipLaunchKernelGGL(nw_pack_planes, dim3(njobs, 2), dim3(256), 0, st, arena, jobs);
+	hipLaunchKernelGGL(nw_pack_planes, dim3(njobs, 2, kPackSlices), dim3(256), 0, st, arena, jobs);
 	return hipGetLastError();
 }
 
