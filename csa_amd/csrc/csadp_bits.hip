@@ -488,17 +488,46 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
  * L-d) is replayed with the fill's own step function: lane state from the checkpoint before the
  * block, the words entering the group's first lane from the fill's marks (or, for group 0, from the
  * strip to the left).  A wave replays 4 pieces at once (one per DPP row), 4 waves = 16 pieces =
- * ~500 path cells per round; wave 0 then walks inside the 16 LDS tiles (run-batched like K2b)
+ * ~480 path cells per round; wave 0 then walks inside the 16 LDS tiles (run-batched like K2b)
  * until the path leaves them.  Replay work: ~(nrows + ncols) / 31 pieces of 16 lanes x 32 steps,
  * 3 % of the fill's work for square matrices.
+ * Which 16-lane group a piece holds: the path crosses a group boundary every 16 lanes = every 16.5 blocks,
+ * and it does so in the MIDDLE of a block -- the cells of that block lie in two groups.  The round-2 form gave
+ * every block one group ((L - d) / 16) and so ended a round at each crossing, usually twice (in-kernel timers on a
+ * 16 kbp pair: 64 rounds where 34 + 8 strip crossings would do; a round costs 15 k cycles: checkpoint loads 1.8 k,
+ * replay 5.4 k, walk 7.5 k).  Now a round is planned from the diagonal through the current cell: `dc` = the block
+ * (counted down from btop) holding the first cell of the next group down; blocks before it are replayed for the
+ * current group, blocks after it for the next one, and block dc for BOTH (piece dc and piece dc + 1).
  */
 constexpr int kReplay = kBitCkptWords == 1 ? 4 : 2;   /* waves: 64 KB of LDS tiles either way */
 constexpr int kPieces = 4 * kReplay;
 
-__device__ __forceinline__ int piece_group(int lane0, int d)
+struct RoundPlan {
+	int ghi;              /* 16-lane group of the current cell */
+	int dc;               /* blocks below btop at which the diagonal enters group ghi - 1 (huge: not in this strip / matrix) */
+};
+
+__device__ __forceinline__ RoundPlan plan_round(int r, int k, int lane0, int btop)
 {
-	const int l = lane0 - d / kCkptWords;                  /* a lane holds 32 * W columns: W blocks per lane on a diagonal */
-	return (l < 0 ? 0 : l) >> 4;
+	constexpr int CL = 32 * kCkptWords;                    /* columns per lane */
+	RoundPlan P;
+	P.ghi = lane0 >> 4;
+	P.dc = 1 << 20;
+	const int cx = ((k - 1) % (16 * CL)) + 1;              /* cells up the diagonal to the first cell of the group below */
+	const int r2 = r - cx, k2 = k - cx;
+	if (P.ghi > 0 && r2 > 0 && k2 > 0) {
+		const int lane2 = ((k2 - 1) / CL) & 63;
+		P.dc = btop - ((r2 - 1) + lane2) / kBitBlock;
+	}
+	return P;
+}
+
+/* piece p of a round: how many blocks below btop, and which group */
+__device__ __forceinline__ void piece_of(const RoundPlan &P, int p, int &delta, int &g)
+{
+	const bool hi = p <= P.dc;
+	delta = hi ? p : p - 1;
+	g = hi ? P.ghi : P.ghi - 1;
 }
 
 template <bool SCORE>       /* SCORE: also sum the move scores of the path (score-only callers skip the host walk) */
@@ -528,11 +557,13 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 		const int s = w0 >> 6;
 		const int lane0 = w0 & 63;
 		const int btop = ((r - 1) + lane0) / kBitBlock;
+		const RoundPlan P = plan_round(r, k, lane0, btop);
 		{
 			/* this lane's piece */
 			const int d = 4 * wv + (lane >> 4);
-			const int b = btop - d < 0 ? 0 : btop - d;       /* pieces above block 0 replay block 0 and are never read */
-			const int g = piece_group(lane0, d);
+			int delta, g;
+			piece_of(P, d, delta, g);
+			const int b = btop - delta < 0 ? 0 : btop - delta;   /* pieces above block 0 replay block 0 and are never read */
 			const int sl = 16 * g + (lane & 15);               /* lane index in the strip */
 			BitState<W> S;
 			if (b > 0) {
@@ -582,8 +613,11 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 					const int wi = kc / (32 * W);
 					const int sl = wi & 63;
 					const int l = (ri - 1) + sl;
-					const int d = btop - l / kBitBlock;
-					if ((wi >> 6) == s && d >= 0 && d < kPieces && d <= btop && (sl >> 4) == piece_group(lane0, d)) {
+					const int delta = btop - l / kBitBlock;        /* <= btop: l >= 0 */
+					const int grp = sl >> 4;
+					const bool second = delta > P.dc || (delta == P.dc && grp != P.ghi);
+					const int d = delta + (second ? 1 : 0);
+					if ((wi >> 6) == s && delta >= 0 && d < kPieces && grp == (second ? P.ghi - 1 : P.ghi)) {
 						const int at = ((l % kBitBlock) * 16 + (sl & 15)) * W + ((kc >> 5) % W);
 						const uint2 dd = tile[d][at];
 						const uint32_t bit = 1u << (kc & 31);
