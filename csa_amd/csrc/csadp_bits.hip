@@ -100,20 +100,28 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[
 	 * run ONE wave per SIMD): all 32 up front; a lone wave otherwise waits out an LDS round trip in every step,
 	 * 235 cycles per step where its 31 VALU instructions take 130 (tools/cellstep_microbench.hip).  Up-front
 	 * reads in the many-wave kernel cost 12 % of its throughput (measured), hence the switch. */
+	/* One wave per SIMD (AHEAD): LDS instructions cost a lone wave 16-27 cycles of its issue time each, so both directions
+	 * move four steps at a time -- 8 ds_read_b128 up front, 8 ds_write_b128 -- instead of 32 + 32 (a 16 kbp pair 1.49 -> 1.44 ms,
+	 * a 200 kbp pair 17.9 -> 17.4).  With several waves per SIMD the same batching LOSES 2 % sustained and 10 % at four
+	 * passes per launch (measured), although the bare step says otherwise (tools/carrystep_probe.hip: 113 cycles at four
+	 * waves per SIMD, 144 with a write and a read per step, 124 with one of each per four steps): word by word there. */
 	uint32_t ioff = 0;
 	asm volatile("" : "+v"(ioff));
 	const uint32_t *ip = reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(inject, 16)) + ioff;
-	uint32_t inj[AHEAD ? kBitBlock : 1];
-	uint32_t cur = ip[0];
+	const uint4 *ip4 = reinterpret_cast<const uint4 *>(inject) + ioff;
+	uint4 inj4[AHEAD ? kBitBlock / 4 : 1];
+	uint32_t cur = AHEAD ? 0u : ip[0];
 	if (AHEAD) {
 #pragma unroll
-		for (int t = 0; t < kBitBlock; ++t) inj[AHEAD ? t : 0] = ip[t];
+		for (int j = 0; j < kBitBlock / 4; ++j) inj4[AHEAD ? j : 0] = ip4[j];
 	}
+	[[maybe_unused]] uint32_t pp[4];
 #pragma unroll
 	for (int t = 0; t < kBitBlock; ++t) {
 		uint32_t in;
 		if (AHEAD) {
-			in = from_left<ROWS>(inj[AHEAD ? t : 0], S.PP);
+			const uint4 g4 = inj4[AHEAD ? t / 4 : 0];
+			in = from_left<ROWS>((t & 3) == 0 ? g4.x : (t & 3) == 1 ? g4.y : (t & 3) == 2 ? g4.z : g4.w, S.PP);
 		} else {
 			const uint32_t nxt = ip[t + 1 < kBitBlock ? t + 1 : t];
 			in = from_left<ROWS>(cur, S.PP);
@@ -157,7 +165,12 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[
 				const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);      /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
 				const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);      /* byte 3 <- O0 byte 3 */
 				S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
-				if (FEEDS) lanebuf[t] = S.PP;                       /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks, all others -> a scrap row */
+				if (FEEDS && AHEAD) {                               /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks, all others -> a scrap slot */
+					pp[t & 3] = S.PP;
+					if ((t & 3) == 3) *reinterpret_cast<uint4 *>(lanebuf + t - 3) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
+				} else if (FEEDS) {
+					lanebuf[t] = S.PP;
+				}
 			}
 
 			/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
@@ -260,9 +273,9 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *_
 {
 	constexpr int OUT = CKPT ? OUT_NONE : OUT_GLOBAL;
 	constexpr int W = CKPT ? kCkptWords : 1;
-	__shared__ uint32_t ring[kBitMaxStrips][kRingSteps];
+	__shared__ __attribute__((aligned(16))) uint32_t ring[kBitMaxStrips][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
-	__shared__ uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
+	__shared__ __attribute__((aligned(16))) uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
 	__shared__ uint32_t scrap[kBitMaxStrips][kLanes + kBitBlock];   /* lane l, step t -> word l + t: 64 different banks per store */
 	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
 	const BitJob &J = jobs[blockIdx.x];
@@ -376,10 +389,11 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 {
 	constexpr int OUT = OUT_NONE;
 	constexpr int W = kCkptWords;
-	__shared__ uint32_t ring[WAVES][kRingSteps];
+	__shared__ __attribute__((aligned(16))) uint32_t ring[WAVES][kRingSteps];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[WAVES][kBitBlock];
-	__shared__ uint32_t mbuf[WAVES][3][kBitBlock];
-	__shared__ uint32_t scrap[WAVES][kLanes + kBitBlock];
+	__shared__ __attribute__((aligned(16))) uint32_t mbuf[WAVES][3][kBitBlock];
+	/* word l + t per lane and step (64 different banks per store); one wave per SIMD: 16 bytes per lane and four steps at word 4 l + t */
+	__shared__ __attribute__((aligned(16))) uint32_t scrap[WAVES][(WAVES == 4 ? 4 : 1) * kLanes + kBitBlock];
 	__shared__ int made[WAVES], taken[WAVES];
 	const TileRef item = work[blockIdx.x];                      /* x: the work list of one pass, y: the pass */
 	const BitJob &J = jobs[(size_t)blockIdx.y * njobs + item.job];
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__re
 		}
 		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
 		if (lane < kBitBlock) inject[wv][lane] = word;
-		uint32_t *lanebuf = !writes ? &scrap[wv][lane] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
+		uint32_t *lanebuf = !writes ? &scrap[wv][(WAVES == 4 ? 4 : 1) * lane] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
 		if (feeds) {
 			/* the ring slots of this block last held block b - kRing, whose words the consumer
 			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */

@@ -122,10 +122,17 @@ __global__ void k_new(uint32_t *out, const uint32_t *in, int nblocks)
 	out[blockIdx.x * blockDim.x + threadIdx.x] = S.nH0 ^ S.H1 ^ S.H2 ^ sink ^ (uint32_t)co2 ^ (uint32_t)co1 ^ (uint32_t)co0;
 }
 
-/* the round-2 step, as in csadp_bits.hip (without the LDS traffic) */
+/* the round-2 step, as in csadp_bits.hip; LDSMODE 0: without the LDS traffic, 1: one ds_write_b32 of the hand-off word and one
+ * broadcast ds_read_b32 of the next inject word per step (as shipped), 2: one ds_write_b128 and one ds_read_b128 per four steps */
+template <int LDSMODE>
 __global__ void k_old(uint32_t *out, const uint32_t *in, int nblocks)
 {
+	__shared__ __attribute__((aligned(16))) uint32_t lbuf[16][64 * 4 + 64];
 	const int lane = threadIdx.x & 63;
+	uint32_t *mine = &lbuf[(threadIdx.x >> 6) & 15][LDSMODE == 2 ? lane * 4 : lane];
+	const uint32_t *inj = &lbuf[(threadIdx.x >> 6) & 15][0];
+	uint32_t pp4[4] = {0, 0, 0, 0};
+	uint4 in4 = make_uint4(0, 0, 0, 0);
 	St S{in[lane], in[64 + lane], in[128 + lane]};
 	const uint32_t B0 = in[192 + lane], B1 = in[256 + lane];
 	uint32_t PP = in[320 + lane];
@@ -160,6 +167,17 @@ __global__ void k_old(uint32_t *out, const uint32_t *in, int nblocks)
 			const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);
 			const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);
 			PP = BITOP3(pq, inw, 0xffu, LA | (LB & LC));
+			if (LDSMODE == 1) {
+				mine[t] = PP;
+				cur ^= inj[(t + 1) & 31];
+			} else if (LDSMODE == 2) {
+				pp4[t & 3] = PP;
+				if ((t & 3) == 3) {
+					*reinterpret_cast<uint4 *>(mine) = make_uint4(pp4[0], pp4[1], pp4[2], pp4[3]);
+					in4 = *reinterpret_cast<const uint4 *>(inj + ((t + 1) & 28));
+				}
+				cur ^= (t & 3) == 0 ? in4.x : (t & 3) == 1 ? in4.y : (t & 3) == 2 ? in4.z : in4.w;
+			}
 			const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
 			const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
 			S.H2 = BITOP3(C1, G0, G0, LA & ~LB);
@@ -180,9 +198,11 @@ static void run(const char *name, K kernel, uint32_t *out, const uint32_t *in)
 	hipEvent_t e0, e1;
 	CHECK(hipEventCreate(&e0));
 	CHECK(hipEventCreate(&e1));
-	const int shapes[4][2] = {{256, 256}, {256, 512}, {256, 1024}, {512, 1024}};   /* 1, 2, 4, 8 waves per SIMD */
+	/* 1, 2, 4, 8 waves per SIMD on every compute unit; then 2 waves per SIMD on 128 and on 64 workgroups only (half / a
+	 * quarter of the chip busy: does a workgroup run faster when its neighbours are idle?) */
+	const int shapes[6][2] = {{256, 256}, {256, 512}, {256, 1024}, {512, 1024}, {128, 512}, {64, 512}};
 	printf("%-34s", name);
-	for (int s = 0; s < 4; ++s) {
+	for (int s = 0; s < 6; ++s) {
 		hipLaunchKernelGGL(kernel, dim3(shapes[s][0]), dim3(shapes[s][1]), 0, 0, out, in, 4);
 		CHECK(hipDeviceSynchronize());
 		float best = 1e9f;
@@ -195,8 +215,8 @@ static void run(const char *name, K kernel, uint32_t *out, const uint32_t *in)
 			CHECK(hipEventElapsedTime(&ms, e0, e1));
 			if (ms < best) best = ms;
 		}
-		const int wps = 1 << s;
-		printf("  w%d %6.1f cyc/step/SIMD", wps, best * 1e-3 * 2.4e9 / (nblocks * 32.0) / wps);
+		const int wps = s < 4 ? 1 << s : 2;
+		printf("  %s%d %6.1f", s < 4 ? "w" : (s == 4 ? "half-chip w" : "quarter-chip w"), wps, best * 1e-3 * 2.4e9 / (nblocks * 32.0) / wps);
 	}
 	printf("\n");
 }
@@ -213,7 +233,9 @@ int main()
 		h[i] = x;
 	}
 	CHECK(hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice));
-	run("round-2 step (31 VALU)", k_old, out, in);
+	run("round-2 step (31 VALU)", k_old<0>, out, in);
+	run(" + ds_write_b32, ds_read_b32 / step", k_old<1>, out, in);
+	run(" + b128 write and read / 4 steps", k_old<2>, out, in);
 	run("carry masks, VALU only (22)", k_new<0>, out, in);
 	run("carry masks + scalar part in C++", k_new<1>, out, in);
 	run("carry masks + SCC chains (18 SALU)", k_new<2>, out, in);
