@@ -193,6 +193,28 @@ def profile_path_leg(csa_amd):
     return out
 
 
+def single_matrix_leg(csa_amd):
+    """Latency of ONE matrix (BASELINE config 2: a 16 kbp pair; config 5's upper end: a 200 kbp pair): device fill and
+    traceback + row expansion of a one-job batch (its strips spread over compute units, one wave per SIMD), best of 3."""
+    from csa_amd.synth import synth_pair
+    out = {}
+    for length in (16384, 200000):
+        a, b, ra, rb = synth_pair(777, length=length)
+        pb = csa_amd.PairBatch([([a, b], [ra, rb], None, None)])
+        best = None
+        for _ in range(3):
+            pb.run()
+            pb.sync()
+            t = pb.timing()
+            if best is None or t["total_ms"] < best["total_ms"]:
+                best = t
+        pb.fetch()
+        pb.close()
+        out[str(length)] = {"fill_ms": round(best["fill_ms"], 3), "traceback_expand_ms": round(best["traceback_ms"], 3),
+                            "gcups": round(len(a) * len(b) / best["total_ms"] / 1e6, 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -391,6 +413,7 @@ def main():
             line["streaming"]["pairs_per_batch"] = len(big)
             line["streaming"]["vs_value"] = round(line["streaming"]["gcups"] / (value / args.gpus), 3)
             line["profile_path"] = profile_path_leg(csa_amd)
+            line["single_matrix"] = single_matrix_leg(csa_amd)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)
             line["cpu_baseline"]["many_cores"] = many_cores
