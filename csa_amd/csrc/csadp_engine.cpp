@@ -853,12 +853,25 @@ int FillBatch::layout_bits()
 	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
 	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
 	bits_group_ = 1;
+	bits_carry_ = false;
 	nslots_ = 1;
 	if (pipelined_) {
 		const int want = std::max(E.compute_units(), 1);
 		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
 		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
-		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", 2), E.main_streams()));
+		/* CSADP_BITS_CARRY=1 (off by default) selects the scalar-carry kernels of csadp_carry.hip for launches of this kind.
+		 * They run best with four fill launches in flight, the vector form with two (tools/ab2.sh, ms per pass over 48 passes:
+		 * vector 2 x 2 0.868, carry 2 x 2 0.88-0.92, carry 4 x 2 0.81-0.83) -- but over the driver's 20 passes the gain is
+		 * -4..+2 %, and the streaming leg (one 512-pair pass per batch) falls from 31 to 23 TCUPS behind their heavier traceback:
+		 * measured, kept selectable and under test, not the default. */
+		long long strips = 0;
+		bool narrow = true;
+		for (const BitJob &B : bjobs_) {
+			strips += B.nstrips;
+			if (B.nstrips > kBitMaxStrips) narrow = false;
+		}
+		bits_carry_ = bits_ckpt_ && narrow && kBitCkptWords == 1 && strips * bits_group_ >= 8LL * want && env_int("CSADP_BITS_CARRY", 0) != 0;
+		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", bits_carry_ ? 4 : 2), E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
 		 * stream while the next fill of the stream already works on the other range */
 		bits_streams_ = std::max(1, std::min(bits_streams_, Engine::kMaxSlots / (2 * bits_group_)));
@@ -884,6 +897,11 @@ int FillBatch::layout_bits()
 	for (const BitJob &B : bjobs_)
 		if (B.nstrips > bits_chunk_) bits_wide_ = true;
 	if (!bits_wide_) bits_chunk_ = kBitMaxStrips;
+	/* Pipelined launches that put two or more waves on every SIMD run the scalar-carry form of the step (csadp_carry.hip: 22
+	 * vector + 12 scalar instructions per step instead of 31 vector ones); it needs other waves to hide its scalar round trips,
+	 * so launches of few strips and the chunked launches keep the vector hand-off form (candidates chosen above, with the
+	 * number of streams). */
+	if (bits_wide_ || !pipelined_) bits_carry_ = false;
 	next_slot_ = 0;
 	size_t off = 0;
 	for (int sl = 0; sl < nslots_; ++sl) {
@@ -1236,6 +1254,8 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 				HIP_TRY(launch_fill_bits_wide(bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
 				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 		}
+	} else if (bits_carry_) {
+		HIP_TRY(launch_fill_carry(arena_, bj, g * nj, bits_maxstrips_, abort_word, st));
 	} else {
 		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, abort_word, st));
 	}
@@ -1243,7 +1263,8 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
-	HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, side));
+	if (bits_carry_) HIP_TRY(launch_traceback_carry(arena_, bj, g * nj, want_scores_, side));
+	else HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, side));
 	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
 	HIP_TRY(hipEventRecord(ev[2], side));
 	slot_used_[first] = true;
@@ -1467,7 +1488,7 @@ int FillBatch::timing(csadp_timing *t)
 	t->merge_group = bits_ ? bits_group_ : 1;
 	t->recoveries = recoveries_;
 	t->device_io = io_ ? 1 : 0;
-	t->bit_parallel = bits_ ? (bits_ckpt_ ? 2 : 1) : 0;
+	t->bit_parallel = bits_ ? (bits_carry_ ? 3 : bits_ckpt_ ? 2 : 1) : 0;
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;
 	t->fill_tiles = (long long)tiles_.size();

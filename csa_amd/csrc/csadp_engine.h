@@ -190,6 +190,7 @@ private:
 	int launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial);
 	int check_abort();
 	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0;
+	bool bits_carry_ = false;                     /* many-job checkpoint launches: the scalar-carry kernels (csadp_carry.hip) */
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	unsigned used_streams_ = 0;
 	unsigned long long issued_ = 0;             /* bit-parallel path: slot ranges (by first slot) with a launch on record */

@@ -38,6 +38,11 @@ hipError_t launch_fill_bits_wide(int waves, uint8_t *arena, const BitJob *jobs, 
                                  uint32_t epoch, int *abort_word, hipStream_t st);
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
 hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st);
+
+/* csadp_carry.hip: the same fill with the carries between lanes in scalar lane masks (checkpoint mode, one workgroup per job,
+ * many-job launches) and the traceback that replays its checkpoints; same job table, its own layout inside `ckpt` and `hand` */
+hipError_t launch_fill_carry(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int *abort_word, hipStream_t st);
+hipError_t launch_traceback_carry(uint8_t *arena, const BitJob *jobs, int njobs, bool scores, hipStream_t st);
 /* csadp_cells.hip: any fill as a persistent cell-per-lane wavefront; work = (job, chunk) items */
 /* epoch: a value no earlier launch on this memory has used (24 bits): it tags the hand-off granules between chunks */
 hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,

@@ -190,7 +190,8 @@ typedef struct csadp_timing {
 	                        /* launch; fill_ms / traceback_ms / total_ms are that launch's    */
 	int bit_parallel;       /* 0 = tiled kernels, 1 = bit-parallel kernels (nw_fill_bits) with  */
 	                        /* direction planes in HBM, 2 = bit-parallel with checkpoints and    */
-	                        /* replay traceback (default)                                        */
+	                        /* replay traceback (default), 3 = the same with the carries between */
+	                        /* lanes in scalar lane masks (csadp_carry.hip, CSADP_BITS_CARRY=1)  */
 	int merge_group;        /* passes a full launch of this batch carries (bit-parallel path)     */
 	int recoveries;         /* passes repeated on the wait-free path after a bounded wait of the  */
 	                        /* chunked fill ran out (0 in any healthy run)                        */

@@ -190,6 +190,46 @@ def test_thousands_of_small_jobs_in_one_batch(bits_mode):
     assert got[77]["aligned"] == strs and got[77]["score"] == st.last_score
 
 
+@pytest.mark.parametrize("scores", [False, True])
+def test_scalar_carry_kernels_on_a_chip_filling_batch(monkeypatch, scores):
+    """CSADP_BITS_CARRY=1: launches that put two or more waves on every SIMD run csadp_carry.hip (carries between
+    lanes in scalar lane masks, replay of whole strip blocks).  700 pairs of 2-5 strips = ~2400 strips per launch;
+    every result by its properties, a sample of them (every strip count, the longest) against the oracle; with
+    `scores` the traceback also sums its path and every fetch cross-checks it."""
+    monkeypatch.setenv("CSADP_BITS_CARRY", "1")
+    if scores:
+        monkeypatch.setenv("CSADP_FORCE_SCORES", "1")
+    r = rng(1109)
+    base = bytes(r.choice(b"ACGT") for _ in range(20000))
+    lens = (2100, 4200, 6300, 8400, 2049, 4097, 6145, 8193, 3000, 7000)
+    tasks = []
+    for i in range(700):
+        n = lens[i % len(lens)] + (i % 13)
+        o = r.randrange(len(base) - n)
+        a = base[o:o + n]
+        b = bytearray(a)
+        for _ in range(n // 11):
+            b[r.randrange(len(b))] = r.choice(b"ACGT")
+        for _ in range(n // 60):
+            q = r.randrange(len(b) - 8)
+            if r.random() < 0.5:
+                del b[q:q + 1 + i % 5]
+            else:
+                b[q:q] = bytes(r.choice(b"ACGT") for _ in range(1 + i % 4))
+        tasks.append(([a, bytes(b)], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    pb = csa_amd.PairBatch(tasks)
+    for _ in range(3):
+        pb.run()
+    pb.sync()
+    assert pb.timing()["bit_parallel"] == 3          # the scalar-carry kernels did run
+    got = pb.fetch()
+    pb.close()
+    _properties(tasks, got)
+    for i in (0, 1, 2, 3, 4, 5, 6, 7, 13, 697):
+        cons, strs, st = oracle_progressive(tasks[i][0], tasks[i][1])
+        assert got[i]["aligned"] == strs and got[i]["score"] == st.last_score, i
+
+
 def test_extreme_aspect_ratios(bits_mode):
     r = rng(109)
     long = bytes(r.choice(b"ACGT") for _ in range(150000))
