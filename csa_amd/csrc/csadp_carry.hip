@@ -116,7 +116,10 @@ __device__ __forceinline__ void bits_block(BitState &S, const uint32_t B0, const
 		shift_carries(C, F);
 		[[maybe_unused]] const uint32_t live = RAMPIN ? ((l0 + t >= lane) ? ~0u : 0u) : ~0u;
 		const uint32_t nH0 = S.nH0, H1 = S.H1, H2 = S.H2;
-		const uint32_t x0 = B0 ^ R0;
+		/* v_xor as an 8-byte instruction: with the twelve 4-byte scalar instructions of the step the number of 4-byte instructions
+		 * per step is even, so every step's vector instructions sit in the same phase of the 8-byte grid (tools/code_phase.py) */
+		uint32_t x0;
+		asm("v_xor_b32_e64 %0, %1, %2" : "=v"(x0) : "v"(B0), "v"(R0));
 		const uint32_t nE = BITOP3(x0, B1, R1, LA | (LB ^ LC));          /* 1 = mismatch */
 
 		/* vertical step >= 2: generated by a match over w = -1, carried through mismatches over w = -1 */
@@ -342,6 +345,8 @@ __global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_carry(uint8_t *
 	};
 	bool ok = true;
 	for (int b = 0; ok && b < 2 && b < nb; ++b) ok = block(b, std::true_type());
+	/* the steady-state block in the faster phase of the 8-byte grid (tools/code_phase.py) */
+	asm volatile("s_nop 0");
 	for (int b = 2; ok && b < nb; ++b) ok = block(b, std::false_type());
 	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }

@@ -124,7 +124,7 @@ __global__ void k_new(uint32_t *out, const uint32_t *in, int nblocks)
 
 /* the round-2 step, as in csadp_bits.hip; LDSMODE 0: without the LDS traffic, 1: one ds_write_b32 of the hand-off word and one
  * broadcast ds_read_b32 of the next inject word per step (as shipped), 2: one ds_write_b128 and one ds_read_b128 per four steps */
-template <int LDSMODE>
+template <int LDSMODE, int PHASE = -1>
 __global__ void k_old(uint32_t *out, const uint32_t *in, int nblocks)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t lbuf[16][64 * 4 + 64];
@@ -139,6 +139,8 @@ __global__ void k_old(uint32_t *out, const uint32_t *in, int nblocks)
 	const uint32_t *uni = in + 512;
 	for (int b = 0; b < nblocks; ++b) {
 		uint32_t cur = uni[(b & 15) * 5];
+		if (PHASE == 1) asm volatile("s_nop 0");
+		if (PHASE == 2) asm volatile("s_nop 0\n\ts_nop 0");
 #pragma unroll
 		for (int t = 0; t < 32; ++t) {
 			uint32_t inw = cur;
@@ -148,7 +150,9 @@ __global__ void k_old(uint32_t *out, const uint32_t *in, int nblocks)
 			const uint32_t c2 = __builtin_amdgcn_ubfe(inw, 15, 1);
 			const uint32_t c1 = __builtin_amdgcn_ubfe(inw, 23, 1);
 			const uint32_t nH0 = S.nH0, H1 = S.H1, H2 = S.H2;
-			const uint32_t x0 = B0 ^ R0;
+			uint32_t x0;
+			if (PHASE >= 0) asm("v_xor_b32_e64 %0, %1, %2" : "=v"(x0) : "v"(B0), "v"(R0));   /* 8 bytes, like everything else in the step */
+			else x0 = B0 ^ R0;
 			const uint32_t nE = BITOP3(x0, B1, R1, LA | (LB ^ LC));
 			const uint32_t g2 = BITOP3(nE, nH0, nH0, ~LA & LB);
 			const uint32_t s2 = nH0 + g2 + c2;
@@ -185,7 +189,7 @@ __global__ void k_old(uint32_t *out, const uint32_t *in, int nblocks)
 			S.H1 = BITOP3(G0, a1, C0, (LA & LB) | (~LA & LC));
 			const uint32_t b0 = BITOP3(C0, G1, G0, LC & (~LA | LB));
 			S.nH0 = BITOP3(b0, C1, G2, LA & (~LB | LC));
-			cur = cur * 5 + 1;
+			if (PHASE >= 0) asm("v_mad_u32_u24 %0, %0, 5, 1" : "+v"(cur)); else cur = cur * 5 + 1;
 		}
 	}
 	out[blockIdx.x * blockDim.x + threadIdx.x] = S.nH0 ^ S.H1 ^ S.H2 ^ PP;
@@ -236,6 +240,9 @@ int main()
 	run("round-2 step (31 VALU)", k_old<0>, out, in);
 	run(" + ds_write_b32, ds_read_b32 / step", k_old<1>, out, in);
 	run(" + b128 write and read / 4 steps", k_old<2>, out, in);
+	run("all-8-byte step, block at +0", (k_old<0, 0>), out, in);
+	run("all-8-byte step, block at +4", (k_old<0, 1>), out, in);
+	run("all-8-byte step, block at +8", (k_old<0, 2>), out, in);
 	run("carry masks, VALU only (22)", k_new<0>, out, in);
 	run("carry masks + scalar part in C++", k_new<1>, out, in);
 	run("carry masks + SCC chains (18 SALU)", k_new<2>, out, in);
