@@ -17,6 +17,12 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 
 
 def main():
+    # --warn KERNEL MIN: a line on stderr for every block of a kernel whose name contains KERNEL with less than MIN percent
+    warn = None
+    if "--warn" in sys.argv:
+        i = sys.argv.index("--warn")
+        warn = (sys.argv[i + 1], float(sys.argv[i + 2]))
+        del sys.argv[i:i + 3]
     src = sys.argv[1] if len(sys.argv) > 1 else "csadp_bits.hip"
     with tempfile.TemporaryDirectory() as tmp:
         obj, co = os.path.join(tmp, "k.o"), os.path.join(tmp, "k.co")
@@ -53,6 +59,9 @@ def main():
             odd = sum(1 for a, op, sz in big if sz == 8 and a % 8)
             print("%-70s block of %4d instructions at 0x%x: %4d of %4d 8-byte instructions at 4 mod 8 (%.0f %%)"
                   % (name[:70], len(big), big[0][0], odd, n8, 100.0 * odd / max(n8, 1)))
+            if warn and warn[0] in name and 100.0 * odd < warn[1] * max(n8, 1):
+                sys.stderr.write("WARNING: %s: a step block is in the SLOW code phase (%.0f %% of its 8-byte instructions at 4 mod 8): "
+                                 "one s_nop in front of the block loop moves it\n" % (name[:60], 100.0 * odd / max(n8, 1)))
 
 
 if __name__ == "__main__":
