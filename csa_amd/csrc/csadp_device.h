@@ -119,6 +119,7 @@ constexpr int kBitBlock = 32;        /* steps per hand-off block between strips 
 constexpr int kBitCkptWords = 1;     /* words of 32 columns per lane in checkpoint mode.  2 works (tests pass) and */
                                      /* needs 15 % fewer VALU instructions per cell, but halves the waves per job and  */
                                      /* doubles the dependency chain of a step: 36.0 vs 37.4 TCUPS measured, so 1      */
+                                     /* (again late in round 2, in either code phase: 0.90-0.92 vs 0.87 ms per pass)    */
 
 struct BitJob {
 	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */
