@@ -236,6 +236,12 @@ def main():
         from csa_amd.dist import spawn_ranks
         raise SystemExit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
+    # stdout carries ONE line, the JSON of rank 0: whatever libraries write there on the way (gloo announces its connections on
+    # stdout) is sent to stderr, the line itself goes to the descriptor kept aside
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     many_cores = None
     if args.gpus == 1 and not args.no_cpu_baseline:
         from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
@@ -421,7 +427,8 @@ def main():
     group.barrier()
     group.close()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
 
 if __name__ == "__main__":
