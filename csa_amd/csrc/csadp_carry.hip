@@ -16,7 +16,6 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <type_traits>
 
