@@ -70,7 +70,8 @@ class Timing(ctypes.Structure):
                 ("traceback_ms", ctypes.c_float), ("total_ms", ctypes.c_float),
                 ("dir_bytes", ctypes.c_longlong), ("border_bytes", ctypes.c_longlong),
                 ("launch_passes", ctypes.c_int), ("bit_parallel", ctypes.c_int),
-                ("merge_group", ctypes.c_int), ("recoveries", ctypes.c_int), ("device_io", ctypes.c_int)]
+                ("merge_group", ctypes.c_int), ("recoveries", ctypes.c_int), ("device_io", ctypes.c_int),
+                ("words_per_lane", ctypes.c_int), ("streams", ctypes.c_int)]
 
 
 # symbols declared in include/csadp.h and include/csadp_debug.h

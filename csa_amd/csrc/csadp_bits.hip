@@ -1,12 +1,12 @@
 /*
  * csadp_bits.hip -- bit-parallel form of the pairwise fill (dynamicprogramming.c:990-1029 for a
  * profile of ONE sequence: i = 1, scores +1 match / -1 mismatch / -1 gap, fresh borders) and its
- * tracebacks (dynamicprogramming.c:1037-1047).  gfx950, wave64.
+ * traceback (dynamicprogramming.c:1037-1047).  gfx950, wave64.
  *
- *   nw_fill_bits<CKPT>    K1b: one workgroup per matrix, one wave per strip of 2048 columns
- *   nw_fill_bits_wide     K1b for matrices wider than 16 strips: a workgroup per chunk of 16 strips
- *   nw_traceback_replay   K2c: checkpoint mode -- replays the blocks on the path, then walks them
- *   nw_traceback_bits     K2b: direction planes in HBM -- walks them through an LDS window
+ *   nw_fill_bits<W, WAVES, WORK>   K1b: a lane owns W words of 32 columns, a wave a strip of 2048 W columns, a
+ *                                  workgroup WAVES strips; WORK = false: one workgroup per matrix, WORK = true:
+ *                                  a workgroup per chunk of WAVES strips of a matrix (work list)
+ *   nw_traceback_replay<W, NP, SCORE>   K2c: replays the 16-lane x 32-step pieces the path crosses, walks them
  *
  * Why it is exact.  Let u = H[r][k-1] - H[r-1][k-1] (vertical step left of the cell), w =
  * H[r-1][k] - H[r-1][k-1] (horizontal step above it), both in {-1,0,1,2}.  The reference's cell
@@ -16,14 +16,26 @@
  * else L iff c - u = -1, else U.  Along a row the vertical step is a 4-state machine driven by
  * (match, w); with thermometer planes (">= 0", ">= 1", ">= 2") its ">= 2" and ">= 1" planes are
  * carry chains (generate / propagate), which an integer addition resolves for 32 columns at once,
- * and the ">= 0" plane needs no chain.  tools/bitproto.py checks these formulas against the plain
- * recurrence, tie-breaks included.
+ * and the ">= 0" plane is a shift.  tools/bitproto.py checks these formulas against the plain
+ * recurrence, tie-breaks included; tools/subco_probe.hip checks the instruction sequence below
+ * against the plain word recurrence on the device.
  *
- * Work per lane and step: one row of 32 columns in 32 VALU instructions (1 per cell against 4 in
- * the packed-16 kernel: 23 for the recurrence, written as explicit v_bitop3 truth tables, 9 for
- * the hand-off to the right neighbour).  Output: two direction words per step (2 bit per cell), or
- * -- checkpoint mode, the default -- the lane state every 32 steps and four hand-off words per
- * step, 7 % of that, from which the traceback re-derives the directions it needs.
+ * How a lane gets its three carries (round 3).  What crosses from a lane to its right neighbour is one
+ * bit per plane and step: the top bit of the neighbour's outgoing plane.  Each lane keeps the COMPLEMENT
+ * of its outgoing planes; `v_sub_co_u32_dpp vcc <- nO(left lane) - 0x80000000` borrows exactly where the
+ * left lane's top bit was set, for all 64 lanes in one instruction, and `v_addc_co_u32` takes the chain's
+ * carry from VCC.  The first lane of a wave (of a DPP row in the replay) has no left lane: the DPP operand
+ * reads 0 there (bound_ctrl) and its second operand is 0 or 1, loaded per step from LDS -- 0 - 1 borrows.
+ * With W words per lane the carry between a lane's own words is the carry-out of the previous addc: no
+ * instruction.  The row letter travels the same way: x = B ^ R (column-letter plane xor row-letter mask) of
+ * a lane's first word is the left lane's x of the step before xor a per-lane constant (v_xor_b32_dpp; the
+ * first lane keeps the value loaded for it).  The round-2 form packed everything into one hand-off word per
+ * step (2 v_perm, merge, DPP move, 4 v_bfe, v_alignbit, 2 v_add3) and every lane stored that word to LDS
+ * every step; here nothing is stored per step.  Every lane accumulates its outgoing carries
+ * (acc = 2 acc + carry: one v_addc_co_u32 per plane on the carry the chain has just left in VCC); the three
+ * words are saved with the lane's checkpoint every 32 steps, so the traceback can restart a replay at ANY
+ * lane, and lane 63's three words per block are all the next strip needs.
+ * Work per lane and step: 31 VALU for W = 1, 53 for W = 2 (0.83 per cell), 97 for W = 4 (0.76).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -35,157 +47,211 @@ namespace csadp {
 
 namespace {
 
-constexpr int kRing = 8;                 /* hand-off blocks (of 32 steps) buffered per strip boundary */
-constexpr int kRingSteps = kRing * kBitBlock;
-constexpr int kSpinMax = 1 << 22;        /* bound of every wait (~0.5 s) */
+constexpr int kRing = 8;                       /* blocks of hand-off words buffered per strip boundary */
+constexpr unsigned long long kSpinTicks = 50000000ull;   /* bound of every wait: 0.5 s of the 100 MHz s_memrealtime clock */
 
 /* v_bitop3_b32: any boolean function of three words in one instruction; the table is the function
  * applied to these three constants */
 constexpr uint32_t LA = 0xF0, LB = 0xCC, LC = 0xAA;
 #define BITOP3(a, b, c, expr) ((uint32_t)__builtin_amdgcn_bitop3_b32((a), (b), (c), (unsigned char)((expr) & 0xff)))
 
-/* value of lane-1: over the whole wave (lane 0 keeps `old`), or inside each row of 16 lanes (the
- * first lane of every row keeps `old`) */
-template <bool ROWS>
-__device__ __forceinline__ uint32_t from_left(uint32_t old, uint32_t src)
-{
-	/* written as the instruction itself so that the register holding `old` IS the destination
-	 * (the builtin costs a v_mov plus two wait states per step) */
-	if (ROWS) asm("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-	else asm("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(old) : "v"(src));
-	return old;
-}
+/* the same as a statement the compiler keeps in program order with the DPP statements below (all `asm volatile`): a register
+ * written by a vector instruction must not be read through DPP by one of the next two instructions, and the compiler's
+ * hazard recogniser does not look into inline assembly -- left to its scheduler, the complemented planes were computed
+ * right in front of the borrow that reads them (tools/check_dpp_hazards.py gates the build) */
+#define BITOP3_ORDERED(dst, a, b, c, expr) \
+	asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:%4" : "=v"(dst) : "v"(a), "v"(b), "v"(c), "n"((int)((expr) & 0xff)))
 
-/*
- * The word a lane hands to its right neighbour after every step (one DPP move per step):
- *   bit 31 / 23 / 15  top bit of the outgoing vertical-step planes ">= 0" / ">= 1" / ">= 2"
- *   bits 1..0          letter of the row both lanes are working on (the right lane is one step behind)
- */
+constexpr uint32_t kNoCarry = 0x80000000u;     /* complemented outgoing plane whose top bit is clear; also the subtrahend of every lane but the first */
+
 template <int W>            /* W words of 32 columns per lane */
 struct BitState {
 	uint32_t nH0[W], H1[W], H2[W];   /* horizontal steps of the row above: NOT ">= 0", ">= 1", ">= 2" */
-	uint32_t PP;                     /* hand-off word of the previous step */
+	uint32_t x0, x1;                 /* word 0: column-letter planes xor the row letter's masks (the right lane chains from them) */
+	uint32_t nO2, nO1, nO0;          /* complements of the last word's outgoing vertical-step planes */
+	uint32_t acc2, acc1, acc0;       /* the lane's outgoing carries, one bit per step, first step in bit 31 after 32 steps */
 };
 
-/* words per lane in checkpoint mode (csadp_device.h); always 1 with direction planes in HBM */
-constexpr int kCkptWords = kBitCkptWords;
+/* per-lane constants of the letter chain: D = this lane's word 0 xor the left lane's word 0, E[h] = word 0 xor word h */
+template <int W>
+struct LaneConst {
+	uint32_t D0, D1;
+	uint32_t E0[W], E1[W];
+};
 
-/* 32 steps.  inject[t] is the hand-off word entering lane 0 at step t; ringout (lane 63 of a strip
- * that has a right neighbour) receives the word leaving the strip.  RAMPIN: lanes whose row index
- * is still negative keep an empty row above.
- * FEEDS: every lane stores its hand-off word of step t to lanebuf[t] (LDS; a per-lane pointer
- * that is the ring / the marks buffer for the lanes that matter and a shared scrap row for the
- * rest -- no EXEC juggling in the step).
- * OUT_GLOBAL: dirs = this strip's direction planes in HBM.  OUT_TILE (replay): the wave is four
- * independent 16-lane pieces of strips (DPP stays inside a row, `inject` is per lane and only
- * the first lane of a row uses it, `lane` is the lane's index in its strip) and dirs = the
- * row's [32][16] tile. */
-enum : int { OUT_GLOBAL = 0, OUT_NONE = 1, OUT_TILE = 2 };
+#define CSADP_DPP_WAVE " wave_shr:1 row_mask:0xf bank_mask:0xf"
+#define CSADP_DPP_ROW " row_shr:1 row_mask:0xf bank_mask:0xf"
 
-template <bool RAMPIN, bool FEEDS, int OUT, int W, bool MATCHES = false, bool AHEAD = false>
-__device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[W], const uint32_t (&B1)[W], const uint32_t *inject,
-                                           uint32_t *lanebuf, uint2 *dirs, int l0, int lane, uint32_t *matches = nullptr)
+/* x of this lane's first word: the left lane's x of the step before, xor D.  The first lane of the wave (ROWS: of each
+ * row of 16 lanes) has no source lane and keeps `first` -- the register the instruction writes. */
+template <bool ROWS>
+__device__ __forceinline__ uint32_t chain_x(uint32_t first, uint32_t left, uint32_t d)
 {
-	/* MATCHES (replay with scoring): `matches` is an LDS tile like dirs and receives the match masks.
-	 * It must stay an LDS-typed pointer: merged with nullptr it would become a flat pointer, and
-	 * flat accesses do not reach LDS beyond 64 KB. */
-	[[maybe_unused]] uint32_t *outm = MATCHES ? matches + (lane & 15) * W : nullptr;
-	static_assert(OUT != OUT_GLOBAL || W == 1, "direction planes in HBM are laid out for one word per lane");
+	if (ROWS) asm volatile("v_xor_b32_dpp %0, %1, %2" CSADP_DPP_ROW : "+v"(first) : "v"(left), "v"(d));
+	else asm volatile("v_xor_b32_dpp %0, %1, %2" CSADP_DPP_WAVE : "+v"(first) : "v"(left), "v"(d));
+	return first;
+}
+
+/*
+ * One carry chain over the W words of a lane: vcc <- borrow of (left lane's nO) - z  [= the left lane's top bit;
+ * first lane: z = 1 borrows, z = 0 does not]; s[h] = a[h] + b[h] + carry, the carry running through the words;
+ * ACC: acc = 2 acc + the carry that leaves the lane.  The instructions of one chain stay together (VCC).
+ */
+#define CSADP_SUB(dpp) "v_sub_co_u32_dpp %[j], vcc, %[no], %[z]" dpp " bound_ctrl:0\n\t"
+#define CSADP_ACC "v_addc_co_u32 %[acc], vcc, %[acc], %[acc], vcc"
+
+template <bool ROWS, bool ACC>
+__device__ __forceinline__ void chain_w1(uint32_t &s0, uint32_t &acc, uint32_t no, uint32_t z, uint32_t a0, uint32_t b0)
+{
+	uint32_t j;
+	if (ROWS && ACC)
+		asm volatile(CSADP_SUB(CSADP_DPP_ROW) "v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc\n\t" CSADP_ACC
+		    : [j] "=&v"(j), [s0] "=&v"(s0), [acc] "+v"(acc) : [no] "v"(no), [z] "v"(z), [a0] "v"(a0), [b0] "v"(b0) : "vcc");
+	else if (ROWS)
+		asm volatile(CSADP_SUB(CSADP_DPP_ROW) "v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc"
+		    : [j] "=&v"(j), [s0] "=&v"(s0) : [no] "v"(no), [z] "v"(z), [a0] "v"(a0), [b0] "v"(b0) : "vcc");
+	else if (ACC)
+		asm volatile(CSADP_SUB(CSADP_DPP_WAVE) "v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc\n\t" CSADP_ACC
+		    : [j] "=&v"(j), [s0] "=&v"(s0), [acc] "+v"(acc) : [no] "v"(no), [z] "v"(z), [a0] "v"(a0), [b0] "v"(b0) : "vcc");
+	else
+		asm volatile(CSADP_SUB(CSADP_DPP_WAVE) "v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc"
+		    : [j] "=&v"(j), [s0] "=&v"(s0) : [no] "v"(no), [z] "v"(z), [a0] "v"(a0), [b0] "v"(b0) : "vcc");
+}
+
+template <bool ROWS, bool ACC>
+__device__ __forceinline__ void chain_w2(uint32_t &s0, uint32_t &s1, uint32_t &acc, uint32_t no, uint32_t z, uint32_t a0, uint32_t b0, uint32_t a1,
+                                         uint32_t b1)
+{
+	uint32_t j;
+#define CSADP_W2 "v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc\n\tv_addc_co_u32 %[s1], vcc, %[a1], %[b1], vcc"
+#define CSADP_W2_OUT [j] "=&v"(j), [s0] "=&v"(s0), [s1] "=&v"(s1)
+#define CSADP_W2_IN [no] "v"(no), [z] "v"(z), [a0] "v"(a0), [b0] "v"(b0), [a1] "v"(a1), [b1] "v"(b1)
+	if (ROWS && ACC) asm volatile(CSADP_SUB(CSADP_DPP_ROW) CSADP_W2 "\n\t" CSADP_ACC : CSADP_W2_OUT, [acc] "+v"(acc) : CSADP_W2_IN : "vcc");
+	else if (ROWS) asm volatile(CSADP_SUB(CSADP_DPP_ROW) CSADP_W2 : CSADP_W2_OUT : CSADP_W2_IN : "vcc");
+	else if (ACC) asm volatile(CSADP_SUB(CSADP_DPP_WAVE) CSADP_W2 "\n\t" CSADP_ACC : CSADP_W2_OUT, [acc] "+v"(acc) : CSADP_W2_IN : "vcc");
+	else asm volatile(CSADP_SUB(CSADP_DPP_WAVE) CSADP_W2 : CSADP_W2_OUT : CSADP_W2_IN : "vcc");
+#undef CSADP_W2
+#undef CSADP_W2_OUT
+#undef CSADP_W2_IN
+}
+
+template <bool ROWS, bool ACC>
+__device__ __forceinline__ void chain_w4(uint32_t (&s)[4], uint32_t &acc, uint32_t no, uint32_t z, const uint32_t (&a)[4], const uint32_t (&b)[4])
+{
+	uint32_t j;
+#define CSADP_W4                                                                                                        \
+	"v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc\n\tv_addc_co_u32 %[s1], vcc, %[a1], %[b1], vcc\n\t"                    \
+	"v_addc_co_u32 %[s2], vcc, %[a2], %[b2], vcc\n\tv_addc_co_u32 %[s3], vcc, %[a3], %[b3], vcc"
+#define CSADP_W4_OUT [j] "=&v"(j), [s0] "=&v"(s[0]), [s1] "=&v"(s[1]), [s2] "=&v"(s[2]), [s3] "=&v"(s[3])
+#define CSADP_W4_IN                                                                                                     \
+	[no] "v"(no), [z] "v"(z), [a0] "v"(a[0]), [b0] "v"(b[0]), [a1] "v"(a[1]), [b1] "v"(b[1]), [a2] "v"(a[2]), [b2] "v"(b[2]), [a3] "v"(a[3]), \
+	    [b3] "v"(b[3])
+	if (ROWS && ACC) asm volatile(CSADP_SUB(CSADP_DPP_ROW) CSADP_W4 "\n\t" CSADP_ACC : CSADP_W4_OUT, [acc] "+v"(acc) : CSADP_W4_IN : "vcc");
+	else if (ROWS) asm volatile(CSADP_SUB(CSADP_DPP_ROW) CSADP_W4 : CSADP_W4_OUT : CSADP_W4_IN : "vcc");
+	else if (ACC) asm volatile(CSADP_SUB(CSADP_DPP_WAVE) CSADP_W4 "\n\t" CSADP_ACC : CSADP_W4_OUT, [acc] "+v"(acc) : CSADP_W4_IN : "vcc");
+	else asm volatile(CSADP_SUB(CSADP_DPP_WAVE) CSADP_W4 : CSADP_W4_OUT : CSADP_W4_IN : "vcc");
+#undef CSADP_W4
+#undef CSADP_W4_OUT
+#undef CSADP_W4_IN
+}
+
+template <int W, bool ROWS, bool ACC>
+__device__ __forceinline__ void chain(uint32_t (&s)[W], uint32_t &acc, uint32_t no, uint32_t z, const uint32_t (&a)[W], const uint32_t (&b)[W])
+{
+	static_assert(W == 1 || W == 2 || W == 4, "words per lane");
+	if constexpr (W == 1) chain_w1<ROWS, ACC>(s[0], acc, no, z, a[0], b[0]);
+	else if constexpr (W == 2) chain_w2<ROWS, ACC>(s[0], s[1], acc, no, z, a[0], b[0], a[1], b[1]);
+	else chain_w4<ROWS, ACC>(s, acc, no, z, a, b);
+}
+
+/* What the first lane of a wave (fill) / of a DPP row (replay) is given per step, 8 words in LDS: its x0, x1, and
+ * 1 / 0 = carry / no carry into its planes ">= 2", ">= 1", ">= 0".  Every other lane reads the same offsets of
+ * a constant row block whose subtrahend slots hold 0x80000000. */
+constexpr int kInjWords = 8;
+enum : int { INJ_X0 = 0, INJ_X1 = 1, INJ_Z2 = 2, INJ_Z1 = 3, INJ_Z0 = 4 };
+
+enum : int { OUT_NONE = 0, OUT_TILE = 1 };
+
+/*
+ * 32 steps.  ip: this lane's source of per-step inputs in LDS (the inject rows for a first lane, the constant
+ * rows for all others), read PF steps ahead.  RAMPIN: lanes whose row index is still negative keep an empty
+ * row above.  OUT_NONE (fill): ACC is on, nothing is stored.  OUT_TILE (replay): the wave is four independent
+ * pieces of 16 lanes (DPP stays inside a row), `out` = this lane's slot in step 0 of its piece's LDS tile
+ * [32][16 W + 1] of (not-diagonal, left) masks, `outm` the same in the tile of match masks (MATCHES).
+ */
+template <int W, bool RAMPIN, int OUT, bool MATCHES, int PF>
+__device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K, const uint32_t *ip, uint2 *out, uint32_t *outm, int l0, int lane)
+{
 	constexpr bool ROWS = (OUT == OUT_TILE);
-	constexpr int ostride = ROWS ? 16 : kLanes;
-	uint2 *out = (OUT == OUT_GLOBAL) ? dirs + (size_t)l0 * kLanes + lane : dirs + (lane & 15) * W;
-	/* The words entering the row's first lane come from LDS (address kept in a VGPR: broadcast reads), each
-	 * into the register the DPP move of its step then completes.  AHEAD = false: fetched one step ahead -- with
-	 * several waves per SIMD the round trip disappears behind the other waves.  AHEAD = true (the launches that
-	 * run ONE wave per SIMD): all 32 up front; a lone wave otherwise waits out an LDS round trip in every step,
-	 * 235 cycles per step where its 31 VALU instructions take 130 (tools/cellstep_microbench.hip).  Up-front
-	 * reads in the many-wave kernel cost 12 % of its throughput (measured), hence the switch. */
-	/* One wave per SIMD (AHEAD): LDS instructions cost a lone wave 16-27 cycles of its issue time each, so both directions
-	 * move four steps at a time -- 8 ds_read_b128 up front, 8 ds_write_b128 -- instead of 32 + 32 (a 16 kbp pair 1.49 -> 1.44 ms,
-	 * a 200 kbp pair 17.9 -> 17.4).  With several waves per SIMD the same batching LOSES 2 % sustained and 10 % at four
-	 * passes per launch (measured), although the bare step says otherwise (tools/carrystep_probe.hip: 113 cycles at four
-	 * waves per SIMD, 144 with a write and a read per step, 124 with one of each per four steps): word by word there. */
-	uint32_t ioff = 0;
-	asm volatile("" : "+v"(ioff));
-	const uint32_t *ip = reinterpret_cast<const uint32_t *>(__builtin_assume_aligned(inject, 16)) + ioff;
-	const uint4 *ip4 = reinterpret_cast<const uint4 *>(inject) + ioff;
-	uint4 inj4[AHEAD ? kBitBlock / 4 : 1];
-	uint32_t cur = AHEAD ? 0u : ip[0];
-	if (AHEAD) {
+	constexpr bool ACC = (OUT == OUT_NONE);
+	constexpr int pitch = 16 * W + 1;                      /* tile row pitch in cells of W words: odd, so a diagonal walk spreads over the banks */
+	uint4 qa[PF];
+	uint32_t qb[PF];
+	asm volatile("s_nop 1");                               /* whatever the block loop moved into the state registers has landed */
 #pragma unroll
-		for (int j = 0; j < kBitBlock / 4; ++j) inj4[AHEAD ? j : 0] = ip4[j];
+	for (int p = 0; p < PF; ++p) {
+		qa[p] = *reinterpret_cast<const uint4 *>(ip + p * kInjWords);
+		qb[p] = ip[p * kInjWords + INJ_Z0];
 	}
-	[[maybe_unused]] uint32_t pp[4];
 #pragma unroll
 	for (int t = 0; t < kBitBlock; ++t) {
-		uint32_t in;
-		if (AHEAD) {
-			const uint4 g4 = inj4[AHEAD ? t / 4 : 0];
-			in = from_left<ROWS>((t & 3) == 0 ? g4.x : (t & 3) == 1 ? g4.y : (t & 3) == 2 ? g4.z : g4.w, S.PP);
-		} else {
-			const uint32_t nxt = ip[t + 1 < kBitBlock ? t + 1 : t];
-			in = from_left<ROWS>(cur, S.PP);
-			cur = nxt;
+		const uint4 in = qa[t % PF];
+		const uint32_t z0 = qb[t % PF];
+		if (t + PF < kBitBlock) {
+			qa[t % PF] = *reinterpret_cast<const uint4 *>(ip + (t + PF) * kInjWords);
+			qb[t % PF] = ip[(t + PF) * kInjWords + INJ_Z0];
 		}
-		const uint32_t R0 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 0, 1);
-		const uint32_t R1 = (uint32_t)__builtin_amdgcn_sbfe((int)in, 1, 1);
-		uint32_t c2 = __builtin_amdgcn_ubfe(in, 15, 1);
-		uint32_t c1 = __builtin_amdgcn_ubfe(in, 23, 1);
-		uint32_t below = in;                                  /* its bit 31 enters the ">= 0" plane */
-		uint32_t O0 = 0, O1 = 0, O2 = 0;
+		const uint32_t x0 = chain_x<ROWS>(in.x, S.x0, K.D0);
+		const uint32_t x1 = chain_x<ROWS>(in.y, S.x1, K.D1);
+		S.x0 = x0;
+		S.x1 = x1;
 		[[maybe_unused]] const uint32_t live = RAMPIN ? ((l0 + t >= lane) ? ~0u : 0u) : ~0u;
+		uint32_t nE[W], g2[W], s2[W], G2[W], g1[W], A1[W], s1[W], G1[W], O0[W], G0[W], nH0[W];
 #pragma unroll
 		for (int h = 0; h < W; ++h) {
-			const uint32_t nH0 = S.nH0[h], H1 = S.H1[h], H2 = S.H2[h];
-			const uint32_t x0 = B0[h] ^ R0;
-			const uint32_t nE = BITOP3(x0, B1[h], R1, LA | (LB ^ LC));          /* 1 = mismatch */
-
+			nH0[h] = S.nH0[h];
+			nE[h] = (h == 0) ? (x0 | x1) : ((x0 ^ K.E0[h]) | (x1 ^ K.E1[h]));           /* 1 = mismatch */
 			/* vertical step >= 2: generated by a match over w = -1, carried through mismatches over w = -1 */
-			const uint32_t g2 = BITOP3(nE, nH0, nH0, ~LA & LB);
-			const uint32_t s2 = nH0 + g2 + c2;
-			const uint32_t G2 = BITOP3(s2, nH0, g2, LA ^ LB ^ LC);             /* incoming: u >= 2 */
-			O2 = BITOP3(g2, nH0, G2, LA | (LB & LC));                         /* outgoing */
-
+			g2[h] = BITOP3(nE[h], nH0[h], nH0[h], ~LA & LB);
+		}
+		chain<W, ROWS, ACC>(s2, S.acc2, S.nO2, in.z, nH0, g2);
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			G2[h] = BITOP3(s2[h], nH0[h], g2[h], LA ^ LB ^ LC);                         /* incoming: u >= 2 */
+			if (h == W - 1) BITOP3_ORDERED(S.nO2, g2[h], nH0[h], G2[h], ~(LA | (LB & LC)));   /* NOT outgoing: between this step's two other chains */
 			/* >= 1: match over w <= 0, or mismatch over w = 0 with u >= 2; carried over w = -1 */
-			const uint32_t t1 = BITOP3(nE, nH0, G2, ~LA | (~LB & LC));
-			const uint32_t g1 = BITOP3(t1, H1, H1, LA & ~LB);
-			const uint32_t A1 = BITOP3(g1, nE, nH0, LA | (LB & LC));
-			const uint32_t s1 = A1 + g1 + c1;
-			const uint32_t G1 = BITOP3(s1, A1, g1, LA ^ LB ^ LC);
-			O1 = BITOP3(g1, A1, G1, LA | (LB & LC));
-
+			const uint32_t t1 = BITOP3(nE[h], nH0[h], G2[h], ~LA | (~LB & LC));
+			g1[h] = BITOP3(t1, S.H1[h], S.H1[h], LA & ~LB);
+			A1[h] = BITOP3(g1[h], nE[h], nH0[h], LA | (LB & LC));
+		}
+		chain<W, ROWS, ACC>(s1, S.acc1, S.nO1, in.w, A1, g1);
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			G1[h] = BITOP3(s1[h], A1[h], g1[h], LA ^ LB ^ LC);
+			if (h == W - 1) BITOP3_ORDERED(S.nO1, g1[h], A1[h], G1[h], ~(LA | (LB & LC)));
 			/* >= 0: no chain.  match: w <= 1; mismatch: w = -1, or w = 0 and u >= 1, or w = 1 and u >= 2 */
-			const uint32_t v = BITOP3(H1, G2, G1, (LA & LB) | (~LA & LC));
-			const uint32_t w = BITOP3(nE, v, H2, ~LC & (~LA | LB));
-			O0 = BITOP3(w, nE, nH0, LA | (LB & LC));
-			const uint32_t G0 = __builtin_amdgcn_alignbit(O0, below, 31);        /* (O0 << 1) | carry */
-			if (h == W - 1) {
-				/* hand-off word for the right neighbour (top bits of the last word's outgoing planes),
-				 * early: the rest of the step lies between this write and the next step's DPP read */
-				const uint32_t q = __builtin_amdgcn_perm(O1, O2, 0x0c07030cu);      /* byte 2 <- O1 byte 3, byte 1 <- O2 byte 3 */
-				const uint32_t pq = __builtin_amdgcn_perm(O0, q, 0x0702010cu);      /* byte 3 <- O0 byte 3 */
-				S.PP = BITOP3(pq, in, 0xffu, LA | (LB & LC));
-				if (FEEDS && AHEAD) {                               /* LDS: lane 63 -> ring, lanes 15/31/47 -> marks, all others -> a scrap slot */
-					pp[t & 3] = S.PP;
-					if ((t & 3) == 3) *reinterpret_cast<uint4 *>(lanebuf + t - 3) = make_uint4(pp[0], pp[1], pp[2], pp[3]);
-				} else if (FEEDS) {
-					lanebuf[t] = S.PP;
-				}
-			}
-
+			const uint32_t v = BITOP3(S.H1[h], G2[h], G1[h], (LA & LB) | (~LA & LC));
+			const uint32_t w = BITOP3(nE[h], v, S.H2[h], ~LC & (~LA | LB));
+			O0[h] = BITOP3(w, nE[h], nH0[h], LA | (LB & LC));
+		}
+		/* G0 = (O0 << 1) | carry = O0 + O0 + carry, the carry running through the lane's words like the others */
+		chain<W, ROWS, ACC>(G0, S.acc0, S.nO0, z0, O0, O0);
+		BITOP3_ORDERED(S.nO0, O0[W - 1], O0[W - 1], O0[W - 1], ~LA);                   /* behind its own chain: read again a step later */
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
 			/* c = H[r][k] - H[r-1][k-1]: C1 = (c = 1), C0 = (c >= 0); new horizontal steps c - u */
-			const uint32_t C1 = BITOP3(nE, G2, H2, ~LA | LB | LC);
-			const uint32_t C0 = BITOP3(nE, G1, H1, ~LA | LB | LC);
-			uint32_t T2 = BITOP3(C1, G0, G0, LA & ~LB);
-			const uint32_t a1 = BITOP3(C1, G1, G1, LA & ~LB);
-			uint32_t T1 = BITOP3(G0, a1, C0, (LA & LB) | (~LA & LC));
-			const uint32_t b0 = BITOP3(C0, G1, G0, LC & (~LA | LB));
-			uint32_t nT0 = BITOP3(b0, C1, G2, LA & (~LB | LC));
-			if (OUT != OUT_NONE) {
-				const uint32_t notdiag = C0 & nE;
+			const uint32_t C1 = BITOP3(nE[h], G2[h], S.H2[h], ~LA | LB | LC);
+			const uint32_t C0 = BITOP3(nE[h], G1[h], S.H1[h], ~LA | LB | LC);
+			uint32_t T2 = BITOP3(C1, G0[h], G0[h], LA & ~LB);
+			const uint32_t a1 = BITOP3(C1, G1[h], G1[h], LA & ~LB);
+			uint32_t T1 = BITOP3(G0[h], a1, C0, (LA & LB) | (~LA & LC));
+			const uint32_t b0 = BITOP3(C0, G1[h], G0[h], LC & (~LA | LB));
+			uint32_t nT0 = BITOP3(b0, C1, G2[h], LA & (~LB | LC));
+			if (OUT == OUT_TILE) {
+				const uint32_t notdiag = C0 & nE[h];
 				const uint32_t left = notdiag & nT0;
-				out[t * ostride * W + h] = make_uint2(notdiag, left);
-				if (MATCHES) outm[t * ostride * W + h] = ~nE;       /* match mask: the walk scores its path */
+				out[t * pitch + h] = make_uint2(notdiag, left);
+				if (MATCHES) outm[t * pitch + h] = ~nE[h];        /* match mask: the walk scores its path */
 			}
 			if (RAMPIN) {
 				nT0 |= ~live;
@@ -195,59 +261,46 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const uint32_t (&B0)[
 			S.nH0[h] = nT0;
 			S.H1[h] = T1;
 			S.H2[h] = T2;
-			if (h + 1 < W) {                                       /* carries into the lane's next word */
-				c2 = O2 >> 31;
-				c1 = O1 >> 31;
-				below = O0;
-			}
 		}
 	}
 }
 
-/* lane state in the checkpoint array: W = 1: one uint4 (3 planes + hand-off word); W = 2: two */
+/* checkpoint of a lane after block b of strip s: planes per word h at ck[((s nb + b) W + h) 64 + lane] (.w of word 0: acc2),
+ * the other two accumulators at hand[(s nb + b) 64 + lane] */
 template <int W>
-__device__ __forceinline__ void save_state(uint4 *ck, size_t idx, const BitState<W> &S)
+__device__ __forceinline__ void save_state(uint4 *ck, uint2 *hand, size_t blk, int lane, const BitState<W> &S)
 {
-	if (W == 1) {
-		ck[idx] = make_uint4(S.nH0[0], S.H1[0], S.H2[0], S.PP);
-	} else {
-		ck[idx * 2] = make_uint4(S.nH0[0], S.H1[0], S.H2[0], S.PP);
-		ck[idx * 2 + 1] = make_uint4(S.nH0[W - 1], S.H1[W - 1], S.H2[W - 1], 0u);
-	}
+#pragma unroll
+	for (int h = 0; h < W; ++h) ck[(blk * W + h) * kLanes + lane] = make_uint4(S.nH0[h], S.H1[h], S.H2[h], h == 0 ? S.acc2 : 0u);
+	hand[blk * kLanes + lane] = make_uint2(S.acc1, S.acc0);
 }
 
 template <int W>
-__device__ __forceinline__ void load_state(const uint4 *ck, size_t idx, BitState<W> &S)
+__device__ __forceinline__ void fresh_state(BitState<W> &S)
 {
-	const uint4 v = ck[idx * W];
-	S.nH0[0] = v.x;
-	S.H1[0] = v.y;
-	S.H2[0] = v.z;
-	S.PP = v.w;
-	if (W > 1) {
-		const uint4 u = ck[idx * W + 1];
-		S.nH0[W - 1] = u.x;
-		S.H1[W - 1] = u.y;
-		S.H2[W - 1] = u.z;
+#pragma unroll
+	for (int h = 0; h < W; ++h) {
+		S.nH0[h] = ~0u;
+		S.H1[h] = S.H2[h] = 0;
 	}
+	S.x0 = S.x1 = 0;
+	S.nO2 = S.nO1 = S.nO0 = kNoCarry;
+	S.acc2 = S.acc1 = S.acc0 = 0;
 }
 
 /* Counters in LDS that order LDS data only: the LDS executes one wave's accesses in the order they were issued
- * and is coherent inside the compute unit, so relaxed accesses suffice (a reader that sees the counter sees the
- * ring words stored before it; a ring word read before `taken` is stored was read before anyone can see
- * `taken`).  The round-1 form -- acquire loads, a workgroup-scope release fence before each counter store --
- * also drained the wave's outstanding checkpoint and mark stores (s_waitcnt vmcnt(0)) twice per 32-step block:
- * a round trip to memory on the path between two strips. */
-/* TIGHT: poll without sleeping.  Measured both ways per kernel: the one-workgroup-per-job kernel (+3 % of `value`) and the
- * one-wave-per-SIMD launches poll tightly; the chunked launches with 2 or 4 waves per SIMD sleep between polls (config 5:
- * 38.9 vs 40.1 ms per pass) */
-template <bool TIGHT = false>
+ * and is coherent inside the compute unit, so relaxed accesses suffice.  TIGHT: poll without sleeping (the
+ * one-workgroup-per-job launches and the one-wave-per-SIMD launches; the chunked launches with 2 or 4 waves per SIMD
+ * sleep between polls: measured both ways in round 2).  Every wait is bounded in TIME (s_memrealtime, 100 MHz). */
+template <bool TIGHT>
 __device__ __forceinline__ bool wait_at_least(const int *counter, int need)
 {
+	if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 	int spins = 0;
 	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
 		if (!TIGHT) __builtin_amdgcn_s_sleep(2);
-		if (++spins > kSpinMax) return false;
+		if ((++spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
 	}
 	return true;
 }
@@ -256,301 +309,227 @@ __device__ __forceinline__ bool wait_at_least(const int *counter, int need)
  * through the constant address space they become scalar loads, counted apart from the vector memory accesses */
 typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
 
+/* bit for step t (0..31) out of the accumulators of two consecutive blocks of the lane that feeds: `older` holds the
+ * step just before the first one wanted in its bit 0, `newer` the following 31 in bits 31..1 */
+__device__ __forceinline__ uint32_t carry_bit(uint32_t older, uint32_t newer, int t)
+{
+	const uint32_t w = __builtin_amdgcn_alignbit(older, newer, 1);
+	return (w >> (31 - t)) & 1u;
+}
+
+/* hand-off between the chunks of a matrix (WORK): three 8-byte granules per block, {accumulator, epoch}, each written
+ * by ONE write-through store and valid exactly when it carries the launch's epoch (MI355X_MICROARCH.md, data-tagged
+ * granules).  The region is zeroed when the batch is laid out and epochs are never 0. */
+__device__ __forceinline__ unsigned long long granule(uint32_t v, uint32_t epoch) { return ((unsigned long long)epoch << 32) | v; }
+
 }  // namespace
 
 /*
- * K1b.  One workgroup per job, one wave per strip.  Strip s consumes, for every row, the hand-off
- * word that leaves lane 63 of strip s-1 (the producer's lane 63 works on row r at its step r + 63);
- * the words travel through an LDS ring of kRingSteps steps, synchronised per block of 32 steps
- * (`made` = blocks the producer has finished, `taken` = blocks whose inputs the consumer has
- * fetched, for back-pressure).  All waves of a workgroup are resident, so the waits always end;
- * each is bounded all the same and a timeout raises *abort_word.
+ * K1b.  One wave per strip.  Strip s consumes, for every row, the three carries that leave lane 63 of strip s-1
+ * (which works on row r at its step r + 63).  They travel per BLOCK of 32 steps: lane 63's three accumulators, through an
+ * LDS ring inside a workgroup (`made` = blocks the producer has finished, `taken` = blocks whose inputs the consumer has
+ * fetched, for back-pressure), through epoch-tagged granules in HBM between the workgroups of a chunked matrix.  The work
+ * list puts a matrix' chunks in ascending order, so the chunk a workgroup waits for was dispatched before it -- for speed
+ * only: every wait is bounded in time, a time-out raises the abort word and the host repeats the pass chunk by chunk.
+ * LONE (WORK with 4 waves: one wave per SIMD, launches of few strips): inputs are read further ahead and polls do not sleep.
  */
-template <bool CKPT>
-__global__ __launch_bounds__(kBitMaxStrips *kLanes) void nw_fill_bits(uint8_t *__restrict__ arena,
-                                                                      const BitJob *__restrict__ jobs,
-                                                                      int *__restrict__ abort_word)
+template <int W, int WAVES, bool WORK>
+__global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs, int njobs,
+                                                              const TileRef *__restrict__ work, uint32_t epoch, int *__restrict__ abort_word)
 {
-	constexpr int OUT = CKPT ? OUT_NONE : OUT_GLOBAL;
-	constexpr int W = CKPT ? kCkptWords : 1;
-	__shared__ __attribute__((aligned(16))) uint32_t ring[kBitMaxStrips][kRingSteps];
-	__shared__ __attribute__((aligned(16))) uint32_t inject[kBitMaxStrips][kBitBlock];
-	__shared__ __attribute__((aligned(16))) uint32_t mbuf[kBitMaxStrips][3][kBitBlock];
-	__shared__ uint32_t scrap[kBitMaxStrips][kLanes + kBitBlock];   /* lane l, step t -> word l + t: 64 different banks per store */
-	__shared__ int made[kBitMaxStrips], taken[kBitMaxStrips];
-	const BitJob &J = jobs[blockIdx.x];
-	const int s = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-	if (threadIdx.x < kBitMaxStrips) {
-		made[threadIdx.x] = 0;
-		taken[threadIdx.x] = 0;
-	}
-	__syncthreads();
-	if (s >= J.nstrips) return;
-
-	const int nb = J.steps_pad / kBitBlock;
-	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
-	uint32_t B0[W], B1[W];
-#pragma unroll
-	for (int h = 0; h < W; ++h) {
-		B0[h] = cp[(s * kLanes + lane) * W + h];
-		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
-	}
-	ConstWords rp = (ConstWords)(uintptr_t)(arena + J.rowplanes);
-	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                /* requested one block ahead */
-	uint2 *dirs = reinterpret_cast<uint2 *>(arena + J.dirs) + (size_t)s * J.steps_pad * kLanes;   /* wave-uniform */
-	const bool feeds = s + 1 < J.nstrips;
-	/* checkpoint mode: the words leaving lanes 15, 31, 47 (and 63: the ring) are kept per block in
-	 * LDS and copied out once per block as four streams [4][steps_pad] per strip */
-	uint32_t *marks = CKPT ? reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad : nullptr;
-	const bool writes = (lane == kLanes - 1) ? feeds : (CKPT && (lane & 15) == 15);
-
-	BitState<W> S;
-#pragma unroll
-	for (int h = 0; h < W; ++h) {
-		S.nH0[h] = ~0u;
-		S.H1[h] = S.H2[h] = 0;
-		/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
-		 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
-		asm volatile("" : "+v"(B0[h]), "+v"(B1[h]));
-	}
-	S.PP = 0;
-	for (int b = 0; b < nb; ++b) {
-		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
-		 * the producer's step 32b + t + 63, row letter of row 32b + t */
-		uint32_t word = 0;
-		if (s > 0) {
-			const int need = (b + 3 < nb) ? b + 3 : nb;         /* producer steps up to 32b + 94 */
-			if (!wait_at_least<true>(&made[s - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			const int ps = b * kBitBlock + 63 + (lane & 31);
-			if (ps < J.steps_pad) word = ring[s - 1][ps % kRingSteps] & 0xffffff00u;
-			if (lane == 0) __hip_atomic_store(&taken[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
-		const uint32_t a0 = a0n, a1 = a1n;
-		if (b + 1 < nb) {
-			a0n = rp[b + 1];
-			a1n = rp[J.rowwords + b + 1];
-		}
-		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
-		if (lane < kBitBlock) inject[s][lane] = word;
-		uint32_t *lanebuf = !writes ? &scrap[s][lane] : (lane == kLanes - 1) ? &ring[s][(b * kBitBlock) % kRingSteps] : &mbuf[s][lane >> 4][0];
-		if (feeds) {
-			/* the ring slots of this block last held block b - kRing, whose words the consumer
-			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
-			if (!wait_at_least<true>(&taken[s + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-		}
-		if (feeds || CKPT) {
-			if (b < 2) bits_block<true, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
-			else bits_block<false, true, OUT, W>(S, B0, B1, inject[s], lanebuf, dirs, b * kBitBlock, lane);
-		} else {
-			if (b < 2) bits_block<true, false, OUT, W>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
-			else bits_block<false, false, OUT, W>(S, B0, B1, inject[s], nullptr, dirs, b * kBitBlock, lane);
-		}
-		if (CKPT) {
-			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring (strips that feed) */
-			const int g = lane >> 4 >> 1, t = lane & 31;          /* lanes 0..31 -> stream 0, 32..63 -> stream 1 */
-			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[s][g][t];
-			marks[(size_t)(g + 2) * J.steps_pad + b * kBitBlock + t] =
-			    (g == 0) ? mbuf[s][2][t] : (feeds ? ring[s][(b * kBitBlock + t) % kRingSteps] : 0u);
-			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
-		}
-		if (feeds && lane == kLanes - 1) __hip_atomic_store(&made[s], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	}
-}
-
-/*
- * K1b for jobs that do not run as ONE workgroup (checkpoint mode only): the same step function, one
- * workgroup per CHUNK of WAVES strips, all chunks of a job in flight at once.  Two uses: jobs wider than
- * 16 strips (WAVES = 16), and small batches of large jobs -- a single 16 kbp pair, the first fill of a
- * whole-genome profile alignment, config 5's 200 kbp pairs -- whose strips are spread over compute
- * units at ONE wave per SIMD (WAVES = 4) or two (WAVES = 8) instead of sharing one unit's SIMDs: a step's
- * latency is what bounds such a launch.
- * The first strip of chunk c takes the hand-off words that left the last strip of chunk c-1 from stream 3 of
- * that strip's marks in HBM.  Only bits 31 / 23 / 15 of those words are ever used (the outgoing planes'
- * top bits; the row letter comes from the row planes), so the other bits of bytes 1..3 carry the launch's
- * epoch: a word is valid exactly when it holds this launch's epoch, each is written by one write-through
- * store, and the consumer requests a block's 32 words one block ahead and re-reads (bounded) only what
- * had not arrived -- no counter, no fence (MI355X_MICROARCH.md, data-tagged granules; the round-1 form
- * published a counter behind an agent-scope release per block, which stalls a lone wave for microseconds).
- * The marks are zeroed when the batch is laid out and epochs are unique per process.  The work list puts
- * a job's chunks in ascending order, so the chunk a workgroup waits for was dispatched before it -- for
- * speed only: every wait is bounded, a time-out raises the abort word and the host repeats the pass chunk
- * by chunk.  The launch reserves enough LDS for ONE workgroup per compute unit.
- */
-constexpr uint32_t kMarkPayload = 0x80808000u;            /* bits 31, 23, 15 */
-__device__ __forceinline__ uint32_t mark_tag(uint32_t epoch)   /* 21 bits of epoch into bits 30..24, 22..16, 14..8 */
-{
-	return ((epoch & 0x7fu) << 8) | (((epoch >> 7) & 0x7fu) << 16) | (((epoch >> 14) & 0x7fu) << 24);
-}
-
-template <int WAVES>
-__global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits_wide(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs, int njobs,
-                                                                   const TileRef *__restrict__ work, uint32_t epoch,
-                                                                   int *__restrict__ abort_word)
-{
-	constexpr int OUT = OUT_NONE;
-	constexpr int W = kCkptWords;
-	__shared__ __attribute__((aligned(16))) uint32_t ring[WAVES][kRingSteps];
-	__shared__ __attribute__((aligned(16))) uint32_t inject[WAVES][kBitBlock];
-	__shared__ __attribute__((aligned(16))) uint32_t mbuf[WAVES][3][kBitBlock];
-	/* word l + t per lane and step (64 different banks per store); one wave per SIMD: 16 bytes per lane and four steps at word 4 l + t */
-	__shared__ __attribute__((aligned(16))) uint32_t scrap[WAVES][(WAVES == 4 ? 4 : 1) * kLanes + kBitBlock];
+	constexpr bool LONE = WORK && WAVES == 4;
+#ifdef CSADP_VARIANT_SLEEP
+	constexpr bool TIGHT = LONE;
+#else
+	constexpr bool TIGHT = !WORK || LONE;
+#endif
+	constexpr int PF = LONE ? 3 : 1;
+	__shared__ __attribute__((aligned(16))) uint32_t ring[WAVES][kRing][4];
+	__shared__ __attribute__((aligned(16))) uint32_t inject[WAVES][kBitBlock * kInjWords];
+	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords];
 	__shared__ int made[WAVES], taken[WAVES];
-	const TileRef item = work[blockIdx.x];                      /* x: the work list of one pass, y: the pass */
-	const BitJob &J = jobs[(size_t)blockIdx.y * njobs + item.job];
+	int chunk = 0;
+	const BitJob *jp;
+	if (WORK) {
+		const TileRef item = work[blockIdx.x];                   /* x: the work list of one pass, y: the pass */
+		jp = &jobs[(size_t)blockIdx.y * njobs + item.job];
+		chunk = item.a;
+	} else {
+		jp = &jobs[blockIdx.x];
+	}
+	const BitJob &J = *jp;
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-	const int chunk = item.a;
-	const int s = chunk * WAVES + wv;                          /* this wave's strip */
+	const int s = chunk * WAVES + wv;                            /* this wave's strip */
 	if (threadIdx.x < WAVES) {
 		made[threadIdx.x] = 0;
 		taken[threadIdx.x] = 0;
 	}
+	for (int i = threadIdx.x; i < kBitBlock * kInjWords; i += blockDim.x) konst[i] = kNoCarry;
 	__syncthreads();
 	if (s >= J.nstrips) return;
 
 	const int nb = J.steps_pad / kBitBlock;
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
 	ConstWords rp = (ConstWords)(uintptr_t)(arena + J.rowplanes);
-	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                /* requested one block ahead */
+	uint32_t a0n = rp[0], a1n = rp[J.rowwords];                  /* requested one block ahead */
 	uint32_t B0[W], B1[W];
+	const size_t w0 = ((size_t)s * kLanes + lane) * W;
 #pragma unroll
 	for (int h = 0; h < W; ++h) {
-		B0[h] = cp[(s * kLanes + lane) * W + h];
-		B1[h] = cp[J.nwords_pad + (s * kLanes + lane) * W + h];
+		B0[h] = cp[w0 + h];
+		B1[h] = cp[J.nwords_pad + w0 + h];
 	}
-	const bool feeds = wv + 1 < WAVES && s + 1 < J.nstrips;          /* a wave of this workgroup reads my ring */
-	const bool publishes = wv + 1 == WAVES && s + 1 < J.nstrips;     /* the next chunk reads my marks */
-	uint32_t *marks = reinterpret_cast<uint32_t *>(arena + J.hand) + (size_t)s * 4 * J.steps_pad;
-	const bool from_left_chunk = wv == 0 && chunk > 0;
-	const uint32_t *left_marks = from_left_chunk ? reinterpret_cast<const uint32_t *>(arena + J.hand) + ((size_t)(s - 1) * 4 + 3) * J.steps_pad : nullptr;
-	const bool writes = (lane == kLanes - 1) ? (feeds || publishes) : ((lane & 15) == 15);
-	const uint32_t tag = mark_tag(epoch);
-	constexpr uint32_t kTagMask = ~kMarkPayload & 0xffffff00u;
+	LaneConst<W> K;
+	{
+		const size_t wl = lane > 0 ? w0 - W : w0;                /* the first lane's D is never used */
+		K.D0 = B0[0] ^ cp[wl];
+		K.D1 = B1[0] ^ cp[J.nwords_pad + wl];
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			K.E0[h] = B0[0] ^ B0[h];
+			K.E1[h] = B1[0] ^ B1[h];
+		}
+	}
+	const uint32_t b00 = __builtin_amdgcn_readfirstlane(B0[0]), b10 = __builtin_amdgcn_readfirstlane(B1[0]);
+	const bool feeds = wv + 1 < WAVES && s + 1 < J.nstrips;              /* a wave of this workgroup reads my ring */
+	const bool publishes = WORK && wv + 1 == WAVES && s + 1 < J.nstrips;  /* the next chunk reads my granules */
+	const bool from_left_chunk = WORK && wv == 0 && chunk > 0;
+	uint4 *ck = reinterpret_cast<uint4 *>(arena + J.ckpt);
+	uint2 *hand = reinterpret_cast<uint2 *>(arena + J.hand);
+	/* granules [chunk boundary][block][3] */
+	unsigned long long *xout = reinterpret_cast<unsigned long long *>(arena + J.xhand) + (size_t)chunk * nb * 3;
+	const unsigned long long *xin = reinterpret_cast<const unsigned long long *>(arena + J.xhand) + (size_t)(chunk > 0 ? chunk - 1 : 0) * nb * 3;
 
 	BitState<W> S;
+	fresh_state<W>(S);
+	const uint32_t *ip = lane == 0 ? &inject[wv][0] : &konst[0];
+	/* the constants are waited for HERE: left to the compiler the wait sits at their first use inside the block loop, where
+	 * it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
+	asm volatile("" : "+v"(K.D0), "+v"(K.D1));
 #pragma unroll
-	for (int h = 0; h < W; ++h) {
-		S.nH0[h] = ~0u;
-		S.H1[h] = S.H2[h] = 0;
-		/* the column planes are waited for HERE: left to the compiler the wait sits at their first use inside the block
-		 * loop, where it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
-		asm volatile("" : "+v"(B0[h]), "+v"(B1[h]));
+	for (int h = 0; h < W; ++h) asm volatile("" : "+v"(K.E0[h]), "+v"(K.E1[h]));
+
+	/* chunk hand-off: lanes 0..2 hold one granule each.  gA / gB: the producer's blocks b+1 and b+2, pre: block b+3, requested a
+	 * block before it is needed */
+	uint32_t gA[3] = {0, 0, 0}, gB[3] = {0, 0, 0};
+	unsigned long long pre = 0;
+	auto fetch_granules = [&](int blk, unsigned long long v, uint32_t (&g)[3]) -> bool {
+		/* v: what this lane (0..2) has loaded for block blk, or garbage for blk >= nb */
+		if (blk >= nb) {
+			g[0] = g[1] = g[2] = 0;
+			return true;
+		}
+		const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+		int spins = 0;
+		for (;;) {
+			const bool ok = lane >= 3 || (uint32_t)(v >> 32) == epoch;
+			if (__all(ok)) break;
+			__builtin_amdgcn_s_sleep(1);
+			if ((++spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
+			if (!ok) v = __hip_atomic_load(&xin[(size_t)blk * 3 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		g[0] = __builtin_amdgcn_readlane((uint32_t)v, 0);
+		g[1] = __builtin_amdgcn_readlane((uint32_t)v, 1);
+		g[2] = __builtin_amdgcn_readlane((uint32_t)v, 2);
+		return true;
+	};
+	auto request = [&](int blk) -> unsigned long long {
+		return (lane < 3 && blk < nb) ? __hip_atomic_load(&xin[(size_t)blk * 3 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+	};
+	if (from_left_chunk) {
+		const unsigned long long v1 = request(1), v2 = request(2);
+		pre = request(3);
+		if (!fetch_granules(1, v1, gA) || !fetch_granules(2, v2, gB)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 	}
-	S.PP = 0;
-	/* the previous chunk's words for block 0, requested now; inside the loop always one block ahead */
-	uint32_t pre = 0;
-	if (from_left_chunk && 63 + (lane & 31) < J.steps_pad) pre = __hip_atomic_load(&left_marks[63 + (lane & 31)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
 	for (int b = 0; b < nb; ++b) {
-		/* hand-off words entering lane 0 during this block: lane t prepares step t.  Carries from
-		 * the producer's step 32b + t + 63, row letter of row 32b + t */
-		uint32_t word = 0;
-		const int ps = b * kBitBlock + 63 + (lane & 31);
-		const int need = (b + 3 < nb) ? b + 3 : nb;             /* producer steps up to 32b + 94 */
+		/* what enters lane 0 during this block: lane t prepares step t.  Carries: the producer's steps 32 b + t + 63 (its lane
+		 * 63 works on row 32 b + t then), i.e. the last step of its block b + 1 and the first 31 of block b + 2 */
+		const int t = lane & 31;
+		uint32_t z2 = 0, z1 = 0, z0 = 0;
 		if (wv > 0) {
-			if (!wait_at_least<WAVES == 4>(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-			if (ps < J.steps_pad) word = ring[wv - 1][ps % kRingSteps] & 0xffffff00u;
+			const int need = (b + 3 < nb) ? b + 3 : nb;
+			if (!wait_at_least<TIGHT>(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			uint4 A = make_uint4(0, 0, 0, 0), Bv = make_uint4(0, 0, 0, 0);
+			if (b + 1 < nb) A = *reinterpret_cast<const uint4 *>(ring[wv - 1][(b + 1) % kRing]);
+			if (b + 2 < nb) Bv = *reinterpret_cast<const uint4 *>(ring[wv - 1][(b + 2) % kRing]);
+			z2 = carry_bit(A.x, Bv.x, t);
+			z1 = carry_bit(A.y, Bv.y, t);
+			z0 = carry_bit(A.z, Bv.z, t);
 			if (lane == 0) __hip_atomic_store(&taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		} else if (from_left_chunk) {
-			uint32_t v = pre;
-			int spins = 0;
-			for (;;) {
-				const bool ok = ps >= J.steps_pad || (v & kTagMask) == tag;
-				if (__all(ok)) break;
-				__builtin_amdgcn_s_sleep(2);
-				if (++spins > kSpinMax) { if (lane == 0) atomicExch(abort_word, 1); return; }
-				if (!ok) v = __hip_atomic_load(&left_marks[ps], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			if (ps + kBitBlock < J.steps_pad) pre = __hip_atomic_load(&left_marks[ps + kBitBlock], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (ps < J.steps_pad) word = v & kMarkPayload;
+			z2 = carry_bit(gA[0], gB[0], t);
+			z1 = carry_bit(gA[1], gB[1], t);
+			z0 = carry_bit(gA[2], gB[2], t);
 		}
 		const uint32_t a0 = a0n, a1 = a1n;
 		if (b + 1 < nb) {
 			a0n = rp[b + 1];
 			a1n = rp[J.rowwords + b + 1];
 		}
-		word |= ((a0 >> (lane & 31)) & 1u) | (((a1 >> (lane & 31)) & 1u) << 1);
-		if (lane < kBitBlock) inject[wv][lane] = word;
-		uint32_t *lanebuf = !writes ? &scrap[wv][(WAVES == 4 ? 4 : 1) * lane] : (lane == kLanes - 1) ? &ring[wv][(b * kBitBlock) % kRingSteps] : &mbuf[wv][lane >> 4][0];
+		if (lane < kBitBlock) {
+			const uint32_t r0 = 0u - ((a0 >> t) & 1u), r1 = 0u - ((a1 >> t) & 1u);
+			*reinterpret_cast<uint4 *>(&inject[wv][t * kInjWords]) = make_uint4(b00 ^ r0, b10 ^ r1, z2, z1);
+			inject[wv][t * kInjWords + INJ_Z0] = z0;
+		}
+		if (b < 2) bits_block<W, true, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
+		else bits_block<W, false, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
+		save_state<W>(ck, hand, (size_t)s * nb + b, lane, S);
 		if (feeds) {
-			/* the ring slots of this block last held block b - kRing, whose words the consumer
-			 * fetches while preparing its blocks b - kRing - 2 and b - kRing - 1 */
-			if (!wait_at_least<WAVES == 4>(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
-		}
-		if (b < 2) bits_block<true, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
-		else bits_block<false, true, OUT, W, false, WAVES == 4>(S, B0, B1, inject[wv], lanebuf, nullptr, b * kBitBlock, lane);
-		{
-			/* streams 0..2: lanes 15/31/47 from mbuf, stream 3: lane 63 from the ring */
-			const int g = lane >> 5, t = lane & 31;            /* lanes 0..31 -> streams 0 and 2, 32..63 -> 1 and 3 */
-			marks[(size_t)g * J.steps_pad + b * kBitBlock + t] = mbuf[wv][g][t];
-			if (g == 0) {
-				marks[(size_t)2 * J.steps_pad + b * kBitBlock + t] = mbuf[wv][2][t];
-			} else if (publishes) {                             /* for another compute unit: tagged, written through */
-				const uint32_t v = (ring[wv][(b * kBitBlock + t) % kRingSteps] & kMarkPayload) | tag;
-				__hip_atomic_store(&marks[(size_t)3 * J.steps_pad + b * kBitBlock + t], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			} else {
-				marks[(size_t)3 * J.steps_pad + b * kBitBlock + t] = feeds ? ring[wv][(b * kBitBlock + t) % kRingSteps] : 0u;
+			/* the ring slot of this block last held block b - kRing, which the consumer fetches while preparing its blocks
+			 * b - kRing - 2 and b - kRing - 1 */
+			if (!wait_at_least<TIGHT>(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (lane == kLanes - 1) {
+				*reinterpret_cast<uint4 *>(ring[wv][b % kRing]) = make_uint4(S.acc2, S.acc1, S.acc0, 0u);
+				__hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
-			save_state<W>(reinterpret_cast<uint4 *>(arena + J.ckpt), ((size_t)s * nb + b) * kLanes + lane, S);
 		}
-		if (feeds && lane == kLanes - 1) __hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (publishes && lane == kLanes - 1) {                    /* for another compute unit: tagged, written through */
+			__hip_atomic_store(&xout[(size_t)b * 3 + 0], granule(S.acc2, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&xout[(size_t)b * 3 + 1], granule(S.acc1, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&xout[(size_t)b * 3 + 2], granule(S.acc0, epoch), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		if (from_left_chunk) {
+			gA[0] = gB[0];
+			gA[1] = gB[1];
+			gA[2] = gB[2];
+			if (!fetch_granules(b + 3, pre, gB)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			pre = request(b + 4);
+		}
 	}
 }
 
 /*
- * K2c.  Traceback in checkpoint mode: no direction planes exist in HBM.  A round starts at the
- * current cell, in block `btop` (32 steps) of strip s, lane L.  Going up its diagonal the path
- * reaches block btop-d around lane L-d, so piece d = (block btop-d, the 16-lane group holding lane
- * L-d) is replayed with the fill's own step function: lane state from the checkpoint before the
- * block, the words entering the group's first lane from the fill's marks (or, for group 0, from the
- * strip to the left).  A wave replays 4 pieces at once (one per DPP row), 4 waves = 16 pieces =
- * ~480 path cells per round; wave 0 then walks inside the 16 LDS tiles (run-batched like K2b)
- * until the path leaves them.  Replay work: ~(nrows + ncols) / 31 pieces of 16 lanes x 32 steps,
- * 3 % of the fill's work for square matrices.
- * Which 16-lane group a piece holds: the path crosses a group boundary every 16 lanes = every 16.5 blocks,
- * and it does so in the MIDDLE of a block -- the cells of that block lie in two groups.  The round-2 form gave
- * every block one group ((L - d) / 16) and so ended a round at each crossing, usually twice (in-kernel timers on a
- * 16 kbp pair: 64 rounds where 34 + 8 strip crossings would do; a round costs 15 k cycles: checkpoint loads 1.8 k,
- * replay 5.4 k, walk 7.5 k).  Now a round is planned from the diagonal through the current cell: `dc` = the block
- * (counted down from btop) holding the first cell of the next group down; blocks before it are replayed for the
- * current group, blocks after it for the next one, and block dc for BOTH (piece dc and piece dc + 1).
+ * K2c.  Traceback: no direction planes exist in HBM.  A round starts at the current cell (r, k): lane `lane0` of strip s,
+ * block btop.  Going up its diagonal the path reaches block btop - d around lane lane0 - d / W, so piece d = (block
+ * btop - d, the 16 lanes around the diagonal there) is replayed with the fill's own step function: lane state from the
+ * checkpoint before the block, the carries entering the piece's first lane from the accumulators of the lane to its left
+ * (every lane has them: a piece starts at ANY lane; round 2 kept marks for lanes 16 / 32 / 48 only, planned a round around
+ * the 16-lane groups and replayed the block in which the diagonal changes group twice).  A wave replays 4 pieces at once (one
+ * per DPP row); wave 0 then walks inside the NP tiles, run-batched, until the path leaves them.  Replay work: ~(nrows +
+ * ncols) / 31 pieces of 16 lanes x 32 steps, 3 % of the fill's work for square matrices and W = 1.
+ * LDS tiles: [32 steps][16 lanes x W words + 1] cells of (not-diagonal, left) masks: the walk's 64 lanes read cells
+ * (r - i, k - i), one step-row apart; with the round-2 pitch of 16 cells = 128 bytes they hit two bank pairs (6.5 - 17
+ * conflict cycles per LDS instruction, profiles/r02_pmc_summary.json), with an odd pitch 32 different ones.
  */
-constexpr int kReplay = kBitCkptWords == 1 ? 4 : 2;   /* waves: 64 KB of LDS tiles either way */
-constexpr int kPieces = 4 * kReplay;
-
-struct RoundPlan {
-	int ghi;              /* 16-lane group of the current cell */
-	int dc;               /* blocks below btop at which the diagonal enters group ghi - 1 (huge: not in this strip / matrix) */
-};
-
-__device__ __forceinline__ RoundPlan plan_round(int r, int k, int lane0, int btop)
+template <int W>
+__device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d)
 {
-	constexpr int CL = 32 * kCkptWords;                    /* columns per lane */
-	RoundPlan P;
-	P.ghi = lane0 >> 4;
-	P.dc = 1 << 20;
-	const int cx = ((k - 1) % (16 * CL)) + 1;              /* cells up the diagonal to the first cell of the group below */
-	const int r2 = r - cx, k2 = k - cx;
-	if (P.ghi > 0 && r2 > 0 && k2 > 0) {
-		const int lane2 = ((k2 - 1) / CL) & 63;
-		P.dc = btop - ((r2 - 1) + lane2) / kBitBlock;
-	}
-	return P;
+	constexpr int cs = W == 1 ? 5 : W == 2 ? 6 : 7;            /* log2 of the columns per lane */
+	const int m = max(0, 32 * d - 31 + (l0 & 31));             /* cells up the diagonal to the piece's block (upper bound) */
+	const int le = ((k0 - 1 - m) >> cs) - 64 * s;              /* lane of the diagonal there; negative: left of this strip */
+	return min(max(le - 8, 0), kLanes - 16);
 }
 
-/* piece p of a round: how many blocks below btop, and which group */
-__device__ __forceinline__ void piece_of(const RoundPlan &P, int p, int &delta, int &g)
+template <int W, int NP, bool SCORE>       /* SCORE: also sum the move scores of the path (score-only callers skip the host walk) */
+__global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
-	const bool hi = p <= P.dc;
-	delta = hi ? p : p - 1;
-	g = hi ? P.ghi : P.ghi - 1;
-}
-
-template <bool SCORE>       /* SCORE: also sum the move scores of the path (score-only callers skip the host walk) */
-__global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
-{
-	constexpr int W = kCkptWords;
-	__shared__ __attribute__((aligned(16))) uint2 tile[kPieces][kBitBlock * 16 * W];
-	__shared__ uint32_t mtile[SCORE ? kPieces : 1][SCORE ? kBitBlock * 16 * W : 1];    /* match masks of the same cells */
-	__shared__ __attribute__((aligned(16))) uint32_t inject[kPieces][kBitBlock];
+	constexpr int pitch = 16 * W + 1;
+	constexpr int cs = W == 1 ? 5 : W == 2 ? 6 : 7;
+	__shared__ __attribute__((aligned(16))) uint2 tile[NP][kBitBlock * pitch];
+	__shared__ uint32_t mtile[SCORE ? NP : 1][SCORE ? kBitBlock * pitch : 1];    /* match masks of the same cells */
+	__shared__ __attribute__((aligned(16))) uint32_t inject[NP][kBitBlock * kInjWords];
+	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords];
 	__shared__ int pos[4];
 
 	const BitJob &J = jobs[blockIdx.x];
@@ -559,84 +538,131 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
 	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
 	const uint4 *ck = reinterpret_cast<const uint4 *>(arena + J.ckpt);
-	const uint32_t *marks = reinterpret_cast<const uint32_t *>(arena + J.hand);
+	const uint2 *hand = reinterpret_cast<const uint2 *>(arena + J.hand);
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 	const int nb = J.steps_pad / kBitBlock;
 	int r = J.nrows, k = J.ncols;
 	int n = 0;
 	int score = 0;                                             /* sum of the move scores along the path (:993-998 for i = 1) */
+	for (int i = threadIdx.x; i < kBitBlock * kInjWords; i += blockDim.x) konst[i] = kNoCarry;
+	__syncthreads();
+
+	/* the three accumulators lane `l` of strip `st` saved after block `blk` (0 outside the matrix' blocks) */
+	auto acc_of = [&](int st, int blk, int l, uint32_t (&a)[3]) {
+		a[0] = a[1] = a[2] = 0;
+		if (blk < 0 || blk >= nb) return;
+		const size_t at = (size_t)st * nb + blk;
+		a[0] = ck[(at * W) * kLanes + l].w;
+		const uint2 h = hand[at * kLanes + l];
+		a[1] = h.x;
+		a[2] = h.y;
+	};
+	/* mask of bit `row` of a row plane (rows beyond the planes: never on a path) */
+	auto row_mask = [&](int plane, int row) -> uint32_t {
+		if (row < 0 || row >= J.steps_pad) return 0u;
+		return 0u - ((rp[(size_t)plane * J.rowwords + (row >> 5)] >> (row & 31)) & 1u);
+	};
 
 	while (r > 0 && k > 0) {
-		const int w0 = (k - 1) / (32 * W);                   /* lane column of the current cell */
-		const int s = w0 >> 6;
-		const int lane0 = w0 & 63;
-		const int btop = ((r - 1) + lane0) / kBitBlock;
-		const RoundPlan P = plan_round(r, k, lane0, btop);
+		const int wq = (k - 1) >> cs;                          /* lane column of the current cell */
+		const int s = wq >> 6;
+		const int lane0 = wq & 63;
+		const int l0 = (r - 1) + lane0;
+		const int btop = l0 / kBitBlock;
 		{
 			/* this lane's piece */
 			const int d = 4 * wv + (lane >> 4);
-			int delta, g;
-			piece_of(P, d, delta, g);
-			const int b = btop - delta < 0 ? 0 : btop - delta;   /* pieces above block 0 replay block 0 and are never read */
-			const int sl = 16 * g + (lane & 15);               /* lane index in the strip */
+			const int f = piece_first_lane<W>(k, l0, s, d);
+			const int b = btop - d < 0 ? 0 : btop - d;         /* pieces above block 0 replay block 0 and are never read */
+			const int j = lane & 15;
+			const int sl = f + j;                              /* lane index in the strip */
+			const size_t w0 = ((size_t)s * kLanes + sl) * W;
 			BitState<W> S;
-			if (b > 0) {
-				load_state<W>(ck, ((size_t)s * nb + (b - 1)) * kLanes + sl, S);
-			} else {
-#pragma unroll
-				for (int h = 0; h < W; ++h) {
-					S.nH0[h] = ~0u;
-					S.H1[h] = S.H2[h] = 0;
-				}
-				S.PP = 0;
-			}
+			fresh_state<W>(S);
 			uint32_t B0[W], B1[W];
 #pragma unroll
 			for (int h = 0; h < W; ++h) {
-				B0[h] = cp[(s * kLanes + sl) * W + h];
-				B1[h] = cp[J.nwords_pad + (s * kLanes + sl) * W + h];
+				B0[h] = cp[w0 + h];
+				B1[h] = cp[J.nwords_pad + w0 + h];
 			}
-			/* words entering the piece's first lane: lane j of the row prepares steps j and j + 16 */
+			LaneConst<W> K;
+			{
+				const size_t wl = sl > 0 ? w0 - W : w0;
+				K.D0 = B0[0] ^ cp[wl];
+				K.D1 = B1[0] ^ cp[J.nwords_pad + wl];
 #pragma unroll
-			for (int h = 0; h < 2; ++h) {
-				const int t = (lane & 15) + 16 * h;
-				uint32_t word = 0;
-				if (g == 0) {
-					const int ps = b * kBitBlock + 63 + t;     /* lane 63 of the strip to the left is 63 steps ahead */
-					if (s > 0 && ps < J.steps_pad) word = marks[((size_t)(s - 1) * 4 + 3) * J.steps_pad + ps] & 0xffffff00u;
-					const uint32_t a0 = rp[b], a1 = rp[J.rowwords + b];
-					word |= ((a0 >> t) & 1u) | (((a1 >> t) & 1u) << 1);
-				} else {
-					const int ps = b * kBitBlock + t - 1;      /* lane 16g-1 after the previous step */
-					if (ps >= 0) word = marks[((size_t)s * 4 + (g - 1)) * J.steps_pad + ps];
+				for (int h = 0; h < W; ++h) {
+					K.E0[h] = B0[0] ^ B0[h];
+					K.E1[h] = B1[0] ^ B1[h];
 				}
-				inject[d][t] = word;
 			}
-			const bool ramp = btop - 4 * wv - 3 < 2;            /* wave-uniform: some piece of this wave is in block 0 or 1 */
-			if (ramp) bits_block<true, false, OUT_TILE, W, SCORE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl, mtile[SCORE ? d : 0]);
-			else bits_block<false, false, OUT_TILE, W, SCORE>(S, B0, B1, inject[d], nullptr, tile[d], b * kBitBlock, sl, mtile[SCORE ? d : 0]);
+			if (b > 0) {
+				const size_t at = (size_t)s * nb + (b - 1);
+#pragma unroll
+				for (int h = 0; h < W; ++h) {
+					const uint4 v = ck[(at * W + h) * kLanes + sl];
+					S.nH0[h] = v.x;
+					S.H1[h] = v.y;
+					S.H2[h] = v.z;
+					if (h == 0) S.nO2 = (v.w & 1u) ? 0u : kNoCarry;          /* what the lane put out in the last step of block b - 1 */
+				}
+				const uint2 hv = hand[at * kLanes + sl];
+				S.nO1 = (hv.x & 1u) ? 0u : kNoCarry;
+				S.nO0 = (hv.y & 1u) ? 0u : kNoCarry;
+				/* x of the step before the block: the lane worked on row 32 b - 1 - sl then (not yet live: any value) */
+				const int row = b * kBitBlock - 1 - sl;
+				S.x0 = B0[0] ^ row_mask(0, row);
+				S.x1 = B1[0] ^ row_mask(1, row);
+			}
+			/* what enters the piece's first lane: lane j of the row prepares steps j and j + 16 */
+			uint32_t older[3], newer[3];
+			if (f > 0) {                                       /* the lane to the left, one step earlier */
+				acc_of(s, b - 1, f - 1, older);
+				acc_of(s, b, f - 1, newer);
+			} else if (s > 0) {                                /* lane 63 of the strip to the left is 63 steps ahead */
+				acc_of(s - 1, b + 1, kLanes - 1, older);
+				acc_of(s - 1, b + 2, kLanes - 1, newer);
+			} else {
+				older[0] = older[1] = older[2] = newer[0] = newer[1] = newer[2] = 0;
+			}
+			const uint32_t bf0 = cp[((size_t)s * kLanes + f) * W], bf1 = cp[J.nwords_pad + ((size_t)s * kLanes + f) * W];
+#pragma unroll
+			for (int hh = 0; hh < 2; ++hh) {
+				const int t = j + 16 * hh;
+				const int row = b * kBitBlock + t - f;         /* the first lane's row at step t */
+				*reinterpret_cast<uint4 *>(&inject[d][t * kInjWords]) =
+				    make_uint4(bf0 ^ row_mask(0, row), bf1 ^ row_mask(1, row), carry_bit(older[0], newer[0], t), carry_bit(older[1], newer[1], t));
+				inject[d][t * kInjWords + INJ_Z0] = carry_bit(older[2], newer[2], t);
+			}
+			const uint32_t *ip = j == 0 ? &inject[d][0] : &konst[0];
+			uint2 *out = &tile[d][j * W];
+			uint32_t *outm = &mtile[SCORE ? d : 0][SCORE ? j * W : 0];
+			const bool ramp = btop - 4 * wv - 3 < 2;           /* wave-uniform: some piece of this wave is in block 0 or 1 */
+			if (ramp) bits_block<W, true, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
+			else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
 		}
 		__syncthreads();
 		if (wv == 0) {
+			const int k0 = k;
 			for (;;) {
 				const int ri = r - lane, ki = k - lane;
 				uint32_t code = 3;                             /* 3 = stop: border or outside the replayed pieces */
 				bool match = false;
 				if (ri > 0 && ki > 0) {
 					const int kc = ki - 1;
-					const int wi = kc / (32 * W);
+					const int wi = kc >> cs;
 					const int sl = wi & 63;
 					const int l = (ri - 1) + sl;
-					const int delta = btop - l / kBitBlock;        /* <= btop: l >= 0 */
-					const int grp = sl >> 4;
-					const bool second = delta > P.dc || (delta == P.dc && grp != P.ghi);
-					const int d = delta + (second ? 1 : 0);
-					if ((wi >> 6) == s && delta >= 0 && d < kPieces && grp == (second ? P.ghi - 1 : P.ghi)) {
-						const int at = ((l % kBitBlock) * 16 + (sl & 15)) * W + ((kc >> 5) % W);
-						const uint2 dd = tile[d][at];
-						const uint32_t bit = 1u << (kc & 31);
-						code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
-						if (SCORE) match = (mtile[d][at] & bit) != 0;
+					const int d = btop - l / kBitBlock;        /* <= btop: l >= 0 */
+					if ((wi >> 6) == s && d >= 0 && d < NP) {
+						const int rel = sl - piece_first_lane<W>(k0, l0, s, d);
+						if (rel >= 0 && rel < 16) {
+							const int at = (l % kBitBlock) * pitch + rel * W + ((kc >> 5) & (W - 1));
+							const uint2 dd = tile[d][at];
+							const uint32_t bit = 1u << (kc & 31);
+							code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
+							if (SCORE) match = (mtile[SCORE ? d : 0][SCORE ? at : 0] & bit) != 0;
+						}
 					}
 				}
 				/* a run of 'D' and the gap move that ends it are taken in ONE iteration */
@@ -682,139 +708,71 @@ __global__ __launch_bounds__(kReplay *kLanes) void nw_traceback_replay(uint8_t *
 	}
 }
 
-/*
- * K2b.  The walk of dynamicprogramming.c:1037-1047 over the direction planes of nw_fill_bits;
- * same scheme as nw_traceback (csadp_kernels.hip): lane i looks at the i-th cell of the diagonal
- * through the current cell, a ballot finds the end of the run of 'D', one 'L'/'U' is taken from
- * lane 0.  Storage coordinates of cell (r, k), 1-based: word column q = (k-1) >> 5, time
- * tau = (r-1) + q (a strip's local step is tau - 64*(q >> 6)).  Going d cells up a diagonal tau
- * drops by d + d/32 and q by d/32, so the LDS window of WT tau-steps x 8 word columns x 2 planes
- * (64 KiB) is skewed left by one word column every 33 steps, in multiples of 4 columns.
- */
-__global__ __launch_bounds__(64) void nw_traceback_bits(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
-{
-	constexpr int WQ = 8;
-	constexpr int WT = 16384 / (2 * WQ);
-	__shared__ __attribute__((aligned(16))) uint32_t win[WT * WQ * 2];
-
-	const BitJob &J = jobs[blockIdx.x];
-	uint8_t *ops = arena + J.ops;
-	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
-	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
-	const int lane = threadIdx.x;
-	const int qmax = J.nwords_pad;
-	int r = J.nrows, k = J.ncols;
-	int n = 0;
-
-	while (r > 0 && k > 0) {
-		const int q0 = (k - 1) >> 5;
-		const int ttop = (r - 1) + q0;
-		const int qbase = (q0 & ~3) - 4;
-		/* unit u = (window step i, pair of word columns): 4 words = 16 bytes */
-		constexpr int UNITS = WT * WQ / 2;
-		constexpr int BATCH = 16;
-		for (int b0 = 0; b0 < UNITS / kLanes; b0 += BATCH) {
-			uint4 v[BATCH];
-#pragma unroll
-			for (int b = 0; b < BATCH; ++b) {
-				const int u = (b0 + b) * kLanes + lane;
-				const int i = u / (WQ / 2);
-				const int q = qbase - ((i / 33) & ~3) + 2 * (u % (WQ / 2));
-				const int tau = ttop - i;
-				const int l = tau - ((q >> 6) << 6);           /* local step of the strip holding q, q+1 */
-				v[b] = make_uint4(0, 0, 0, 0);
-				if (q >= 0 && q < qmax && l >= 0 && l < J.steps_pad)
-					v[b] = *reinterpret_cast<const uint4 *>(dirs + (((size_t)(q >> 6) * J.steps_pad + l) * kLanes + (q & 63)) * 2);
-			}
-#pragma unroll
-			for (int b = 0; b < BATCH; ++b) reinterpret_cast<uint4 *>(win)[(b0 + b) * kLanes + lane] = v[b];
-		}
-		__syncthreads();
-		for (;;) {
-			const int ri = r - lane, ki = k - lane;
-			uint32_t code = 3;                                 /* 3 = stop: border or outside the window */
-			if (ri > 0 && ki > 0) {
-				const int kc = ki - 1;
-				const int q = kc >> 5;
-				const int i = ttop - ((ri - 1) + q);
-				if (i >= 0 && i < WT) {
-					const int j = q - (qbase - ((i / 33) & ~3));
-					if (j >= 0 && j < WQ) {
-						/* the neighbour word of a pair belongs to row-1 of the NEXT word column: each
-						 * (i, j) slot is the word of column q at time tau, i.e. of row tau - q */
-						const uint32_t nd = win[(i * WQ + j) * 2];
-						const uint32_t lf = win[(i * WQ + j) * 2 + 1];
-						const uint32_t bit = 1u << (kc & 31);
-						code = (nd & bit) ? ((lf & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
-					}
-				}
-			}
-			const unsigned long long stop = __ballot(code != DIR_D);
-			const int run = stop ? __builtin_ctzll(stop) : kLanes;
-			if (run > 0) {
-				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
-				n += run;
-				r -= run;
-				k -= run;
-				continue;
-			}
-			const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
-			if (c0 == 3) break;
-			if (lane == 0) ops[n] = (uint8_t)c0;
-			++n;
-			if (c0 == DIR_L) --k; else --r;
-		}
-		__syncthreads();
-	}
-	if (lane == 0) {
-		summary[0] = n;
-		summary[1] = r;
-		summary[2] = k;
-		summary[3] = 0;
-	}
-}
-
-/* static LDS (8 .. 30 KB) + this = more than half of a compute unit's 160 KB: one nw_fill_bits_wide workgroup per unit */
-constexpr size_t kWideReserve = 76 * 1024;
-
 /* function attributes are per device: called by Engine::init with that device current */
-hipError_t configure_kernels()
+hipError_t configure_kernels() { return hipSuccess; }
+
+namespace {
+
+template <int W, int WAVES>
+hipError_t launch_fill_w(bool chunked, uint8_t *arena, const BitJob *jobs, int njobs, int passes, int threads, const TileRef *work, int nwork,
+                         uint32_t epoch, int *abort_word, hipStream_t st)
 {
-	hipError_t e = hipFuncSetAttribute((const void *)nw_fill_bits_wide<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nw_fill_bits_wide<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
-	if (e == hipSuccess) e = hipFuncSetAttribute((const void *)nw_fill_bits_wide<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWideReserve);
-	return e;
+	if (chunked) hipLaunchKernelGGL((nw_fill_bits<W, WAVES, true>), dim3(nwork, passes), dim3(WAVES * kLanes), 0, st, arena, jobs, njobs, work, epoch, abort_word);
+	else hipLaunchKernelGGL((nw_fill_bits<W, WAVES, false>), dim3(njobs), dim3(threads), 0, st, arena, jobs, njobs, work, epoch, abort_word);
+	return hipGetLastError();
 }
 
-hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
-                            hipStream_t st)
+template <int W>
+hipError_t launch_fill_waves(int waves, bool chunked, uint8_t *arena, const BitJob *jobs, int njobs, int passes, int threads, const TileRef *work,
+                             int nwork, uint32_t epoch, int *abort_word, hipStream_t st)
+{
+	if (waves == 4) return launch_fill_w<W, 4>(chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	if (waves == 8) return launch_fill_w<W, 8>(chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	if (waves == 16) return launch_fill_w<W, 16>(chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	return hipErrorInvalidValue;
+}
+
+hipError_t launch_fill_any(int words, int waves, bool chunked, uint8_t *arena, const BitJob *jobs, int njobs, int passes, int threads,
+                           const TileRef *work, int nwork, uint32_t epoch, int *abort_word, hipStream_t st)
+{
+	if (words == 1) return launch_fill_waves<1>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	if (words == 2) return launch_fill_waves<2>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	if (words == 4) return launch_fill_waves<4>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
 	if (maxstrips < 1 || maxstrips > kBitMaxStrips) return hipErrorInvalidValue;
-	if (checkpoints) hipLaunchKernelGGL(nw_fill_bits<true>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
-	else hipLaunchKernelGGL(nw_fill_bits<false>, dim3(njobs), dim3(maxstrips * kLanes), 0, st, arena, jobs, abort_word);
-	return hipGetLastError();
+	const int waves = maxstrips <= 4 ? 4 : maxstrips <= 8 ? 8 : 16;
+	return launch_fill_any(words, waves, false, arena, jobs, njobs, 1, maxstrips * kLanes, nullptr, 0, 0u, abort_word, st);
 }
 
-hipError_t launch_fill_bits_wide(int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
+hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
                                  uint32_t epoch, int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0 || nwork <= 0 || passes <= 0) return hipSuccess;
-	epoch &= 0x1fffffu;                                /* 21 bits travel in a mark word */
-	const dim3 grid(nwork, passes);
-	if (waves == 4) hipLaunchKernelGGL(nw_fill_bits_wide<4>, grid, dim3(4 * kLanes), kWideReserve, st, arena, jobs, njobs, work, epoch, abort_word);
-	else if (waves == 8) hipLaunchKernelGGL(nw_fill_bits_wide<8>, grid, dim3(8 * kLanes), kWideReserve, st, arena, jobs, njobs, work, epoch, abort_word);
-	else if (waves == 16) hipLaunchKernelGGL(nw_fill_bits_wide<16>, grid, dim3(16 * kLanes), kWideReserve, st, arena, jobs, njobs, work, epoch, abort_word);
-	else return hipErrorInvalidValue;
-	return hipGetLastError();
+	if (epoch == 0) return hipErrorInvalidValue;           /* zeroed granules must never look valid */
+	return launch_fill_any(words, waves, true, arena, jobs, njobs, passes, waves * kLanes, work, nwork, epoch, abort_word, st);
 }
 
-hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st)
+hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	if (checkpoints && scores) hipLaunchKernelGGL(nw_traceback_replay<true>, dim3(njobs), dim3(kReplay * kLanes), 0, st, arena, jobs);
-	else if (checkpoints) hipLaunchKernelGGL(nw_traceback_replay<false>, dim3(njobs), dim3(kReplay * kLanes), 0, st, arena, jobs);
-	else hipLaunchKernelGGL(nw_traceback_bits, dim3(njobs), dim3(kLanes), 0, st, arena, jobs);
+	/* with match masks next to the direction tiles, half as many pieces of two words fit the LDS */
+#define CSADP_TB(W_, NP_, NPS_)                                                                                                        \
+	do {                                                                                                                               \
+		if (scores) hipLaunchKernelGGL((nw_traceback_replay<W_, NPS_, true>), dim3(njobs), dim3(NPS_ * 16), 0, st, arena, jobs);        \
+		else hipLaunchKernelGGL((nw_traceback_replay<W_, NP_, false>), dim3(njobs), dim3(NP_ * 16), 0, st, arena, jobs);                \
+	} while (0)
+	if (words == 1) CSADP_TB(1, kReplayPieces1, kReplayPieces1);
+	else if (words == 2) CSADP_TB(2, kReplayPieces2, 8);
+	else if (words == 4) CSADP_TB(4, kReplayPieces4, kReplayPieces4);
+	else return hipErrorInvalidValue;
+#undef CSADP_TB
 	return hipGetLastError();
 }
 

@@ -108,38 +108,40 @@ struct PairJob {
 /*
  * Bit-parallel job: ONE first fill (i = 1, fresh borders H[0][k] = -k, H[r][0] = -r, scores
  * +1 / -1 / -1).  Adjacent cells of such a matrix differ by -1..2, so a row is held as three
- * thermometer bit planes of its horizontal differences and a lane advances 32 columns per step
- * with word-wide logic and two carry-propagating additions (csadp_kernels.hip: nw_fill_bits).
- * A wave owns a strip of 64 words = 2048 columns; the strips of a job are the waves of ONE
- * workgroup, chained through LDS, so the whole matrix is a single launch.  Lane L of a strip
- * computes row (l - L) at its local step l.
+ * thermometer bit planes of its horizontal differences and a lane advances `wpl` words of 32 columns per
+ * step with word-wide logic and carry-propagating additions (csadp_bits.hip: nw_fill_bits).
+ * A wave owns a strip of 64 * wpl words; lane L of a strip computes row (l - L) at its local step l.
+ * The fill stores no directions: after every block of 32 steps a lane saves its state and the 3 x 32
+ * carries it has put out, and the traceback replays the 16-lane x 32-step pieces its path crosses.
  */
-constexpr int kBitMaxStrips = 16;    /* waves per workgroup: jobs up to 32768 columns */
+constexpr int kBitMaxStrips = 16;    /* waves per workgroup */
 constexpr int kBitBlock = 32;        /* steps per hand-off block between strips */
-constexpr int kBitCkptWords = 1;     /* words of 32 columns per lane in checkpoint mode.  2 works (tests pass) and */
-                                     /* needs 15 % fewer VALU instructions per cell, but halves the waves per job and  */
-                                     /* doubles the dependency chain of a step: 36.0 vs 37.4 TCUPS measured, so 1      */
-                                     /* (again late in round 2, in either code phase: 0.90-0.92 vs 0.87 ms per pass)    */
+constexpr int kBitMaxWords = 4;      /* words per lane: 1, 2 or 4, chosen per batch (csadp_engine.cpp: layout_bits) */
+/* pieces (16 lanes x 32 steps) a traceback round replays, by words per lane: 64-68 KB of LDS tiles each way */
+#ifndef CSADP_TB_NP2
+#define CSADP_TB_NP2 8
+#endif
+constexpr int kReplayPieces1 = 16, kReplayPieces2 = CSADP_TB_NP2, kReplayPieces4 = 4;
 
 struct BitJob {
 	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */
 	uint64_t rowplanes;       /* u32 [2][rowwords]   same for the rows (0-based), zero padded                             */
-	uint64_t dirs;            /* u32 [nstrips][steps_pad][64][2]: word 0 = NOT-diagonal mask, word 1 = left mask of the   */
-	                          /*     32 columns of lane L in row (step - L).  Unused (0 bytes) in checkpoint mode         */
-	uint64_t ckpt;            /* checkpoint mode: u32 [nstrips][steps_pad/32][64][words][4] lane state (per word of a lane: */
-	                          /*     nH0, H1, H2; + the hand-off word) after every block of 32 steps                      */
-	uint64_t hand;            /* checkpoint mode: u32 [nstrips][4][steps_pad] hand-off words leaving lanes 15, 31, 47 and   */
-	                          /*     63 after each step: a replay can restart at any 16-lane boundary of a strip.  Stream 3  */
-	                          /*     of a chunk's last strip also feeds the next chunk (nw_fill_bits_wide): there only bits   */
-	                          /*     31/23/15 are payload, the rest of bytes 1..3 holds the launch's epoch                    */
-	uint64_t progress;        /* unused since round 2 (chunks hand over through epoch-tagged mark words, csadp_bits.hip)     */
+	uint64_t ckpt;            /* u32 [nstrips][steps_pad/32][wpl][64][4] lane state after every block of 32 steps, per word */
+	                          /*     of a lane: nH0, H1, H2; the fourth word of a lane's word 0: the carries its ">= 2"     */
+	                          /*     plane put out during the block, first step in bit 31                                   */
+	uint64_t hand;            /* u32 [nstrips][steps_pad/32][64][2] the same for the planes ">= 1" and ">= 0": with them a   */
+	                          /*     replay can start at any lane of a strip                                                */
+	uint64_t xhand;           /* u64 [nchunks-1][steps_pad/32][3] chunked launches: {carries, epoch} of lane 63 of a chunk's   */
+	                          /*     last strip per block and plane, valid when they carry the launch's epoch; zeroed at upload */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;
 	int32_t nstrips;
 	int32_t steps_pad;        /* local steps per strip, multiple of kBitBlock, >= nrows + 64                               */
-	int32_t nwords_pad;       /* 64 * nstrips                                                                              */
+	int32_t nwords_pad;       /* 64 * wpl * nstrips                                                                        */
 	int32_t rowwords;         /* steps_pad / 32                                                                            */
+	int32_t wpl;              /* words of 32 columns per lane                                                              */
+	int32_t pad_;
 	/* device-side input packing / output expansion of 2-sequence tasks (nw_pack_planes, nw_expand_rows): the batch
 	 * holds the raw circular texts; [0] = the column sequence (the shorter region, dynamicprogramming.c:290-307),
 	 * [1] = the row sequence.  text = 0 (no arena offset is 0: the job table sits there) marks a job whose planes

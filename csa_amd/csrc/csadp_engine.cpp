@@ -332,13 +332,8 @@ int FillBatch::layout()
 	cells_mode_ = false;
 	if (bits_allowed_ && nj >= 1 && env_int("CSADP_BITS", 1) != 0) {
 		bits_ = true;
-		bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
-		for (const FillJob &J : jobs_) {
+		for (const FillJob &J : jobs_)
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) bits_ = false;
-			/* more than 16 strips: a workgroup per chunk of 16 strips, chained through the recorded
-			 * hand-off words (checkpoint mode only) */
-			if (J.ncols > kBitMaxStrips * kLanes * 32 * (bits_ckpt_ ? kBitCkptWords : 1) && !bits_ckpt_) bits_ = false;
-		}
 	}
 	if (bits_) return layout_bits();
 	if (nj >= 2 && C == 16 && R <= 2 && env_int("CSADP_PK16", 1) != 0) {
@@ -816,14 +811,29 @@ int FillBatch::layout_bits()
 	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
 	bits_maxstrips_ = 1;
 	bits_wide_ = false;
+	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
+	test_abort_ = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;        /* testing: read once per layout, not per launch */
+	/* Words of 32 columns per lane (1, 2 or 4).  More words per lane amortise what a step spends on its neighbours (the three
+	 * borrow instructions, the letter chain, the accumulators: 11 of W = 1's 31 instructions, 11 of W = 2's 53) and halve the
+	 * strips -- and with them the waves -- of a matrix.  DESIGN.md section 3 has the measurements behind the default. */
+	long long total_words = 0;
+	for (const FillJob &J : jobs_) total_words += (J.ncols + 31) / 32;
+	{
+		const long long simds = 4LL * std::max(E.compute_units(), 1);
+		/* one pass of the batch as strips of 64 lanes x 2 words: enough of them for two waves on every SIMD? */
+		int w = (total_words / 128 >= 2 * simds || pipelined_) ? 2 : 1;
+		w = env_int("CSADP_BITS_WORDS", w);
+		bits_words_ = (w == 2 || w == 4) ? w : 1;
+	}
+	const int wpl = bits_words_;
 	for (int j = 0; j < nj; ++j) {
 		const FillJob &J = jobs_[(size_t)j];
 		BitJob &B = bjobs_[(size_t)j];
 		memset(&B, 0, sizeof(B));
 		B.nrows = J.nrows;
 		B.ncols = J.ncols;
+		B.wpl = wpl;
 		const int words = (J.ncols + 31) / 32;
-		const int wpl = bits_ckpt_ ? kBitCkptWords : 1;        /* words of 32 columns per lane */
 		B.nstrips = (words + wpl * kLanes - 1) / (wpl * kLanes);
 		B.nwords_pad = B.nstrips * kLanes * wpl;
 		B.steps_pad = (int)align_up((size_t)J.nrows + 64, kBitBlock);
@@ -831,59 +841,42 @@ int FillBatch::layout_bits()
 		bits_maxstrips_ = std::max(bits_maxstrips_, B.nstrips);
 		extra_[(size_t)j].ncols_pad = B.nwords_pad * 32;
 		cells_ += (long long)J.nrows * J.ncols;
-		dir_bytes_ += (long long)J.nrows * words * 8;
+		/* no direction planes: lane state + carry history per block of 32 steps */
+		border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * (16 * wpl + 8);
 	}
+	dir_bytes_ = 0;
 	/* device-side I/O: every job has its two texts registered */
 	io_ = (int)pairio_.size() == nj && nj > 0;
 	for (const PairIo &P : pairio_)
 		if (P.text[0] < 0 || P.text[1] < 0) io_ = false;
-	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
-	if (bits_ckpt_) {                              /* no direction planes: lane state per block + hand-off words */
-		dir_bytes_ = 0;
-		for (const BitJob &B : bjobs_)
-			border_bytes_ += (long long)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 * kBitCkptWords + (long long)B.nstrips * B.steps_pad * 16;
-	}
-	/* A job is one workgroup of up to 16 waves, and 128 jobs fill half of the chip's compute units, so
-	 * consecutive passes are MERGED: `group` passes (slots) form one launch of group * nj workgroups, aiming at
-	 * ONE workgroup per compute unit, and two such fill launches are kept in flight on two streams, each with
-	 * its traceback on a side stream (launch_bits_pass), so that fills never pause for a traceback.  Measured
-	 * on the bench batch (tools/sweep2.sh, ms per pass sustained over 48 passes; group x streams): 2 x 2:
-	 * 0.920-0.929, 4 x 2: 1.003-1.021, 8 x 2: 1.135-1.146, 2 x 3: 1.089-1.090, 4 x 1: 1.059-1.063 (before the
-	 * side streams: 2 x 3: 0.952-0.958, tools/sweep_groups.sh). */
-	bits_ckpt_ = env_int("CSADP_BITS_CKPT", 1) != 0;
-	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
+	/* A job is one workgroup of up to 16 waves; consecutive passes are MERGED: `group` passes (slots) form one launch of
+	 * group * nj workgroups, and `streams` such fill launches are kept in flight on as many streams, each with its traceback
+	 * on a side stream (launch_bits_pass), so that fills never pause for a traceback.  Round 2 (one word per lane, 8 waves per
+	 * 16 kbp job): group x streams = 2 x 2.  The target is the same number of WAVES in flight whatever the words per lane:
+	 * four per SIMD. */
 	bits_group_ = 1;
-	bits_carry_ = false;
 	nslots_ = 1;
 	if (pipelined_) {
-		const int want = std::max(E.compute_units(), 1);
-		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
-		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
-		/* CSADP_BITS_CARRY=1 (off by default) selects the scalar-carry kernels of csadp_carry.hip for launches of this kind.
-		 * They run best with four fill launches in flight, the vector form with two (tools/ab2.sh, ms per pass over 48 passes:
-		 * vector 2 x 2 0.868, carry 2 x 2 0.88-0.92, carry 4 x 2 0.81-0.83) -- but over the driver's 20 passes the gain is
-		 * -4..+2 %, and the streaming leg (one 512-pair pass per batch) falls from 31 to 23 TCUPS behind their heavier traceback:
-		 * measured, kept selectable and under test, not the default. */
 		long long strips = 0;
-		bool narrow = true;
-		for (const BitJob &B : bjobs_) {
-			strips += B.nstrips;
-			if (B.nstrips > kBitMaxStrips) narrow = false;
-		}
-		bits_carry_ = bits_ckpt_ && narrow && kBitCkptWords == 1 && strips * bits_group_ >= 8LL * want && env_int("CSADP_BITS_CARRY", 0) != 0;
-		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", bits_carry_ ? 4 : 2), E.main_streams()));
+		for (const BitJob &B : bjobs_) strips += B.nstrips;
+		const long long simds = 4LL * std::max(E.compute_units(), 1);
+		const int dflt_streams = 2;
+		/* passes per launch so that `dflt_streams` launches put about four waves on every SIMD */
+		long long g = strips > 0 ? (4 * simds / dflt_streams + strips - 1) / strips : 1;
+		bits_group_ = (int)std::max(1LL, std::min(g, 4LL));
+		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
+		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", dflt_streams), E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
 		 * stream while the next fill of the stream already works on the other range */
 		bits_streams_ = std::max(1, std::min(bits_streams_, Engine::kMaxSlots / (2 * bits_group_)));
 		nslots_ = bits_streams_ * 2 * bits_group_;
 	}
-	/* How many strips share a workgroup.  A job is normally ONE workgroup (nw_fill_bits, up to 16 strips).  A
-	 * launch with few strips in all -- a single 16 kbp pair, the first fills of a whole-genome profile
-	 * alignment, a 200 kbp pair -- is latency-bound: its strips are spread over compute units, 4 per
-	 * workgroup = one wave per SIMD while the launch fits the chip that way, else 8 (checkpoint mode only:
-	 * the chunks of a job hand over through the marks in HBM). */
+	/* How many strips share a workgroup.  A job is normally ONE workgroup (up to 16 strips).  A launch with few strips
+	 * in all -- a single 16 kbp pair, the first fills of a whole-genome profile alignment, a 200 kbp pair -- is
+	 * latency-bound: its strips are spread over compute units, 4 per workgroup = one wave per SIMD while the launch
+	 * fits the chip that way, else 8 (the chunks of a job hand over through granules in HBM). */
 	bits_chunk_ = kBitMaxStrips;
-	if (bits_ckpt_) {
+	{
 		long long launch_strips = 0;
 		for (const BitJob &B : bjobs_) launch_strips += B.nstrips;
 		launch_strips *= bits_group_;
@@ -897,11 +890,6 @@ int FillBatch::layout_bits()
 	for (const BitJob &B : bjobs_)
 		if (B.nstrips > bits_chunk_) bits_wide_ = true;
 	if (!bits_wide_) bits_chunk_ = kBitMaxStrips;
-	/* Pipelined launches that put two or more waves on every SIMD run the scalar-carry form of the step (csadp_carry.hip: 22
-	 * vector + 12 scalar instructions per step instead of 31 vector ones); it needs other waves to hide its scalar round trips,
-	 * so launches of few strips and the chunked launches keep the vector hand-off form (candidates chosen above, with the
-	 * number of streams). */
-	if (bits_wide_ || !pipelined_) bits_carry_ = false;
 	next_slot_ = 0;
 	size_t off = 0;
 	for (int sl = 0; sl < nslots_; ++sl) {
@@ -1022,17 +1010,18 @@ int FillBatch::layout_bits()
 		flags_bytes_ = 0;
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
-			B.progress = 0;
-			B.dirs = off;
-			if (!bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * kLanes * 8, 256);
+			const size_t blocks = (size_t)B.nstrips * (B.steps_pad / kBitBlock);
 			B.ckpt = off;
-			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * (B.steps_pad / kBitBlock) * kLanes * 16 * kBitCkptWords, 256);
+			off = align_up(off + blocks * B.wpl * kLanes * 16, 256);
+			B.hand = off;
+			off = align_up(off + blocks * kLanes * 8, 256);
 		}
-		hand_off_[sl] = off;                      /* the marks of all jobs, contiguous: zeroed by upload() when chunks hand over through them */
+		hand_off_[sl] = off;                      /* the granules between the chunks of all jobs, contiguous: zeroed by upload() */
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
-			B.hand = off;
-			if (bits_ckpt_) off = align_up(off + (size_t)B.nstrips * B.steps_pad * 16, 256);
+			B.xhand = off;
+			const int nchunks = (B.nstrips + bits_chunk_ - 1) / bits_chunk_;
+			if (bits_wide_ && nchunks > 1) off = align_up(off + (size_t)(nchunks - 1) * (B.steps_pad / kBitBlock) * 24, 256);
 		}
 		hand_bytes_ = off - hand_off_[sl];
 	}
@@ -1247,24 +1236,22 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 		/* hand-off words between the chunks of a job carry this pass' epoch (see nw_fill_bits_wide) */
 		const uint32_t epoch = Engine::next_epoch();
 		if (!serial) {
-			HIP_TRY(launch_fill_bits_wide(bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch,
-			                              abort_word, st));
+			HIP_TRY(launch_fill_bits_wide(bits_words_, bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_),
+			                              (int)tiles_.size(), epoch, abort_word, st));
 		} else {
 			for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
-				HIP_TRY(launch_fill_bits_wide(bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
+				HIP_TRY(launch_fill_bits_wide(bits_words_, bits_chunk_, arena_, bj, nj, g,
+				                              reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
 				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 		}
-	} else if (bits_carry_) {
-		HIP_TRY(launch_fill_carry(arena_, bj, g * nj, bits_maxstrips_, abort_word, st));
 	} else {
-		HIP_TRY(launch_fill_bits(arena_, bj, g * nj, bits_maxstrips_, bits_ckpt_, abort_word, st));
+		HIP_TRY(launch_fill_bits(bits_words_, arena_, bj, g * nj, bits_maxstrips_, abort_word, st));
 	}
-	if (!serial && bits_wide_ && env_int("CSADP_TEST_FORCE_ABORT", 0) != 0)   /* testing: see run_slot_cells */
+	if (!serial && bits_wide_ && test_abort_)             /* testing: see run_slot_cells */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
-	if (bits_carry_) HIP_TRY(launch_traceback_carry(arena_, bj, g * nj, want_scores_, side));
-	else HIP_TRY(launch_traceback_bits(arena_, bj, g * nj, bits_ckpt_, want_scores_, side));
+	HIP_TRY(launch_traceback_bits(bits_words_, arena_, bj, g * nj, want_scores_, side));
 	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
 	HIP_TRY(hipEventRecord(ev[2], side));
 	slot_used_[first] = true;
@@ -1343,7 +1330,7 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 			HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
 			                          (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 	}
-	if (!serial && env_int("CSADP_TEST_FORCE_ABORT", 0) != 0)   /* testing: pretend a bounded wait ran out, so that the repeat path runs */
+	if (!serial && test_abort_)                           /* testing: pretend a bounded wait ran out, so that the repeat path runs */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	HIP_TRY(launch_traceback_cells(arena_, cj, (int)cjobs_.size(), st));
@@ -1488,7 +1475,9 @@ int FillBatch::timing(csadp_timing *t)
 	t->merge_group = bits_ ? bits_group_ : 1;
 	t->recoveries = recoveries_;
 	t->device_io = io_ ? 1 : 0;
-	t->bit_parallel = bits_ ? (bits_carry_ ? 3 : bits_ckpt_ ? 2 : 1) : 0;
+	t->bit_parallel = bits_ ? 2 : 0;
+	t->words_per_lane = bits_ ? bits_words_ : 0;
+	t->streams = bits_ ? bits_streams_ : 1;
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;
 	t->fill_tiles = (long long)tiles_.size();

@@ -40,7 +40,7 @@ public:
 	/* 1, 2, ... (never 0 modulo 2^24 within 16 M passes): tags of the hand-off granules of nw_fill_cells */
 	static uint32_t next_epoch();
 	bool ready() const { return ready_; }
-	static constexpr int kMaxSlots = 16;
+	static constexpr int kMaxSlots = 32;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
 	int slots() const { return slots_; }
 	/* streams [0, main_streams()) carry fills; stream main_streams() + q is the side stream of main stream q:
@@ -165,7 +165,7 @@ public:
 	const int32_t *summary(int j) const;   /* nops, remj, remk, DP score if device_scores() else 0 */
 	/* the traceback kernel summed the move scores of its path (checkpoint mode of the bit-parallel path) */
 	void want_scores(bool on) { want_scores_ = on; }
-	bool device_scores() const { return bits_ && bits_ckpt_ && want_scores_; }
+	bool device_scores() const { return bits_ && want_scores_; }
 	int timing(csadp_timing *t);
 
 private:
@@ -190,7 +190,8 @@ private:
 	int launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial);
 	int check_abort();
 	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0;
-	bool bits_carry_ = false;                     /* many-job checkpoint launches: the scalar-carry kernels (csadp_carry.hip) */
+	int bits_words_ = 1;                          /* words of 32 columns per lane of this batch's bit-parallel kernels */
+	bool test_abort_ = false;                     /* CSADP_TEST_FORCE_ABORT, read when the batch is laid out */
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	unsigned used_streams_ = 0;
 	unsigned long long issued_ = 0;             /* bit-parallel path: slot ranges (by first slot) with a launch on record */
@@ -202,7 +203,7 @@ private:
 	int finish_layout();
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
-	bool bits_ = false, bits_allowed_ = false, bits_ckpt_ = false, bits_wide_ = false, want_scores_ = false;
+	bool bits_ = false, bits_allowed_ = false, bits_wide_ = false, want_scores_ = false;
 	int bits_maxstrips_ = 1, bits_chunk_ = kBitMaxStrips;
 	int run_slot(int sl, bool persistent);
 	std::vector<PairJob> pjobs_;

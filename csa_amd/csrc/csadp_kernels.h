@@ -28,21 +28,17 @@ hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int n
 
 /* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;
  * chars = nseq x length bytes, sequence-major; out must be zeroed. */
-/* csadp_bits.hip: bit-parallel first fills, one workgroup per job, and their traceback */
-hipError_t launch_fill_bits(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, bool checkpoints, int *abort_word,
-                            hipStream_t st);
-/* chunked form (checkpoint mode): one workgroup per work item = (job, chunk of `waves` strips; 4, 8 or 16); `work`
- * lists the items of ONE pass, `passes` consecutive passes (job tables of njobs entries each) share a launch;
- * epoch = a value no earlier launch on this memory has used (21 bits): it tags the hand-off words between chunks */
-hipError_t launch_fill_bits_wide(int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
+/* csadp_bits.hip: bit-parallel first fills and their traceback; words = 32-column words per lane (1, 2 or 4: BitJob::wpl
+ * of every job of the table).  One workgroup per job (at most 16 strips each) ... */
+hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int *abort_word, hipStream_t st);
+/* ... or chunked: one workgroup per work item = (job, chunk of `waves` strips; 4, 8 or 16); `work` lists the items of
+ * ONE pass, `passes` consecutive passes (job tables of njobs entries each) share a launch; epoch = a non-zero value
+ * no earlier launch on this memory has used: it tags the hand-off granules between chunks */
+hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
                                  uint32_t epoch, int *abort_word, hipStream_t st);
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
-hipError_t launch_traceback_bits(uint8_t *arena, const BitJob *jobs, int njobs, bool checkpoints, bool scores, hipStream_t st);
+hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, hipStream_t st);
 
-/* csadp_carry.hip: the same fill with the carries between lanes in scalar lane masks (checkpoint mode, one workgroup per job,
- * many-job launches) and the traceback that replays its checkpoints; same job table, its own layout inside `ckpt` and `hand` */
-hipError_t launch_fill_carry(uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int *abort_word, hipStream_t st);
-hipError_t launch_traceback_carry(uint8_t *arena, const BitJob *jobs, int njobs, bool scores, hipStream_t st);
 /* csadp_cells.hip: any fill as a persistent cell-per-lane wavefront; work = (job, chunk) items */
 /* epoch: a value no earlier launch on this memory has used (24 bits): it tags the hand-off granules between chunks */
 hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,

@@ -188,15 +188,15 @@ typedef struct csadp_timing {
 	int launch_passes;      /* passes carried by the launch that held the last run(): the   */
 	                        /* bit-parallel path merges consecutive run() calls into one     */
 	                        /* launch; fill_ms / traceback_ms / total_ms are that launch's    */
-	int bit_parallel;       /* 0 = tiled kernels, 1 = bit-parallel kernels (nw_fill_bits) with  */
-	                        /* direction planes in HBM, 2 = bit-parallel with checkpoints and    */
-	                        /* replay traceback (default), 3 = the same with the carries between */
-	                        /* lanes in scalar lane masks (csadp_carry.hip, CSADP_BITS_CARRY=1)  */
+	int bit_parallel;       /* 0 = 32-bit kernels, 2 = bit-parallel kernels (nw_fill_bits: lane   */
+	                        /* checkpoints, replay traceback)                                     */
 	int merge_group;        /* passes a full launch of this batch carries (bit-parallel path)     */
 	int recoveries;         /* passes repeated on the wait-free path after a bounded wait of the  */
 	                        /* chunked fill ran out (0 in any healthy run)                        */
 	int device_io;          /* 1 = a pass starts from the raw letters in HBM and ends with the    */
 	                        /* aligned rows in HBM (nw_pack_planes / nw_expand_rows in the pass)  */
+	int words_per_lane;     /* bit-parallel path: 32-column words a lane owns (1, 2 or 4)         */
+	int streams;            /* bit-parallel path: fill launches kept in flight                    */
 } csadp_timing;
 
 CSADP_API int csadp_pairs_timing(csadp_pairbatch *b, csadp_timing *t);

@@ -1,7 +1,7 @@
 """GPU tests (-m gpu) aimed at the bit-parallel kernels (csadp_bits.hip): word / strip / block
-boundaries of the 32-column lanes, the LDS hand-off between the strips of a workgroup, the
-checkpoint + replay traceback and the direction-plane traceback.  Expected strings come from the
-oracle (oracle/csa_dp_oracle.c) on the same inputs."""
+boundaries of the 32-column words, the hand-off between the strips of a workgroup (LDS) and between the
+chunks of a matrix (granules in HBM), the checkpoint + replay traceback -- with 1, 2 and 4 words per lane.
+Expected strings come from the oracle (oracle/csa_dp_oracle.c) on the same inputs."""
 import pytest
 
 import csa_amd
@@ -16,12 +16,11 @@ def device():
     yield
 
 
-# checkpoint mode (default) replays blocks during the traceback; "planes" keeps the direction
-# planes in HBM and walks them through the skewed LDS window
-@pytest.fixture(params=["checkpoints", "planes"])
+# words of 32 columns per lane: the engine picks 1 or 2 by the shape of the batch (layout_bits); every test below runs with
+# each of the three kernels
+@pytest.fixture(params=["1 word", "2 words", "4 words"])
 def bits_mode(request, monkeypatch):
-    if request.param == "planes":
-        monkeypatch.setenv("CSADP_BITS_CKPT", "0")
+    monkeypatch.setenv("CSADP_BITS_WORDS", request.param.split()[0])
     return request.param
 
 
@@ -191,12 +190,10 @@ def test_thousands_of_small_jobs_in_one_batch(bits_mode):
 
 
 @pytest.mark.parametrize("scores", [False, True])
-def test_scalar_carry_kernels_on_a_chip_filling_batch(monkeypatch, scores):
-    """CSADP_BITS_CARRY=1: launches that put two or more waves on every SIMD run csadp_carry.hip (carries between
-    lanes in scalar lane masks, replay of whole strip blocks).  700 pairs of 2-5 strips = ~2400 strips per launch;
-    every result by its properties, a sample of them (every strip count, the longest) against the oracle; with
-    `scores` the traceback also sums its path and every fetch cross-checks it."""
-    monkeypatch.setenv("CSADP_BITS_CARRY", "1")
+def test_chip_filling_batch_of_two_to_five_strip_jobs(bits_mode, monkeypatch, scores):
+    """700 pairs of 2-5 strips (at one word per lane) = ~2400 strips per launch, several waves on every SIMD; every
+    result by its properties, a sample of them (every strip count, the longest) against the oracle; with `scores` the
+    traceback also sums its path and every fetch cross-checks it."""
     if scores:
         monkeypatch.setenv("CSADP_FORCE_SCORES", "1")
     r = rng(1109)
@@ -221,7 +218,8 @@ def test_scalar_carry_kernels_on_a_chip_filling_batch(monkeypatch, scores):
     for _ in range(3):
         pb.run()
     pb.sync()
-    assert pb.timing()["bit_parallel"] == 3          # the scalar-carry kernels did run
+    tm = pb.timing()
+    assert tm["bit_parallel"] == 2 and tm["words_per_lane"] == int(bits_mode.split()[0])
     got = pb.fetch()
     pb.close()
     _properties(tasks, got)

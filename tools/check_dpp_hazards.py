@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The hand-scheduled steps of nw_fill_cells are inline assembly; the compiler's hazard recogniser does not
-look into it.  This checks the compiled ISA for the one rule they rely on: a VGPR written by a VALU
+"""The hand-scheduled steps of nw_fill_cells and the DPP instructions of nw_fill_bits / nw_traceback_replay are inline
+assembly; the compiler's hazard recogniser does not look into it.  This checks the compiled ISA for the one rule they rely on: a VGPR written by a VALU
 instruction is not read through DPP within the next two wait states (gfx9: 2).  Usage:
   hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only -o cells.s csadp_cells.hip; check_dpp_hazards.py cells.s"""
 import re
@@ -29,8 +29,9 @@ for ln in lines:
     parts = ln.replace(",", " ").split()
     op = parts[0]
     if op.endswith("_dpp") or "row_mask" in ln or "wave_shr" in ln or "row_shr" in ln or "quad_perm" in ln:
-        # DPP source = second operand (first source)
-        src = regs_of(parts[2]) if len(parts) > 2 else set()
+        # DPP source = the first source operand: after the destination, and after the carry-out of v_add_co / v_sub_co forms
+        ops = [p for p in parts[1:] if p != "vcc"]
+        src = regs_of(ops[1]) if len(ops) > 1 else set()
         dist = 0
         for wr, ws in reversed(window):
             if dist >= 2:
