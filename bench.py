@@ -17,7 +17,8 @@ torch.distributed.run.  No collective inside the timed region (independent tasks
 
 --mode strong: rank 0 owns the whole task list (config 4: 1024 pairs, config 5: 256 mixed-length
 pairs), partitions it by LPT (csadp_partition_lpt), broadcasts the assignment; every rank aligns
-its part; records are gathered and checked.  Prints ONE JSON line (rank 0).
+its part; records are all-gathered, the aligned rows gathered to rank 0, both checked.  --workload mammals: rank 0
+reads a real FASTA batch (config 3) and broadcasts it as a packed pool.  Prints ONE JSON line (rank 0).
 """
 import argparse
 import ctypes
@@ -39,25 +40,130 @@ HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # operations per second (a wave64 instruction issues in 2 cycles on a SIMD-32: MI355X_MICROARCH.md,
 # "Wave scheduling"; it is the FP32 vector peak of 157.3 TFLOP/s counted without the FMA's factor 2).
 VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-# VALU instructions of the compiled steady-state step of nw_fill_bits per 32 cells (one lane, one
-# row of 32 columns): `python tools/count_valu.py` on the shipped source -- 20 v_bitop3, 10 half-rate
-# (2 v_add3, 2 v_perm, 4 v_bfe, v_alignbit, the DPP move), 1 v_xor = 31; PMC cross-check: SQ_INSTS_VALU
-# per wave / steps = 32.9 including the per-block work (profiles/r02_pmc_summary.json).  The calibrated ceiling prices each instruction kind at the issue
-# cost measured alone on this chip (profiles/r01_valu_microbench.txt): v_bitop3 2.6, DPP /
-# three-operand 4.3, two-operand 2.1 cycles per wave64 and SIMD.
-BITS_STEP_MIX = {"v_bitop3": (20, 2.6), "dpp_or_three_operand": (10, 4.3), "two_operand": (1, 2.1)}
-BITS_VALU_PER_CELL = sum(n for n, _ in BITS_STEP_MIX.values()) / 32.0
-BITS_CYCLES_PER_64_CELLS = sum(n * c for n, c in BITS_STEP_MIX.values()) / 32.0
+# VALU instructions of the compiled steady-state step of nw_fill_bits per lane (32 cells per word), by words per lane:
+# `python tools/count_valu.py csadp_bits.hip nw_fill_bitsILi<W>E...` on the shipped source.  Half-rate on gfx950
+# (profiles/r01_valu_microbench.txt): everything that reads another lane (v_sub_co_u32_dpp x3, v_xor_b32_dpp x2) or moves a
+# carry (v_addc_co_u32: 3 per word + 3 accumulators).  The calibrated ceiling prices each kind at the issue cost measured
+# alone on this chip: v_bitop3 2.6, DPP / carry 4.3, two-operand 2.1 cycles per wave64 and SIMD.
+BITS_STEP_MIX = {
+    1: {"v_bitop3": (19, 2.6), "dpp_or_carry": (11, 4.3), "two_operand": (1, 2.1)},
+    2: {"v_bitop3": (36, 2.6), "dpp_or_carry": (14, 4.3), "two_operand": (2, 2.1)},
+    4: {"v_bitop3": (70, 2.6), "dpp_or_carry": (20, 4.3), "two_operand": (4, 2.1)},
+}
+
+
+def bits_valu_per_cell(w):
+    return sum(n for n, _ in BITS_STEP_MIX[w].values()) / (32.0 * w)
+
+
+def bits_cycles_per_64_cells(w):
+    return sum(n * c for n, c in BITS_STEP_MIX[w].values()) / (32.0 * w)
+
+
 ALG_BYTES_PER_CELL = 0.25             # the 2-bit direction of every cell
 
 
 def pmc_summary(kernel):
     """Per-launch PMC figures of `kernel` from this round's committed rocprofv3 passes, or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
             return json.load(f)[kernel]
     except Exception:
         return None
+
+
+def host_description():
+    """The box the CPU baseline runs on, and how oracle/_ref was built (oracle/Makefile writes build_info.json next to it)."""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    build = None
+    try:
+        with open(os.path.join(ROOT, "oracle", "_ref", "build_info.json")) as f:
+            build = json.load(f)
+    except Exception:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except Exception:
+        usable = None
+    return {"nproc": os.cpu_count(), "usable_cores": usable, "cpu_model": model, "reference_build": build}
+
+
+def reference_faithful_sample(csa_amd, seconds_budget=20.0):
+    """SURVEY 8(d)(i) / BASELINE.md section 3: the compiled reference, 1 thread, full int32 matrix + byte directions with one
+    malloc per row, on config 2 (Primates 0 x 1 with rotations 1947 / 1949) and the first 8 whole-sequence pairs of Mammals
+    (config 3) -- and the GPU's strings for the same tasks beside it."""
+    from helpers import GOLDEN, have_ref, load_golden, read_fasta, ref_progressive
+    if not have_ref():
+        return None
+    pipe = load_golden("pipeline.json")
+    tasks = []
+    names = []
+    _, prim = read_fasta(os.path.join(GOLDEN, "data", "Primates.txt"))
+    rp = pipe["Primates"]["rotations"]
+    tasks.append(([prim[0], prim[1]], [rp[0], rp[1]], None, None))
+    names.append("Primates 0x1")
+    _, mam = read_fasta(os.path.join(GOLDEN, "data", "Mammals.txt"))
+    rm = pipe["Mammals"]["rotations"]
+    pairs = [(a, b) for a in range(len(mam)) for b in range(a + 1, len(mam))][:8]
+    for a, b in pairs:
+        tasks.append(([mam[a], mam[b]], [rm[a], rm[b]], None, None))
+        names.append("Mammals %dx%d" % (a, b))
+    gpu = csa_amd.align_batch(tasks)
+    cells = 0
+    secs = 0.0
+    done = 0
+    same = 0
+    first = None
+    for t, g in zip(tasks, gpu):
+        rc, strs, dt = ref_progressive(t[0], t[1])
+        secs += dt
+        cells += len(t[0][0]) * len(t[0][1])
+        done += 1
+        same += 1 if strs == g["aligned"] else 0
+        if first is None:
+            first = {"pair": names[0], "cells": cells, "seconds": round(dt, 3), "gcups": round(cells / dt / 1e9, 4),
+                     "consensus": g["consensus"], "score": g["score"]}
+        if secs > seconds_budget:
+            break
+    return {"value": round(cells / secs / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "reference",
+            "sample": "config 2 (%s, rotations %d/%d) + the first %d whole-sequence Mammals pairs with the reference's rotations: %d tasks, "
+                      "%.1f s inside ProgressiveDP; GPU strings identical for %d of %d" % (names[0], rp[0], rp[1], done - 1, done, secs, same, done),
+            "config2": first}
+
+
+def one_shot_leg(csa_amd, tasks):
+    """ONE pass of the step's batch on an idle chip, create -> fetch: what a caller with a single batch of this size gets (the
+    timed region keeps several passes in flight and re-uses the resident letters)."""
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pb = csa_amd.PairBatch(tasks)
+        t1 = time.perf_counter()
+        pb.run()
+        pb.sync()
+        t2 = time.perf_counter()
+        tm = pb.timing()
+        res = pb.fetch()
+        t3 = time.perf_counter()
+        pb.close()
+        ok = all(r["status"] == 0 for r in res)
+        cur = {"device_ms": round(tm["total_ms"], 3), "fill_ms": round(tm["fill_ms"], 3), "traceback_expand_ms": round(tm["traceback_ms"], 3),
+               "create_ms": round((t1 - t0) * 1e3, 2), "run_and_wait_ms": round((t2 - t1) * 1e3, 2), "fetch_ms": round((t3 - t2) * 1e3, 2),
+               "gcups_device": round(tm["cells"] / tm["total_ms"] / 1e6, 1), "gcups_create_to_fetch": round(tm["cells"] / (t3 - t0) / 1e9, 1),
+               "words_per_lane": tm["words_per_lane"], "ok": ok}
+        if best is None or cur["device_ms"] < best["device_ms"]:
+            best = cur
+    best["what"] = ("one pass of the same %d pairs with nothing else on the chip (best of 3): device_ms = HIP events around pack + fill + "
+                    "traceback + expand; create_to_fetch = host letters to host strings, Python unpacking included" % len(tasks))
+    return best
 
 
 def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
@@ -223,7 +329,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
     ap.add_argument("--len", type=int, default=16384, dest="length")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--workload", default="config4", choices=["config4", "config5"])
+    ap.add_argument("--workload", default="config4", choices=["config4", "config5", "mammals"],
+                    help="--mode strong: which list rank 0 owns; mammals = config 3, all 66 whole-sequence pairs of "
+                         "tests/golden/data/Mammals.txt with the reference's rotations: rank 0 reads the FASTA and broadcasts the pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the streaming and profile-path legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -274,7 +382,22 @@ def main():
             args.pairs, args.length, args.pairs)
     else:
         # rank 0 owns the list; cost = DP cells from the nominal lengths; LPT + broadcast
-        if args.workload == "config4":
+        pair_of = None
+        if args.workload == "mammals":
+            # config 3: rank 0 owns the FASTA batch; every other rank receives the letters and rotations as one packed pool
+            seqs = rots = None
+            if rank == 0:
+                from helpers import GOLDEN, load_golden, read_fasta
+                _, seqs = read_fasta(os.path.join(GOLDEN, "data", "Mammals.txt"))
+                rots = load_golden("pipeline.json")["Mammals"]["rotations"]
+            pool, prot = group.broadcast_pool(seqs, rots)
+            pair_of = [(a, b) for a in range(len(pool)) for b in range(a + 1, len(pool))]
+            lens = [(len(pool[a]), len(pool[b])) for a, b in pair_of]
+
+            def make(p):
+                a, b = pair_of[p]
+                return pool[a], pool[b], prot[a], prot[b]
+        elif args.workload == "config4":
             lens = [(args.length, args.length)] * 1024
 
             def make(p):
@@ -321,9 +444,13 @@ def main():
     fetch_s = time.perf_counter() - t_f0
     ok = all(r["status"] == 0 for r in results)
 
-    # the multi-GPU data path: every rank's 16-byte records (task id, score, consensus, FNV-1a) all-gathered
+    # the multi-GPU data path: every rank's 16-byte records (task id, score, consensus, FNV-1a) all-gathered, and the aligned
+    # rows themselves -- what the reference's consumer prints (alignment.c:134-156) -- gathered to rank 0
     recs = group.all_gather_records([(t, r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])) for t, r in zip(ids, results)])
     by_id = {r[0]: (r[1], r[2], cdist.u32(r[3])) for r in recs}
+    t_g0 = time.perf_counter()
+    rows_by_id = group.gather_rows(ids, [r["aligned"] for r in results])
+    gather_s = time.perf_counter() - t_g0
 
     value = cells_step * args.steps / elapsed / 1e9
     line = None
@@ -336,7 +463,16 @@ def main():
         # gathered records: complete, and the ones the compiled reference has digests for agree with it
         expect = args.pairs * world if args.mode == "weak" else len(part)
         ok = ok and len(by_id) == expect
+        # every task's rows have arrived on rank 0 and are the rows their record was computed from
+        rows_ok = len(rows_by_id) == expect and all(csa_amd.fnv1a(rows_by_id[t]) == by_id[t][2] for t in by_id)
+        ok = ok and rows_ok
         checked = 0
+        if args.mode == "strong" and args.workload == "mammals":
+            gold = {(c["a"], c["b"]): c for c in load_golden("real_pairs.json") if c["set"] == "Mammals"}
+            for t, (a, b) in enumerate(pair_of):
+                g = gold[(a, b)]
+                ok = ok and by_id[t] == (g["sp"], g["consensus"], int(g["fnv1a"], 16))
+                checked += 1
         if args.workload == "config4" and args.length == 16384:
             for g in load_golden("config4_pairs.json"):
                 if g["pair"] in by_id:
@@ -347,16 +483,19 @@ def main():
         rank_cells = tm["cells"]
         launch_cells = lp * rank_cells
         fill_s = tm["fill_ms"] * 1e-3
-        alone_tops = BITS_VALU_PER_CELL * launch_cells / fill_s / 1e12               # lane operations per second
-        sustained_tops = BITS_VALU_PER_CELL * rank_cells * args.steps / elapsed / 1e12
-        calibrated_peak_gcups = 256 * 4 * 64 / BITS_CYCLES_PER_64_CELLS * 2.4
+        wpl = tm["words_per_lane"] if tm["words_per_lane"] in BITS_STEP_MIX else 1
+        valu_per_cell = bits_valu_per_cell(wpl)
+        alone_tops = valu_per_cell * launch_cells / fill_s / 1e12               # lane operations per second
+        sustained_tops = valu_per_cell * rank_cells * args.steps / elapsed / 1e12
+        calibrated_peak_gcups = 256 * 4 * 64 / bits_cycles_per_64_cells(wpl) * 2.4
         pmc = pmc_summary("nw_fill_bits")
         traffic = None
         if pmc and pmc.get("launch_shape") == {"jobs": lp * len(tasks), "len": args.length}:
             traffic = int(pmc["hbm_write_bytes_per_launch"] + pmc["hbm_read_bytes_per_launch_x2_corrected"])
         line = {
             "metric": "DP cells/sec (GCUPS) on %s, letters in HBM -> aligned rows in HBM, whole job" % (
-                "1-200 kbp mixed-length pairs (config 5)" if args.workload == "config5" and args.mode == "strong" else "16 kbp x 16 kbp pairs"),
+                "1-200 kbp mixed-length pairs (config 5)" if args.workload == "config5" and args.mode == "strong" else
+                "the 66 whole-sequence Mammals pairs (config 3)" if args.workload == "mammals" and args.mode == "strong" else "16 kbp x 16 kbp pairs"),
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,
@@ -366,12 +505,14 @@ def main():
             "config": {"workload": workload + "; linear-gap NW: pack + fill + traceback + row expansion on the device, "
                                               "bit-exact vs the reference",
                        "pairs_this_rank": len(tasks), "seq_len": "1000..200000" if args.workload == "config5" and args.mode == "strong" else args.length,
-                       "kernel": "nw_fill_bits",
+                       "kernel": "nw_fill_bits", "words_per_lane": tm["words_per_lane"], "launches_in_flight": tm_pipe["streams"],
                        "passes_per_launch": max(tm_pipe["launch_passes"], 1), "device_io": tm["device_io"],
                        "parallelism": "independent tasks over %d GPU(s); no collective in the timed region; result records "
                                       "all-gathered over %s afterwards" % (args.gpus, "RCCL" if args.backend == "nccl" else "gloo"),
                        "lpt_imbalance": round(imbalance, 4)},
-            "records": {"gathered": len(by_id), "checked_against_reference_digests": checked},
+            "records": {"gathered": len(by_id), "checked_against_reference_digests": checked,
+                        "rows_on_rank0": len(rows_by_id), "rows_match_their_records": bool(rows_ok),
+                        "rows_bytes": sum(len(x) for v in rows_by_id.values() for x in v), "rows_gather_ms": round(gather_s * 1e3, 2)},
             "kernel_ms": {"fill_launch_alone": round(tm["fill_ms"], 3),
                           "traceback_and_expand_alone": round(tm["traceback_ms"], 3),
                           "passes_in_that_launch": lp,
@@ -386,28 +527,31 @@ def main():
                          "achieved": round(sustained_tops, 2), "peak": round(VALU_PEAK_TOPS, 2), "unit": "TOP/s",
                          "frac": round(sustained_tops / VALU_PEAK_TOPS, 4),
                          "traffic": traffic,
-                         "what": "integer VALU lane-operations per second of the fill kernel over the timed region: %.0f wave64 "
-                                 "VALU instructions per 2048 cells (ISA count of the compiled step; PMC SQ_INSTS_VALU agrees "
-                                 "within 3 %%) x cells of all timed passes / wall time -- launches of `passes_per_launch` passes "
-                                 "rotate over three streams, so the kernel is in flight during the whole region and its "
-                                 "launches overlap; peak = 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (nominal 2 issue "
-                                 "cycles per wave64 instruction, MI355X_MICROARCH.md)" % (BITS_VALU_PER_CELL * 32),
+                         "what": "integer VALU lane-operations per second of the fill kernel over the timed region: %d wave64 "
+                                 "VALU instructions per lane-step of %d cells (ISA count of the compiled step, %d words per lane: "
+                                 "tools/count_valu.py) x cells of all timed passes / wall time -- %d launches of `passes_per_launch` "
+                                 "passes are in flight on as many streams, each launch's traceback on a side stream, so the kernel runs "
+                                 "during the whole region; peak = 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz (nominal 2 issue cycles "
+                                 "per wave64 instruction, MI355X_MICROARCH.md).  Round 3 lowered the instructions per cell (0.97 -> %.2f) "
+                                 "as well as the time: `value` is the figure to compare across rounds" % (
+                                     round(valu_per_cell * 32 * wpl), 32 * wpl, wpl, tm_pipe["streams"], valu_per_cell),
+                         "valu_per_cell": round(valu_per_cell, 4), "words_per_lane": wpl,
                          "one_launch_alone": {"cells": launch_cells, "avg_launch_us": round(tm["fill_ms"] * 1e3, 1),
                                               "achieved": round(alone_tops, 2), "frac": round(alone_tops / VALU_PEAK_TOPS, 4),
                                               "what": "HIP events around ONE launch with nothing else in flight (one workgroup "
-                                                      "per compute unit = two waves per SIMD; the timed region keeps three "
-                                                      "such launches in flight); rocprofv3: profiles/r02_bench_kernel_solo.csv"},
+                                                      "per compute unit; the timed region keeps two such launches in "
+                                                      "flight); rocprofv3: profiles/r03_bench_kernel_solo.csv"},
                          "calibrated": {"peak_gcups": round(calibrated_peak_gcups, 1),
                                         "frac_alone": round(launch_cells / fill_s / 1e9 / calibrated_peak_gcups, 4),
                                         "frac_sustained": round(value / args.gpus / calibrated_peak_gcups, 4),
                                         "what": "ceiling with every instruction kind at the issue cost measured alone on this "
-                                                "chip (profiles/r01_valu_microbench.txt): %.1f cycles per 64 cells" % BITS_CYCLES_PER_64_CELLS}},
+                                                "chip (profiles/r01_valu_microbench.txt): %.1f cycles per 64 cells" % bits_cycles_per_64_cells(wpl)}},
             "roofline_hbm": {"bound": "hbm", "achieved": round(lp * impl_bytes / fill_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": round(lp * impl_bytes / fill_s / 1e9 / HBM_PEAK_GBS, 4),
                              "bytes_per_launch": int(lp * impl_bytes),
                              "algorithmic_bytes_per_launch": int(ALG_BYTES_PER_CELL * launch_cells),
-                             "what": "bytes the fill actually writes (lane-state checkpoints + hand-off marks; no direction "
-                                     "planes in checkpoint mode) / launch duration.  SURVEY 8(d)'s algorithmic 0.25 B/cell is "
+                             "what": "bytes the fill actually writes (per lane and block of 32 steps: its planes + the carries it put "
+                                     "out; no direction planes) / launch duration.  SURVEY 8(d)'s algorithmic 0.25 B/cell is "
                                      "listed for reference only: the kernel does not move those bytes, so it is not priced "
                                      "against HBM"},
         }
@@ -418,11 +562,15 @@ def main():
             line["streaming"] = streaming_leg(csa_amd, big, batches=8)
             line["streaming"]["pairs_per_batch"] = len(big)
             line["streaming"]["vs_value"] = round(line["streaming"]["gcups"] / (value / args.gpus), 3)
+            line["one_shot"] = one_shot_leg(csa_amd, tasks)
+            line["one_shot"]["vs_value"] = round(line["one_shot"]["gcups_device"] / (value / args.gpus), 3)
             line["profile_path"] = profile_path_leg(csa_amd)
             line["single_matrix"] = single_matrix_leg(csa_amd)
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)
             line["cpu_baseline"]["many_cores"] = many_cores
+            line["cpu_baseline"]["host"] = host_description()
+            line["cpu_baseline"]["reference_faithful"] = reference_faithful_sample(csa_amd)
     batch.close()
     group.barrier()
     group.close()

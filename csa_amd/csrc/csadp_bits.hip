@@ -177,7 +177,7 @@ enum : int { OUT_NONE = 0, OUT_TILE = 1 };
  * rows for all others), read PF steps ahead.  RAMPIN: lanes whose row index is still negative keep an empty
  * row above.  OUT_NONE (fill): ACC is on, nothing is stored.  OUT_TILE (replay): the wave is four independent
  * pieces of 16 lanes (DPP stays inside a row), `out` = this lane's slot in step 0 of its piece's LDS tile
- * [32][16 W + 1] of (not-diagonal, left) masks, `outm` the same in the tile of match masks (MATCHES).
+ * [32 steps][W words][16 lanes] (+ 1 per step) of (not-diagonal, left) masks, `outm` the same in the tile of match masks (MATCHES).
  */
 template <int W, bool RAMPIN, int OUT, bool MATCHES, int PF>
 __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K, const uint32_t *ip, uint2 *out, uint32_t *outm, int l0, int lane)
@@ -250,8 +250,8 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K
 			if (OUT == OUT_TILE) {
 				const uint32_t notdiag = C0 & nE[h];
 				const uint32_t left = notdiag & nT0;
-				out[t * pitch + h] = make_uint2(notdiag, left);
-				if (MATCHES) outm[t * pitch + h] = ~nE[h];        /* match mask: the walk scores its path */
+				out[t * pitch + h * 16] = make_uint2(notdiag, left);
+				if (MATCHES) outm[t * pitch + h * 16] = ~nE[h];   /* match mask: the walk scores its path */
 			}
 			if (RAMPIN) {
 				nT0 |= ~live;
@@ -343,10 +343,17 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 #else
 	constexpr bool TIGHT = !WORK || LONE;
 #endif
-	constexpr int PF = LONE ? 3 : 1;
+#ifndef CSADP_PF_MANY
+#define CSADP_PF_MANY 1
+#endif
+#ifndef CSADP_LONE_PF
+#define CSADP_LONE_PF 3
+#endif
+	constexpr int PF = LONE ? CSADP_LONE_PF : CSADP_PF_MANY;
 	__shared__ __attribute__((aligned(16))) uint32_t ring[WAVES][kRing][4];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[WAVES][kBitBlock * kInjWords];
-	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords];
+	/* 4 words further than a multiple of the 64 banks from the inject rows: the first lane's 16 bytes and everybody else's never share a bank */
+	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];
 	__shared__ int made[WAVES], taken[WAVES];
 	int chunk = 0;
 	const BitJob *jp;
@@ -364,7 +371,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 		made[threadIdx.x] = 0;
 		taken[threadIdx.x] = 0;
 	}
-	for (int i = threadIdx.x; i < kBitBlock * kInjWords; i += blockDim.x) konst[i] = kNoCarry;
+	for (int i = threadIdx.x; i < kBitBlock * kInjWords + 4; i += blockDim.x) konst[i] = kNoCarry;
 	__syncthreads();
 	if (s >= J.nstrips) return;
 
@@ -402,7 +409,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 
 	BitState<W> S;
 	fresh_state<W>(S);
-	const uint32_t *ip = lane == 0 ? &inject[wv][0] : &konst[0];
+	const uint32_t *ip = lane == 0 ? &inject[wv][0] : &konst[4];
 	/* the constants are waited for HERE: left to the compiler the wait sits at their first use inside the block loop, where
 	 * it is s_waitcnt vmcnt(0) -- and drains the checkpoint stores of the block before, every block */
 	asm volatile("" : "+v"(K.D0), "+v"(K.D1));
@@ -529,7 +536,7 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 	__shared__ __attribute__((aligned(16))) uint2 tile[NP][kBitBlock * pitch];
 	__shared__ uint32_t mtile[SCORE ? NP : 1][SCORE ? kBitBlock * pitch : 1];    /* match masks of the same cells */
 	__shared__ __attribute__((aligned(16))) uint32_t inject[NP][kBitBlock * kInjWords];
-	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords];
+	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];   /* 4 words off the banks of the inject rows */
 	__shared__ int pos[4];
 
 	const BitJob &J = jobs[blockIdx.x];
@@ -544,7 +551,7 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 	int r = J.nrows, k = J.ncols;
 	int n = 0;
 	int score = 0;                                             /* sum of the move scores along the path (:993-998 for i = 1) */
-	for (int i = threadIdx.x; i < kBitBlock * kInjWords; i += blockDim.x) konst[i] = kNoCarry;
+	for (int i = threadIdx.x; i < kBitBlock * kInjWords + 4; i += blockDim.x) konst[i] = kNoCarry;
 	__syncthreads();
 
 	/* the three accumulators lane `l` of strip `st` saved after block `blk` (0 outside the matrix' blocks) */
@@ -634,9 +641,9 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 				    make_uint4(bf0 ^ row_mask(0, row), bf1 ^ row_mask(1, row), carry_bit(older[0], newer[0], t), carry_bit(older[1], newer[1], t));
 				inject[d][t * kInjWords + INJ_Z0] = carry_bit(older[2], newer[2], t);
 			}
-			const uint32_t *ip = j == 0 ? &inject[d][0] : &konst[0];
-			uint2 *out = &tile[d][j * W];
-			uint32_t *outm = &mtile[SCORE ? d : 0][SCORE ? j * W : 0];
+			const uint32_t *ip = j == 0 ? &inject[d][0] : &konst[4];
+			uint2 *out = &tile[d][j];                          /* a step's row of a tile: [word][lane], so the 16 lanes of a store are contiguous */
+			uint32_t *outm = &mtile[SCORE ? d : 0][SCORE ? j : 0];
 			const bool ramp = btop - 4 * wv - 3 < 2;           /* wave-uniform: some piece of this wave is in block 0 or 1 */
 			if (ramp) bits_block<W, true, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
 			else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
@@ -657,7 +664,7 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 					if ((wi >> 6) == s && d >= 0 && d < NP) {
 						const int rel = sl - piece_first_lane<W>(k0, l0, s, d);
 						if (rel >= 0 && rel < 16) {
-							const int at = (l % kBitBlock) * pitch + rel * W + ((kc >> 5) & (W - 1));
+							const int at = (l % kBitBlock) * pitch + ((kc >> 5) & (W - 1)) * 16 + rel;
 							const uint2 dd = tile[d][at];
 							const uint32_t bit = 1u << (kc & 31);
 							code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
@@ -711,14 +718,24 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 /* function attributes are per device: called by Engine::init with that device current */
 hipError_t configure_kernels() { return hipSuccess; }
 
+/* static LDS of a fill workgroup of `waves` strips / of a traceback workgroup (without match masks), for the engine's
+ * choice of how much dynamic LDS a fill launch reserves on top */
+int fill_bits_lds_bytes(int waves) { return waves * (kRing * 16 + kBitBlock * kInjWords * 4 + 8) + (kBitBlock * kInjWords + 4) * 4; }
+int traceback_bits_lds_bytes(int words)
+{
+	const int np = words == 1 ? kReplayPieces1 : words == 2 ? kReplayPieces2 : kReplayPieces4;
+	return np * (kBitBlock * (16 * words + 1) * 8 + kBitBlock * kInjWords * 4) + (kBitBlock * kInjWords + 4) * 4 + 16;
+}
+
 namespace {
 
 template <int W, int WAVES>
 hipError_t launch_fill_w(bool chunked, uint8_t *arena, const BitJob *jobs, int njobs, int passes, int threads, const TileRef *work, int nwork,
                          uint32_t epoch, int *abort_word, hipStream_t st)
 {
+	/* chunked: `passes` doubles as nothing else; one workgroup per job: `passes` carries the dynamic LDS to reserve */
 	if (chunked) hipLaunchKernelGGL((nw_fill_bits<W, WAVES, true>), dim3(nwork, passes), dim3(WAVES * kLanes), 0, st, arena, jobs, njobs, work, epoch, abort_word);
-	else hipLaunchKernelGGL((nw_fill_bits<W, WAVES, false>), dim3(njobs), dim3(threads), 0, st, arena, jobs, njobs, work, epoch, abort_word);
+	else hipLaunchKernelGGL((nw_fill_bits<W, WAVES, false>), dim3(njobs), dim3(threads), passes, st, arena, jobs, njobs, work, epoch, abort_word);
 	return hipGetLastError();
 }
 
@@ -743,12 +760,12 @@ hipError_t launch_fill_any(int words, int waves, bool chunked, uint8_t *arena, c
 
 }  // namespace
 
-hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int *abort_word, hipStream_t st)
+hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	if (maxstrips < 1 || maxstrips > kBitMaxStrips) return hipErrorInvalidValue;
+	if (maxstrips < 1 || maxstrips > kBitMaxStrips || lds_pad < 0 || lds_pad > 60 * 1024) return hipErrorInvalidValue;
 	const int waves = maxstrips <= 4 ? 4 : maxstrips <= 8 ? 8 : 16;
-	return launch_fill_any(words, waves, false, arena, jobs, njobs, 1, maxstrips * kLanes, nullptr, 0, 0u, abort_word, st);
+	return launch_fill_any(words, waves, false, arena, jobs, njobs, lds_pad, maxstrips * kLanes, nullptr, 0, 0u, abort_word, st);
 }
 
 hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,

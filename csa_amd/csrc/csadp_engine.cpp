@@ -813,15 +813,20 @@ int FillBatch::layout_bits()
 	bits_wide_ = false;
 	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
 	test_abort_ = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;        /* testing: read once per layout, not per launch */
+	bits_lds_pad_ = -1;                                             /* chosen below, once the launch shape is known */
 	/* Words of 32 columns per lane (1, 2 or 4).  More words per lane amortise what a step spends on its neighbours (the three
 	 * borrow instructions, the letter chain, the accumulators: 11 of W = 1's 31 instructions, 11 of W = 2's 53) and halve the
 	 * strips -- and with them the waves -- of a matrix.  DESIGN.md section 3 has the measurements behind the default. */
-	long long total_words = 0;
-	for (const FillJob &J : jobs_) total_words += (J.ncols + 31) / 32;
 	{
+		/* two words per lane when that still puts two waves on every SIMD: strips of 64 lanes x 2 words, times the passes a
+		 * pipelined batch keeps in flight (2 launches of up to 4 passes, chosen below by the same rule).  Batches smaller than
+		 * that -- down to one matrix -- are bound by the latency of a step: one word per lane, twice the strips. */
+		long long strips2 = 0;
+		for (const FillJob &J : jobs_) strips2 += ((J.ncols + 31) / 32 + 127) / 128;
 		const long long simds = 4LL * std::max(E.compute_units(), 1);
-		/* one pass of the batch as strips of 64 lanes x 2 words: enough of them for two waves on every SIMD? */
-		int w = (total_words / 128 >= 2 * simds || pipelined_) ? 2 : 1;
+		const int group2 = pipelined_ ? std::max(1, std::min((std::max(E.compute_units(), 1) + nj - 1) / nj, 4)) : 1;
+		const long long in_flight = strips2 * (pipelined_ ? 2 * group2 : 1);
+		int w = in_flight >= 2 * simds ? 2 : 1;
 		w = env_int("CSADP_BITS_WORDS", w);
 		bits_words_ = (w == 2 || w == 4) ? w : 1;
 	}
@@ -859,11 +864,12 @@ int FillBatch::layout_bits()
 	if (pipelined_) {
 		long long strips = 0;
 		for (const BitJob &B : bjobs_) strips += B.nstrips;
-		const long long simds = 4LL * std::max(E.compute_units(), 1);
 		const int dflt_streams = 2;
-		/* passes per launch so that `dflt_streams` launches put about four waves on every SIMD */
-		long long g = strips > 0 ? (4 * simds / dflt_streams + strips - 1) / strips : 1;
-		bits_group_ = (int)std::max(1LL, std::min(g, 4LL));
+		/* passes per launch: one workgroup per compute unit (tools/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
+		 * per lane 2 streams x 2 passes = two waves per SIMD runs 44 TCUPS, 4 x 2 39-43, 2 x 4 37-40: more workgroups than compute
+		 * units per launch are not spread evenly over them) */
+		const int want = std::max(E.compute_units(), 1);
+		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
 		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
 		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", dflt_streams), E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
@@ -890,6 +896,20 @@ int FillBatch::layout_bits()
 	for (const BitJob &B : bjobs_)
 		if (B.nstrips > bits_chunk_) bits_wide_ = true;
 	if (!bits_wide_) bits_chunk_ = kBitMaxStrips;
+	/* Pipelined launches of one workgroup per job: the dispatcher hands a compute unit as many workgroups as fit, not one of each
+	 * launch in flight -- three fills on one unit and one on the next run at the pace of the fuller one.  Every fill workgroup
+	 * reserves dynamic LDS so that exactly two of them fit next to one traceback workgroup (tools/sweep_pad.sh,
+	 * profiles/r03_sweep_pad.txt: +2-4 %, and a collapse of 25 % as soon as two fills and a traceback no longer fit). */
+	bits_lds_pad_ = 0;
+	if (pipelined_ && !bits_wide_) {
+		const int waves = bits_maxstrips_ <= 4 ? 4 : bits_maxstrips_ <= 8 ? 8 : 16;
+		const int room = (160 * 1024 - traceback_bits_lds_bytes(bits_words_)) / 2 - fill_bits_lds_bytes(waves) - 2048;
+		bits_lds_pad_ = std::max(0, std::min(room, 60 * 1024)) & ~255;
+	}
+	{
+		const int forced = env_int("CSADP_BITS_LDS_PAD", -1);
+		if (forced >= 0) bits_lds_pad_ = std::min(forced, 60) * 1024;
+	}
 	next_slot_ = 0;
 	size_t off = 0;
 	for (int sl = 0; sl < nslots_; ++sl) {
@@ -1245,7 +1265,7 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 		}
 	} else {
-		HIP_TRY(launch_fill_bits(bits_words_, arena_, bj, g * nj, bits_maxstrips_, abort_word, st));
+		HIP_TRY(launch_fill_bits(bits_words_, arena_, bj, g * nj, bits_maxstrips_, bits_lds_pad_, abort_word, st));
 	}
 	if (!serial && bits_wide_ && test_abort_)             /* testing: see run_slot_cells */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));

@@ -30,12 +30,14 @@ hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int n
  * chars = nseq x length bytes, sequence-major; out must be zeroed. */
 /* csadp_bits.hip: bit-parallel first fills and their traceback; words = 32-column words per lane (1, 2 or 4: BitJob::wpl
  * of every job of the table).  One workgroup per job (at most 16 strips each) ... */
-hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int *abort_word, hipStream_t st);
+hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st);
 /* ... or chunked: one workgroup per work item = (job, chunk of `waves` strips; 4, 8 or 16); `work` lists the items of
  * ONE pass, `passes` consecutive passes (job tables of njobs entries each) share a launch; epoch = a non-zero value
  * no earlier launch on this memory has used: it tags the hand-off granules between chunks */
 hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
                                  uint32_t epoch, int *abort_word, hipStream_t st);
+int fill_bits_lds_bytes(int waves);          /* static LDS of a fill workgroup */
+int traceback_bits_lds_bytes(int words);    /* ... of a traceback workgroup */
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
 hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, hipStream_t st);
 

@@ -1,10 +1,13 @@
 """One-process-per-GPU plumbing for bench.py and the multi-rank tests.
 
 The DP hot path shards by independent tasks: no collective inside a matrix.  The
-work split is: rank 0 owns the task list, partitions it by longest-processing-time-first over
-the task costs (csadp_partition_lpt) and BROADCASTS the assignment; every rank aligns its part;
-fixed 16-byte result records (task id, DP score, consensus, FNV-1a of the two rows) are
-ALL-GATHERED, so every rank -- rank 0 in particular -- holds the whole batch's outcome.
+work split is: rank 0 owns the task list -- and, for real inputs, the sequences: it BROADCASTS them
+as one packed pool (broadcast_pool) --, partitions the list by longest-processing-time-first over the
+task costs (csadp_partition_lpt) and BROADCASTS the assignment; every rank aligns its part; fixed
+16-byte result records (task id, DP score, consensus, FNV-1a of the two rows) are ALL-GATHERED, so
+every rank holds the whole batch's outcome; and the aligned ROWS -- what the reference's consumer
+prints (alignment.c:134-156, segment->alignedstrings of dynamicprogramming.c:1160) -- are GATHERED
+to rank 0 as one padded byte buffer per rank (gather_rows).
 torch.distributed: backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests.  Also the
 barriers around the timed region and the max/sum reductions of the timing scalars."""
 import os
@@ -115,6 +118,82 @@ class Group:
         return res
 
 
+    def broadcast_bytes(self, data):
+        """Rank 0's bytes object on every rank: its length first, then the payload (two broadcasts)."""
+        if self._dist is None:
+            return bytes(data)
+        import torch
+        n = self.broadcast_ints([len(data) if self.rank == 0 else 0], 1)[0]
+        if self.rank == 0:
+            t = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(self._dev())
+        else:
+            t = torch.empty(n, dtype=torch.uint8, device=self._dev())
+        if n:
+            self._dist.broadcast(t, src=0)
+        return t.cpu().numpy().tobytes()
+
+    def broadcast_pool(self, seqs, rotations=None):
+        """The packed sequence pool of SURVEY 8(e): rank 0's sequences (bytes) and rotations on every rank.
+        Layout: int32 count, count x int32 length, count x int32 rotation, then the letters back to back."""
+        import struct
+        blob = b""
+        if self.rank == 0:
+            rotations = list(rotations) if rotations is not None else [0] * len(seqs)
+            blob = struct.pack("<i", len(seqs)) + struct.pack("<%di" % len(seqs), *[len(x) for x in seqs]) + \
+                struct.pack("<%di" % len(seqs), *rotations) + b"".join(seqs)
+        blob = self.broadcast_bytes(blob)
+        (n,) = struct.unpack_from("<i", blob, 0)
+        lens = struct.unpack_from("<%di" % n, blob, 4)
+        rots = list(struct.unpack_from("<%di" % n, blob, 4 + 4 * n))
+        out, off = [], 4 + 8 * n
+        for ln in lens:
+            out.append(blob[off:off + ln])
+            off += ln
+        return out, rots
+
+    def gather_rows(self, ids, rows):
+        """The aligned rows of this rank's tasks to rank 0: ids[i] is the global task id of rows[i] (a list of equal-length byte
+        strings, one per sequence of the task).  Every rank packs [id, nseq, length, rows...] records into one byte buffer,
+        padded to the longest buffer of any rank (one max-reduce), and ONE gather brings them to rank 0.  Returns
+        {task id: [rows]} on rank 0 (complete), {} elsewhere."""
+        import struct
+        mine = bytearray()
+        for t, rs in zip(ids, rows):
+            mine += struct.pack("<iii", int(t), len(rs), len(rs[0]) if rs else 0)
+            for r in rs:
+                mine += r
+        if self._dist is None:
+            return _unpack_rows(bytes(mine))
+        import torch
+        most = int(self.max(len(mine)))
+        buf = torch.zeros(most + 8, dtype=torch.uint8)
+        buf[:8] = torch.frombuffer(bytearray(struct.pack("<q", len(mine))), dtype=torch.uint8)
+        if mine:
+            buf[8:8 + len(mine)] = torch.frombuffer(mine, dtype=torch.uint8)
+        buf = buf.to(self._dev())
+        dst = [torch.empty_like(buf) for _ in range(self.world)] if self.rank == 0 else None
+        self._dist.gather(buf, dst, dst=0)
+        if self.rank != 0:
+            return {}
+        out = {}
+        for t in dst:
+            raw = t.cpu().numpy().tobytes()
+            (n,) = struct.unpack_from("<q", raw, 0)
+            out.update(_unpack_rows(raw[8:8 + n]))
+        return out
+
+
+def _unpack_rows(raw):
+    import struct
+    out, off = {}, 0
+    while off < len(raw):
+        t, nseq, ln = struct.unpack_from("<iii", raw, off)
+        off += 12
+        out[t] = [raw[off + i * ln:off + (i + 1) * ln] for i in range(nseq)]
+        off += nseq * ln
+    return out
+
+
 def _i32(v):
     v &= 0xFFFFFFFF
     return v - (1 << 32) if v >= (1 << 31) else v
@@ -137,19 +216,21 @@ def lpt_assignment(group, costs):
 
 def run_sharded(group, costs, align_mine):
     """The multi-GPU flow of one batch: LPT -> per-rank task lists -> align -> gather.
-    align_mine(ids) aligns the global task ids this rank owns and returns one
-    (score, consensus, fnv1a) per id.  Returns (records by task id, this rank's ids, imbalance)."""
+    align_mine(ids) aligns the global task ids this rank owns and returns one (score, consensus, fnv1a, rows) per id
+    (rows = the aligned strings of the task).  Returns (records by task id -- on every rank --, this rank's ids, imbalance,
+    rows by task id -- complete on rank 0, empty elsewhere)."""
     part = lpt_assignment(group, costs)
     mine = [t for t, p in enumerate(part) if p == group.rank]
     got = align_mine(mine)
-    recs = group.all_gather_records([(t, sc, cons, dig) for t, (sc, cons, dig) in zip(mine, got)])
+    recs = group.all_gather_records([(t, g[0], g[1], g[2]) for t, g in zip(mine, got)])
     by_id = {r[0]: (r[1], r[2], u32(r[3])) for r in recs}
+    rows = group.gather_rows(mine, [g[3] for g in got])
     load = [0] * group.world
     for t, p in enumerate(part):
         load[p] += int(costs[t])
     total = sum(load)
     imbalance = max(load) * group.world / total if total else 1.0
-    return by_id, mine, imbalance
+    return by_id, mine, imbalance, rows
 
 
 def spawn_ranks(script, argv, world):
@@ -167,9 +248,21 @@ def spawn_ranks(script, argv, world):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll: when one rank dies (no device, an import error), the others would sit in init_process_group or a barrier until the
+    # collective's time-out -- end them (they are this process' own fresh children) and report the first failure
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = 128 - code if code < 0 else code       # death by signal s -> 128 + s, like a shell
+                for q in live:
+                    q.terminate()
     return rc
 
 

@@ -228,4 +228,24 @@ def test_bench_collectives_run_over_rccl_on_one_rank():
     line = json.loads(p.stdout.decode().strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["verified"] is True
     assert line["records"]["gathered"] == 1024
+    assert line["records"]["rows_on_rank0"] == 1024 and line["records"]["rows_match_their_records"] is True
     assert line["config"]["lpt_imbalance"] == 1.0
+
+
+def test_bench_shards_a_real_fasta_batch_over_rccl():
+    """--workload mammals (BASELINE config 3): rank 0 reads Mammals.txt and the reference's rotations, broadcasts them as
+    one packed pool (RCCL: the forced one-rank group), every rank builds its LPT share of the 66 pairs from the pool,
+    the aligned rows are gathered to rank 0 and all 66 records equal the compiled reference's digests."""
+    import json
+    import sys
+    env = dict(os.environ, CSADP_DIST_FORCE_GROUP="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0",
+                        "--mode", "strong", "--workload", "mammals", "--no-cpu-baseline", "--no-extra-legs"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = json.loads(p.stdout.decode().strip().splitlines()[-1])
+    assert line["verified"] is True
+    assert line["records"]["gathered"] == 66 and line["records"]["checked_against_reference_digests"] == 66
+    assert line["records"]["rows_on_rank0"] == 66 and line["records"]["rows_match_their_records"] is True

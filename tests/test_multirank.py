@@ -86,17 +86,23 @@ la = [max(8, x // 400) for x in la]
 pairs = [synth_pair(3000 + i, length=n) for i, n in enumerate(la)]
 costs = [len(a) * len(b) for a, b, _, _ in pairs]
 fill = oracle_filler()          # the DEVICE step is stubbed by the test seam (csadp_debug.h): no GPU here
+# rank 0 owns the real inputs: every other rank gets them through the packed pool (letters + rotations), like a FASTA batch
+seqs = [x for a, b, _, _ in pairs for x in (a, b)] if g.rank == 0 else None
+rots = [x for _, _, ra, rb in pairs for x in (ra, rb)] if g.rank == 0 else None
+pool, prot = g.broadcast_pool(seqs, rots)
+assert len(pool) == 80 and all(pool[2 * i] == pairs[i][0] and pool[2 * i + 1] == pairs[i][1] for i in range(40))
+assert prot == [x for _, _, ra, rb in pairs for x in (ra, rb)]
 def align_mine(ids):
     out = []
     for t in ids:
-        a, b, ra, rb = pairs[t]
-        r = csa_amd.debug_align_with_filler(([a, b], [ra, rb], None, None), fill)
+        r = csa_amd.debug_align_with_filler(([pool[2 * t], pool[2 * t + 1]], [prot[2 * t], prot[2 * t + 1]], None, None), fill)
         assert r["status"] == 0
-        out.append((r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])))
+        out.append((r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"]), r["aligned"]))
     return out
-by_id, mine, imbalance = cdist.run_sharded(g, costs, align_mine)
+by_id, mine, imbalance, rows = cdist.run_sharded(g, costs, align_mine)
 print(json.dumps({"rank": g.rank, "world": g.world, "mine": mine, "imbalance": imbalance,
-                  "records": sorted([k] + list(v) for k, v in by_id.items())}), flush=True)
+                  "records": sorted([k] + list(v) for k, v in by_id.items()),
+                  "rows": {str(k): [x.decode() for x in v] for k, v in sorted(rows.items())}}), flush=True)
 g.close()
 ''' % (ROOT, ROOT)
 
@@ -121,16 +127,19 @@ def _run_flow(tmp_path, world):
 
 
 def test_two_rank_lpt_split_and_gather_equals_single_rank(tmp_path):
-    """World 2 (gloo): rank 0 partitions by LPT and broadcasts, each rank aligns only its tasks
-    (host logic of the product, fills from the test seam), the 16-byte records are all-gathered.
-    Every rank must end up with exactly the world-1 records; the split is disjoint, complete and
-    balanced within 5 %."""
+    """World 2 (gloo): rank 0 broadcasts the packed sequence pool and the LPT assignment, each rank aligns only its
+    tasks (host logic of the product, fills from the test seam), the 16-byte records are all-gathered and the aligned
+    ROWS gathered to rank 0.  Every rank must end up with exactly the world-1 records, rank 0 with exactly the world-1
+    rows (what SaveAlignment prints, alignment.c:134-156); the split is disjoint, complete and balanced within 5 %."""
     one = _run_flow(tmp_path, 1)[0]
     two = _run_flow(tmp_path, 2)
     assert len(one["records"]) == 40 and one["mine"] == list(range(40))
     for o in two:
         assert o["records"] == one["records"]            # gathered == single rank, on BOTH ranks
         assert o["imbalance"] <= 1.05
+    assert len(one["rows"]) == 40 and two[0]["rows"] == one["rows"] and two[1]["rows"] == {}      # the rows themselves, on rank 0
+    for k, rws in one["rows"].items():
+        assert len(rws) == 2 and len(rws[0]) == len(rws[1]) == dict((r[0], r[2]) for r in one["records"])[int(k)]
     assert sorted(two[0]["mine"] + two[1]["mine"]) == list(range(40))
     assert two[0]["mine"] and two[1]["mine"] and not set(two[0]["mine"]) & set(two[1]["mine"])
 

@@ -5,7 +5,7 @@ nw_fill_cells that is the fully unrolled block of 32 steady-state steps (the ram
 lanes above the matrix idle with v_cndmask, is one of the first two blocks of a strip only) -- and counts
 its instructions by kind.
 
-    python tools/count_valu.py [csadp_bits.hip nw_fill_bitsILb1] [--steps 32]
+    python tools/count_valu.py [csadp_bits.hip nw_fill_bitsILi2ELi4ELb0] [--steps 32]     (W = 2, 4 waves, one workgroup per job)
 
 Prints the VALU instructions per step and the mix bench.py prices (v_bitop3 / three-operand and DPP /
 two-operand).  Needs hipcc only (no GPU)."""
@@ -17,14 +17,14 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HALF_RATE = ("v_add3", "v_perm", "v_bfe", "v_alignbit", "v_max3", "v_min3", "v_max_", "v_min_", "v_lshl_add", "v_lshl_or",
+HALF_RATE = ("v_addc_co", "v_sub_co", "v_add_co", "v_add3", "v_perm", "v_bfe", "v_alignbit", "v_max3", "v_min3", "v_max_", "v_min_", "v_lshl_add", "v_lshl_or",
              "v_and_or", "v_or3", "v_bfi", "v_cndmask", "v_cmp", "v_lshlrev", "v_mad", "v_mul", "v_readlane", "v_readfirstlane")
 
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     src = args[0] if args else "csadp_bits.hip"
-    kernel = args[1] if len(args) > 1 else "nw_fill_bitsILb1"
+    kernel = args[1] if len(args) > 1 else "nw_fill_bitsILi2ELi4ELb0"
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 32
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")

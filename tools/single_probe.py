@@ -31,5 +31,5 @@ for length in [int(x) for x in (sys.argv[1:] or ["16384", "100000", "200000"])]:
     csa_amd.align_batch([task])
     t3 = time.perf_counter()
     cells = len(a) * len(b)
-    print("%7d x %7d: fill %.3f ms  traceback+expand %.3f ms  = %.1f GCUPS on the device; align_batch host-to-host %.2f ms (second call %.2f)"
-          % (len(a), len(b), best["fill_ms"], best["traceback_ms"], cells / best["total_ms"] / 1e6, (t1 - t0) * 1e3, (t3 - t2) * 1e3), flush=True)
+    print("%7d x %7d (W %d): fill %.3f ms  traceback+expand %.3f ms  = %.1f GCUPS on the device; align_batch host-to-host %.2f ms (second call %.2f)"
+          % (len(a), len(b), best["words_per_lane"], best["fill_ms"], best["traceback_ms"], cells / best["total_ms"] / 1e6, (t1 - t0) * 1e3, (t3 - t2) * 1e3), flush=True)
