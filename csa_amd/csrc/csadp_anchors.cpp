@@ -107,80 +107,132 @@ struct Border {
 int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Border *out)
 {
 	const int N = (int)rev.size();
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto tp = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!trace) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "  border nodes: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+		tp = now;
+	};
 	std::vector<Automaton> sam((size_t)N);
 	host_parallel_for(N, [&](int t) { sam[(size_t)t].build(rev[(size_t)t].data(), (int)rev[(size_t)t].size()); });
+	lap("automata");
 
 	/* common[s][p] = length of the longest prefix of T_s[p..] found in every sequence;
-	 * ident[s][p]  = state of that prefix (reversed) in sequence 0's automaton */
+	 * ident[s][p]  = state of that prefix (reversed) in sequence 0's automaton.
+	 * One item per (text s, automaton t): N x N independent walks (round 2 ran one item per text: 12-19 items on a host
+	 * with 256 hardware threads), then one item per text takes the minimum over the automata. */
 	std::vector<std::vector<int>> common((size_t)N), ident((size_t)N);
-	host_parallel_for(N, [&](int s) {
+	std::vector<std::vector<int>> walk((size_t)N * N), st0((size_t)N);
+	host_parallel_for(N * N, [&](int item) {
+		const int s = item / N, t = item % N;
+		if (t == s && t != 0) return;                              /* the text's own bound is the suffix itself */
 		const std::vector<unsigned char> &R = rev[(size_t)s];
 		const int n = (int)R.size();
+		std::vector<int> &L = walk[(size_t)item];
+		L.resize((size_t)n);
+		if (t == 0) st0[(size_t)s].assign((size_t)n, 0);
+		const Automaton &A = sam[(size_t)t];
+		int v = 0, l = 0;
+		for (int q = 0; q < n; ++q) {
+			const int c = R[(size_t)q];
+			while (v != 0 && A.st[(size_t)v].next[c] == -1) {
+				v = A.st[(size_t)v].link;
+				l = A.st[(size_t)v].len;
+			}
+			if (A.st[(size_t)v].next[c] != -1) {
+				v = A.st[(size_t)v].next[c];
+				++l;
+			}
+			const int p = n - 1 - q;
+			L[(size_t)p] = l;
+			if (t == 0) st0[(size_t)s][(size_t)p] = v;
+		}
+	});
+	host_parallel_for(N, [&](int s) {
+		const int n = (int)rev[(size_t)s].size();
 		std::vector<int> &L = common[(size_t)s];
 		std::vector<int> &id = ident[(size_t)s];
 		L.resize((size_t)n);
 		id.assign((size_t)n, 0);
-		for (int q = 0; q < n; ++q) L[(size_t)(n - 1 - q)] = q + 1;          /* own bound: the suffix itself */
-		std::vector<int> st0((size_t)n, 0);
+		for (int p = 0; p < n; ++p) L[(size_t)p] = n - p;         /* own bound: the suffix itself */
 		for (int t = 0; t < N; ++t) {
 			if (t == s && t != 0) continue;
-			const Automaton &A = sam[(size_t)t];
-			int v = 0, l = 0;
-			for (int q = 0; q < n; ++q) {
-				const int c = R[(size_t)q];
-				while (v != 0 && A.st[(size_t)v].next[c] == -1) {
-					v = A.st[(size_t)v].link;
-					l = A.st[(size_t)v].len;
-				}
-				if (A.st[(size_t)v].next[c] != -1) {
-					v = A.st[(size_t)v].next[c];
-					++l;
-				}
-				const int p = n - 1 - q;
-				if (l < L[(size_t)p]) L[(size_t)p] = l;
-				if (t == 0) st0[(size_t)p] = v;
-			}
+			const std::vector<int> &W = walk[(size_t)s * N + t];
+			for (int p = 0; p < n; ++p)
+				if (W[(size_t)p] < L[(size_t)p]) L[(size_t)p] = W[(size_t)p];
 		}
 		const Automaton &A0 = sam[0];
 		for (int p = 0; p < n; ++p) {
-			int v = st0[(size_t)p];
+			int v = st0[(size_t)s][(size_t)p];
 			const int len = L[(size_t)p];
 			if (len == 0) continue;
 			while (A0.st[(size_t)A0.st[(size_t)v].link].len >= len) v = A0.st[(size_t)v].link;
 			id[(size_t)p] = v;
 		}
 	});
-
+	lap("matching statistics");
 	struct Credit {
 		long long key;
 		int seq, pos;
 	};
 	std::vector<Credit> credits;
-	size_t total = 0;
-	for (int s = 0; s < N; ++s) total += rev[(size_t)s].size();
-	credits.reserve(total);
+	{
+		/* credits in (seq, pos) order: every text counts its own, then writes them at its offset */
+		std::vector<size_t> first((size_t)N + 1, 0);
+		host_parallel_for(N, [&](int s) {
+			size_t c = 0;
+			for (int len : common[(size_t)s]) c += len != 0;      /* len 0: credited to the root, the list's sentinel (alignment.c:47) */
+			first[(size_t)s + 1] = c;
+		});
+		for (int s = 0; s < N; ++s) first[(size_t)s + 1] += first[(size_t)s];
+		credits.resize(first[(size_t)N]);
+		const long long span0 = (long long)rev[0].size() + 2;
+		host_parallel_for(N, [&](int s) {
+			size_t at = first[(size_t)s];
+			const int n = (int)rev[(size_t)s].size();
+			for (int p = 0; p < n; ++p) {
+				const int len = common[(size_t)s][(size_t)p];
+				if (len == 0) continue;
+				credits[at++] = {(long long)ident[(size_t)s][(size_t)p] * span0 + len, s, p};
+			}
+		});
+	}
 	const long long span = (long long)rev[0].size() + 2;
-	for (int s = 0; s < N; ++s)
-		for (int p = 0; p < (int)rev[(size_t)s].size(); ++p) {
-			const int len = common[(size_t)s][(size_t)p];
-			if (len == 0) continue;          /* credited to the root, which is the list's sentinel (alignment.c:47) */
-			credits.push_back({(long long)ident[(size_t)s][(size_t)p] * span + len, s, p});
-		}
 	/* order by (key, seq, pos): the credits were generated in (seq, pos) order, so a STABLE sort on
-	 * the key alone does it -- LSD radix, 11 bits a pass */
+	 * the key alone does it -- LSD radix, 11 bits a pass, every pass split over the pool: each thread counts its
+	 * slice, the slices' counts are turned into write offsets digit by digit (slice order inside a digit keeps the
+	 * sort stable), each thread scatters its slice */
 	{
 		long long maxkey = 0;
 		for (const Credit &c : credits) maxkey = std::max(maxkey, c.key);
 		std::vector<Credit> tmp(credits.size());
+		const int T = (int)std::max<size_t>(1, std::min<size_t>(16, credits.size() / 8192));
+		std::vector<size_t> count((size_t)T * 2048);
+		const size_t n = credits.size();
 		for (int shift = 0; (maxkey >> shift) != 0; shift += 11) {
-			size_t count[2049] = {0};
-			for (const Credit &c : credits) ++count[((c.key >> shift) & 2047) + 1];
-			for (int i = 0; i < 2048; ++i) count[i + 1] += count[i];
-			for (const Credit &c : credits) tmp[count[(c.key >> shift) & 2047]++] = c;
+			std::fill(count.begin(), count.end(), 0);
+			host_parallel_for(T, [&](int t) {
+				size_t *cnt = &count[(size_t)t * 2048];
+				for (size_t i = n * t / T, e = n * (t + 1) / T; i < e; ++i) ++cnt[(credits[i].key >> shift) & 2047];
+			}, T);
+			size_t run = 0;
+			for (int d = 0; d < 2048; ++d)
+				for (int t = 0; t < T; ++t) {
+					const size_t c = count[(size_t)t * 2048 + d];
+					count[(size_t)t * 2048 + d] = run;
+					run += c;
+				}
+			host_parallel_for(T, [&](int t) {
+				size_t *at = &count[(size_t)t * 2048];
+				for (size_t i = n * t / T, e = n * (t + 1) / T; i < e; ++i) tmp[at[(credits[i].key >> shift) & 2047]++] = credits[i];
+			}, T);
 			credits.swap(tmp);
 		}
 	}
 
+	lap("credits + radix sort");
 	struct Group {
 		size_t from, to;
 		int first0;
@@ -223,6 +275,7 @@ int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Bor
 			B.tail[node * N + s] = (int)B.pool.size();
 		}
 	}
+	lap("groups + nodes");
 	return CSADP_OK;
 }
 

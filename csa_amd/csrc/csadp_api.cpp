@@ -22,6 +22,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "csadp_engine.h"
+#include "csadp_hostpar.h"
 #include "csadp_kernels.h"
 #include "csadp_progressive.h"
 
@@ -32,73 +33,8 @@ using csadp::Progressive;
 namespace {
 
 /* Per-task host work (validation, table packing, traceback application, string building) is
- * independent across tasks: spread it over a persistent pool of host threads
- * (CSADP_HOST_THREADS, default min(16, hardware threads): more only adds allocator contention,
- * and creating threads per call cost ~2 ms per phase, both measured); n small -> run inline. */
-class HostPool {
-public:
-	static HostPool &get()
-	{
-		static HostPool *pool = new HostPool;        /* never destroyed: workers may outlive static destructors */
-		return *pool;
-	}
-	int size() const { return nthreads_; }
-	/* run body() on all workers and on the caller, return when every one has finished */
-	void run(const std::function<void()> &body, int workers)
-	{
-		std::unique_lock<std::mutex> busy(run_mutex_);       /* one parallel region at a time */
-		{
-			std::lock_guard<std::mutex> lock(m_);
-			body_ = &body;
-			want_ = workers - 1;
-			started_ = 0;
-			done_ = 0;
-			++epoch_;
-		}
-		cv_.notify_all();
-		body();
-		std::unique_lock<std::mutex> lock(m_);
-		cv_done_.wait(lock, [&] { return done_ == want_; });
-		body_ = nullptr;
-	}
-
-private:
-	HostPool()
-	{
-		const char *e = getenv("CSADP_HOST_THREADS");
-		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
-		nthreads_ = t < 1 ? 1 : (t > 16 ? 16 : t);
-		for (int w = 1; w < nthreads_; ++w) std::thread([this] { loop(); }).detach();
-	}
-	void loop()
-	{
-		unsigned long long seen = 0;
-		for (;;) {
-			const std::function<void()> *body = nullptr;
-			{
-				std::unique_lock<std::mutex> lock(m_);
-				cv_.wait(lock, [&] { return epoch_ != seen; });
-				seen = epoch_;
-				if (started_ >= want_) continue;             /* this region needs fewer workers */
-				++started_;
-				body = body_;
-			}
-			(*body)();
-			{
-				std::lock_guard<std::mutex> lock(m_);
-				++done_;
-			}
-			cv_done_.notify_one();
-		}
-	}
-	int nthreads_ = 1;
-	std::mutex run_mutex_, m_;
-	std::condition_variable cv_, cv_done_;
-	const std::function<void()> *body_ = nullptr;
-	int want_ = 0, started_ = 0, done_ = 0;
-	unsigned long long epoch_ = 0;
-};
-
+ * independent across tasks: spread it over the process' persistent pool of host threads (csadp_hostpar.h),
+ * at most 16 of them here: more only adds allocator contention (measured); n small -> run inline. */
 constexpr int kNoDeviceIo = 1;    /* pairs_create_io: use the host-I/O path instead (never leaves this file) */
 
 bool env_on(const char *name, bool dflt)
@@ -110,17 +46,11 @@ bool env_on(const char *name, bool dflt)
 template <class F>
 void parallel_for(int n, F &&fn)
 {
-	const int nthreads = HostPool::get().size();
-	const int workers = n < 4 ? 1 : (nthreads < n ? nthreads : n);
-	if (workers <= 1) {
+	if (n < 4) {
 		for (int i = 0; i < n; ++i) fn(i);
 		return;
 	}
-	std::atomic<int> next(0);
-	const std::function<void()> body = [&]() {
-		for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
-	};
-	HostPool::get().run(body, workers);
+	csadp::host_parallel_for(n, fn, 16);
 }
 
 }  // namespace
@@ -392,10 +322,13 @@ int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp_result *r
                             csadp_multi_stats *stats)
 {
 	if (!tasks || !results || ntasks < 0 || ndevices < 1 || ndevices > CSADP_MAX_DEVICES) return CSADP_ERR_ARG;
+	/* every entry is defined whatever happens below: the caller may hand the whole array to csadp_free_result(s) */
+	memset(results, 0, sizeof(csadp_result) * (size_t)ntasks);
 	std::vector<long long> cost((size_t)ntasks);
 	for (int t = 0; t < ntasks; ++t) {
-		cost[(size_t)t] = csadp_task_cost(&tasks[t]);
-		if (cost[(size_t)t] < 0) return CSADP_ERR_ARG;
+		/* a task no device could align (nseq < 2, bad bounds) costs nothing here and gets its error per task from
+		 * csadp_align_batch_on, like in csadp_align_batch */
+		cost[(size_t)t] = std::max(0LL, csadp_task_cost(&tasks[t]));
 	}
 	std::vector<int> part((size_t)ntasks);
 	long long maxload = 0;
@@ -425,6 +358,8 @@ int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp_result *r
 		drc[(size_t)d] = r;
 		if (r == CSADP_OK)
 			for (size_t i = 0; i < idx.size(); ++i) results[idx[i]] = res[i];
+		else
+			for (size_t i = 0; i < idx.size(); ++i) results[idx[i]].status = r;      /* aligned / progress stay NULL */
 		dms[(size_t)d] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td).count();
 	};
 	std::vector<std::thread> threads;

@@ -50,8 +50,15 @@ Engine *Engine::open(int device, const csadp_config *cfg, int *rc)
 	/* An engine runs two fill streams, their side streams and a copy stream; the HIP runtime multiplexes all streams of a
 	 * process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run in order -- a fill
 	 * behind somebody else's traceback (rocprofv3 trace of tools/stream_probe2.py).  Ask for 8 unless the caller has
-	 * chosen; without effect when the process has initialised HIP before (then the caller sets it, as bench.py does). */
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	 * chosen: ONCE per process, under the registry lock, in front of the library's first HIP call -- later calls would
+	 * change nothing (the runtime reads it when it initialises) and would write the environment next to other threads'
+	 * getenv.  Without effect when the process has initialised HIP before (then the caller sets it, as bench.py does;
+	 * INTEGRATION.md). */
+	static bool queues_asked = false;
+	if (!queues_asked) {
+		setenv("GPU_MAX_HW_QUEUES", "8", 0);
+		queues_asked = true;
+	}
 	int count = 0;
 	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
 		fprintf(stderr, "csadp: no HIP device available (this library has no CPU fallback)\n");

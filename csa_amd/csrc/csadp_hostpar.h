@@ -1,7 +1,10 @@
 /*
- * csadp_hostpar.h -- tiny fork-join helper for the host stages around the DP (rotation finder,
- * anchor stage): independent per-sequence work spread over short-lived threads
- * (CSADP_HOST_THREADS, default min(64, hardware threads)).
+ * csadp_hostpar.h -- the host side's fork-join helper: ONE persistent pool of threads per process
+ * (CSADP_HOST_THREADS, default min(64, hardware threads)) shared by the per-task work around the device
+ * passes (csadp_api.cpp) and the host stages around the DP (rotation finder, anchor stage).  Creating
+ * threads per call cost ~2 ms per parallel region on the 256-thread hosts of the GPU boxes (measured in
+ * round 2 for the per-task work; the host stages had kept their own short-lived threads until round 3).
+ * Items are handed out one at a time through an atomic counter, so uneven items balance.
  */
 #ifndef CSADP_HOSTPAR_H
 #define CSADP_HOSTPAR_H
@@ -9,33 +12,103 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
-#include <vector>
 
 namespace csadp {
 
-inline int host_stage_threads()
+class HostPool {
+public:
+	static HostPool &get()
+	{
+		static HostPool *pool = new HostPool;        /* never destroyed: workers may outlive static destructors */
+		return *pool;
+	}
+	int size() const { return nthreads_; }
+	/* run body() on `workers` - 1 pool threads and on the caller, return when every one has finished */
+	void run(const std::function<void()> &body, int workers)
+	{
+		std::unique_lock<std::mutex> busy(run_mutex_);       /* one parallel region at a time */
+		{
+			std::lock_guard<std::mutex> lock(m_);
+			body_ = &body;
+			want_ = std::min(workers, nthreads_) - 1;
+			started_ = 0;
+			done_ = 0;
+			++epoch_;
+		}
+		cv_.notify_all();
+		body();
+		std::unique_lock<std::mutex> lock(m_);
+		cv_done_.wait(lock, [&] { return done_ == want_; });
+		body_ = nullptr;
+	}
+
+private:
+	HostPool()
+	{
+		const char *e = getenv("CSADP_HOST_THREADS");
+		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
+		nthreads_ = t < 1 ? 1 : (t > 64 ? 64 : t);
+		for (int w = 1; w < nthreads_; ++w) std::thread([this] { loop(); }).detach();
+	}
+	void loop()
+	{
+		unsigned long long seen = 0;
+		for (;;) {
+			const std::function<void()> *body = nullptr;
+			{
+				std::unique_lock<std::mutex> lock(m_);
+				cv_.wait(lock, [&] { return epoch_ != seen; });
+				seen = epoch_;
+				if (started_ >= want_) continue;             /* this region needs fewer workers */
+				++started_;
+				body = body_;
+			}
+			(*body)();
+			{
+				std::lock_guard<std::mutex> lock(m_);
+				++done_;
+			}
+			cv_done_.notify_one();
+		}
+	}
+	int nthreads_ = 1;
+	std::mutex run_mutex_, m_;
+	std::condition_variable cv_, cv_done_;
+	const std::function<void()> *body_ = nullptr;
+	int want_ = 0, started_ = 0, done_ = 0;
+	unsigned long long epoch_ = 0;
+};
+
+inline bool &host_in_region()
 {
-	const char *e = getenv("CSADP_HOST_THREADS");
-	const int n = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
-	return std::max(1, std::min(n, 64));
+	static thread_local bool inside = false;
+	return inside;
 }
 
+/* fn(i) for i in [0, n) on at most `cap` threads of the pool (the caller included); n small -> inline.  A call
+ * from inside a parallel region (an item that is itself parallel) runs its items on the calling thread: the pool
+ * serves one region at a time. */
 template <class F>
-void host_parallel_for(int n, F &&fn)
+void host_parallel_for(int n, F &&fn, int cap = 64)
 {
-	const int nt = std::min(host_stage_threads(), n);
-	if (nt <= 1) {
+	const int nthreads = std::min(HostPool::get().size(), cap);
+	const int workers = (n < 2 || host_in_region()) ? 1 : std::min(nthreads, n);
+	if (workers <= 1) {
 		for (int i = 0; i < n; ++i) fn(i);
 		return;
 	}
-	std::vector<std::thread> pool;
-	pool.reserve((size_t)nt);
-	for (int t = 0; t < nt; ++t)
-		pool.emplace_back([&fn, t, n, nt]() {
-			for (int i = t; i < n; i += nt) fn(i);
-		});
-	for (auto &th : pool) th.join();
+	std::atomic<int> next(0);
+	const std::function<void()> body = [&]() {
+		host_in_region() = true;
+		for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+		host_in_region() = false;
+	};
+	HostPool::get().run(body, workers);
 }
 
 }  // namespace csadp

@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -106,10 +108,13 @@ struct Sam {
 			}
 			last = cur;
 		}
-		/* propagate counts and largest end positions up the suffix links, longest first */
-		std::vector<int> order(st.size());
-		for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-		std::sort(order.begin(), order.end(), [&](int a, int b) { return st[(size_t)a].len > st[(size_t)b].len; });
+		/* propagate counts and largest end positions up the suffix links, longest first: a counting sort by length
+		 * (lengths are at most 2n; a comparison sort of the 4n states took as long as building them) */
+		std::vector<int> first((size_t)2 * n + 2, 0), order(st.size());
+		for (const State &x : st) ++first[(size_t)x.len + 1];
+		for (int l = 0; l <= 2 * n; ++l) first[(size_t)l + 1] += first[(size_t)l];
+		for (size_t i = 0; i < st.size(); ++i) order[(size_t)first[(size_t)st[i].len]++] = (int)i;
+		std::reverse(order.begin(), order.end());
 		for (int v : order) {
 			const int l = st[(size_t)v].link;
 			if (l >= 0) {
@@ -158,6 +163,14 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 	const int cap = minlen - 1;
 	if (cap < 1) return CSADP_ERR_ARG;
 
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto tp = std::chrono::steady_clock::now();
+	auto lap = [&](const char *what) {
+		if (!trace) return;
+		const auto now = std::chrono::steady_clock::now();
+		fprintf(stderr, "  rotations: %s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+		tp = now;
+	};
 	/* ---- matching statistics of sequence 0 against every sequence ------------------------- */
 	std::vector<Sam> sam((size_t)nseq);
 	std::vector<std::vector<int>> state_at((size_t)nseq);     /* automaton state after end position e */
@@ -198,6 +211,7 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 	for (int s = 0; s < nseq; ++s)
 		for (int p = 0; p < n0; ++p) M[(size_t)p] = std::min(M[(size_t)p], Ms[(size_t)s][(size_t)p]);
 
+	lap("automata + matching statistics");
 	/* ---- blocks ---------------------------------------------------------------------------- */
 	std::vector<Block> blocks;
 	for (int p = 0; p < n0; ++p) {
@@ -220,6 +234,7 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 	}
 	if (blocks.empty()) return CSADP_ERR_RANGE;               /* reference: "No unique subsequences found" */
 
+	lap("blocks");
 	/* ---- list order: decreasing depth; equal depths in reverse order of the tree's DFS -------- */
 	const std::vector<unsigned char> &s0 = seq[0];
 	auto letter = [&](const Block &b, int i) { return s0[(size_t)((b.p0 + i) % n0)]; };
@@ -245,6 +260,7 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 	});
 	const int nb = (int)blocks.size();
 
+	lap("list order");
 	/* ---- chain links, csamsa.c:143-178 --------------------------------------------------------- */
 	std::vector<int> by_pos((size_t)nb);
 	for (int k = 0; k < nseq; ++k) {
@@ -302,6 +318,7 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 		}
 		b.total += b.size;
 	}
+	lap("chains");
 	/* ---- the first strictly largest chain wins (sortList, nodeslinkedlists.c:55-79) ------------- */
 	int best = 0;
 	for (int i = 1; i < nb; ++i)

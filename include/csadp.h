@@ -138,7 +138,10 @@ typedef struct csadp_multi_stats {
 /* One batch over ndevices GPUs of this node from ONE host process: tasks are partitioned by
  * longest-processing-time-first over their csadp_task_cost (csadp_partition_lpt), one host thread
  * per GPU aligns its part (csadp_align_batch_on), results land in results[] in task order -- the
- * gather is host memory.  devices = NULL means ordinals 0..ndevices-1.  stats may be NULL. */
+ * gather is host memory.  devices = NULL means ordinals 0..ndevices-1.  stats may be NULL.
+ * Every results[] entry is defined on return, also when the call fails: the tasks of a device whose
+ * thread failed carry that error in .status with NULL strings, the others are complete and the
+ * caller's to free (csadp_free_results over the whole array is always safe). */
 CSADP_API int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp_result *results,
                                       const int *devices, int ndevices, csadp_multi_stats *stats);
 
