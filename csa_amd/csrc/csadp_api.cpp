@@ -163,7 +163,6 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	parallel_for((int)active.size(), [&](int j) {
 		Progressive &p = tasks[active[(size_t)j]];
 		if (fb.bits()) p.write_tables_bits(fb.bit_cols(j), fb.bit_nwords(j), fb.bit_rows(j), fb.bit_rowwords(j));
-		else if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
 		else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 	});
 	lap();
@@ -528,8 +527,7 @@ static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pa
 			Progressive &p = bp->tasks[(size_t)bp->active[(size_t)j]];
 			FillBatch &fb = bp->fb;
 			if (fb.bits()) p.write_tables_bits(fb.bit_cols(j), fb.bit_nwords(j), fb.bit_rows(j), fb.bit_rowwords(j));
-			else if (fb.packed()) p.write_tables_pk(fb.pk_tab(j), fb.ncols_pad(j), fb.pk_rowsel(j), fb.pk_selbase(j), fb.pk_top(j));
-			else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
+				else p.write_tables(fb.coltab(j), fb.leftc(j), fb.ncols_pad(j), fb.rowshift(j), fb.top(j), fb.wide());
 		});
 		lap("tables");
 		if ((rc = b->fb.upload()) != CSADP_OK) return rc;

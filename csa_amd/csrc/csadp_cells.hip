@@ -45,7 +45,7 @@ namespace {
 
 constexpr int kRing = 8;                          /* hand-off blocks buffered per strip boundary */
 constexpr int kRingSteps = kRing * kCellBlock;
-constexpr int kSpinMax = 1 << 22;
+constexpr unsigned long long kSpinTicks = 50000000ull;    /* bound of every wait: 0.5 s of the 100 MHz s_memrealtime clock (round 2: an iteration count) */
 constexpr int DPP_WAVE_SHR1 = 0x138;
 
 /* Counters in LDS that order LDS data only: the LDS executes one wave's instructions in order and is
@@ -53,9 +53,11 @@ constexpr int DPP_WAVE_SHR1 = 0x138;
  * would also drain the wave's outstanding direction stores (vmcnt(0)), a microsecond per 32-step block. */
 __device__ __forceinline__ bool wait_lds(const int *counter, int need)
 {
+	if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= need) return true;
+	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 	int spins = 0;
 	while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) {
-		if (++spins > kSpinMax) return false;
+		if ((++spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
 	}
 	return true;
 }
@@ -273,11 +275,13 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			granule_wait(pre);
 			unsigned long long v = pre;
 			int spins = 0;
+			unsigned long long t0 = 0;
 			for (;;) {
 				const bool ok = ps >= J.steps_pad || (uint32_t)(v >> 40) == epoch;
 				if (__all(ok)) break;
 				__builtin_amdgcn_s_sleep(2);
-				if (++spins > kSpinMax) return false;
+				if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
+				if ((++spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
 				if (!ok) granule_reload(v, hand_in + ps);
 			}
 			if (lane < kCellBlock) L.inject_mine[3 + lane] = (uint32_t)v;

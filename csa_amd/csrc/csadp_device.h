@@ -24,85 +24,22 @@ constexpr int kLanes = 64;           /* wave64 */
 /* direction codes stored 2 bit per cell */
 enum : int { DIR_U = 0, DIR_L = 1, DIR_D = 2 };
 
-/* One matrix fill (one progressive step of one task).  Columns are owned by lanes:
- * global lane L = 64*strip + lane owns columns [L*C+1, L*C+C]; at global step T it computes
- * the R rows with 0-based index R*(T-L) .. R*(T-L)+R-1.  A tile is TR consecutive steps of
- * one strip. */
+/* One matrix fill as the host registers it (one progressive step of one task); the engine turns it into a BitJob or a
+ * CellJob when the batch is laid out. */
 struct FillJob {
-	/* byte offsets into the batch arena (one hipMalloc); the kernels add them to their
-	 * arena kernel argument so every access is a global_* (not flat_*) instruction */
-	uint64_t coltab;          /* u32 [ncols_pad] diag gains per row letter: bytes 8*sv[c]+2 (narrow, i <= 31) or    */
-	                          /*     6-bit fields sv[c] (wide, i <= 63)                                            */
-	uint64_t leftc;           /* i32 [ncols_pad] left gain 4*(sv[4]-i) + 1                                        */
-	uint64_t rowshift;        /* u8  [padl + R*steps_pad + R*64] bfe offset of row r's letter (8*code narrow,     */
-	                          /*     6*code wide) at index padl + (r-1), zero padded                               */
-	uint64_t top;             /* i32 [ncols_pad + 1] X of border row 0 = 4*H[0][k] (possibly stale, survey Q1)    */
-	uint64_t handoff;         /* i32 [nstrips][hpitch][R] right-edge cost after step T, row q, at index R*(T+1)+q */
-	uint64_t state;           /* i32 [nstrips][C+1+R][64] lane registers between two tiles of a strip             */
-	uint64_t dirs;            /* u32 [nstrips][steps_pad][R][C/16][64] sixteen 2-bit codes per word               */
-	uint64_t ops;             /* u8  [nrows + ncols + 64] traceback ops, walk order (from (nrows,ncols) back)     */
-	uint64_t summary;         /* i32 [4] nops, remaining rows j, remaining cols k, 0                              */
 	int32_t nrows, ncols;
 	int32_t nstrips;
-	int32_t steps_pad;        /* number of steps allocated per strip (multiple of TR)                         */
-	int32_t hpitch;           /* steps_pad + 64                                                               */
-	int32_t padl;             /* left padding of rowshift = R*(64*nstrips + 64)                               */
+	int32_t steps_pad;
 	int32_t nprev;            /* i                                                                             */
 	int32_t leftmul;          /* 4*(i - left_i): X of border column 0 is leftmul * r (0 on fresh borders)      */
 };
 
+/* work item of a chunked launch: chunk `a` of job `job` (csadp_bits.hip, csadp_cells.hip) */
 struct TileRef {
 	int32_t job;
-	int32_t a;                /* tile index along the step axis: steps [a*TR, (a+1)*TR) */
-	int32_t s;                /* strip                                                  */
-	int32_t first;            /* 1 = first tile of this strip: start from the top border */
-};
-
-/* One launch may carry tiles of several passes that are in flight at different anti-diagonals
- * (csadp_engine.cpp: FillBatch::flush): each segment is a tile list plus the index of its
- * pass' first job in the job table. */
-struct TileSeg {
-	uint64_t tiles;           /* byte offset of a TileRef array in the arena */
-	int32_t count;
-	int32_t job_base;
-};
-constexpr int kMaxSegs = 8;
-struct SegList {
-	TileSeg seg[kMaxSegs];
-	int32_t n;
-	int32_t pad;
-};
-
-/*
- * Packed-16 pair job: TWO pairwise fills (i = 1, fresh borders, hence left gain -3 in every
- * column) share every register, the
- * low half word carrying matrix A and the high half word matrix B (v_pk_add_i16 /
- * v_pk_max_i16 process both at once: 8 VALU instructions per 2 cells).  Values are kept
- * relative to a per-strip, per-matrix 32-bit base that is re-centred at every tile start;
- * the Lipschitz bound of the recurrence (|dX| <= 8 per column, <= 12 per row for i = 1)
- * keeps a wave's live values within +-11 k of it.  Geometry (strips, steps) is that of the
- * larger of the two matrices; the smaller one computes unread cells beyond its edge.
- */
-struct PairJob {
-	uint64_t tab[2];          /* u32 [ncols_pad] per matrix: bytes 8*sv[c]+2 (narrow table format)          */
-	uint64_t rowsel;          /* u32 [padl + R*steps_pad + R*64] v_perm selector of row r at index padl+(r-1): */
-	                          /*     byte0 = letter of A, byte2 = 4 + letter of B, 0x0c (-> 0) elsewhere       */
-	uint64_t top[2];          /* i32 [ncols_pad + 1] X of border row 0 per matrix                             */
-	uint64_t handoff;         /* i32 [nstrips][hpitch][R][2] ABSOLUTE right-edge X after step T: index T+1    */
-	uint64_t state;           /* u32 [nstrips][C+1+R+2][64] packed lane registers + the two bases             */
-	uint64_t dirs;            /* u32 [nstrips][steps_pad][R][64][2]: word g of a lane = columns 8g..8g+7,      */
-	                          /*     8 codes of A in the low half, 8 codes of B in the high half, first column  */
-	                          /*     in the top bits of each half                                              */
-	uint64_t progress;        /* i32 [nstrips] persistent kernel: chunks (TR steps) each strip has published    */
-	uint64_t ops[2];          /* u8 traceback ops per matrix                                                   */
-	uint64_t summary[2];      /* i32 [4] per matrix                                                            */
-	int32_t nrows[2], ncols[2];
-	int32_t nrows_max, ncols_max;
-	int32_t nstrips;
-	int32_t steps_pad;
-	int32_t hpitch;
-	int32_t padl;             /* in rows: R*(64*nstrips + 64)                                                  */
-	int32_t leftmul[2];       /* X of border column 0 is leftmul * r (0 on fresh borders)                     */
+	int32_t a;
+	int32_t s;                /* unused */
+	int32_t first;            /* unused */
 };
 
 /*
@@ -180,7 +117,6 @@ struct CellJob {
 	                          /*     first step in bits 1:0                                                                 */
 	uint64_t hand;            /* u64 [nchunks-1][steps_pad] granules {X, epoch << 8} leaving the last column of each chunk   */
 	                          /*     but the last: valid when they carry the launch's epoch                                  */
-	uint64_t progress;        /* unused (kept for layout stability)                                                          */
 	uint64_t ops;             /* u8 traceback ops, walk order                                                              */
 	uint64_t summary;         /* i32 [4] nops, remaining rows, remaining cols, 0                                           */
 	int32_t nrows, ncols;

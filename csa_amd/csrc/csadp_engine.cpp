@@ -142,13 +142,6 @@ int Engine::init(int dev, const csadp_config *cfg)
 	nstreams_ = 2 * main_streams();
 	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-	C_ = env_int("CSADP_COLS_PER_LANE", 16);
-	R_ = env_int("CSADP_ROWS_PER_STEP", 2);
-	TR_ = (cfg && cfg->tile_rows > 0) ? cfg->tile_rows : env_int("CSADP_TILE_ROWS", 64);
-	if (C_ != 16 && C_ != 32) return CSADP_ERR_ARG;
-	if (R_ != 1 && R_ != 2 && R_ != 4) return CSADP_ERR_ARG;
-	if (C_ == 32 && R_ == 4) return CSADP_ERR_ARG;
-	if (TR_ != 64 && TR_ != 128 && TR_ != 256) return CSADP_ERR_ARG;
 	HIP_TRY(configure_kernels());                     /* per-device function attributes (csadp_bits.hip) */
 	verbose_ = cfg && cfg->verbose;
 	ready_ = true;
@@ -276,11 +269,6 @@ void FillBatch::clear()
 	extra_.clear();
 	tiles_.clear();
 	diag_off_.clear();
-	pjobs_.clear();
-	pextra_.clear();
-	pair_of_.clear();
-	half_of_.clear();
-	pk_ = false;
 	bits_ = false;
 	bjobs_.clear();
 	bextra_.clear();
@@ -329,12 +317,10 @@ int FillBatch::layout()
 	Engine &E = *E_;
 	if (!E.ready()) return CSADP_ERR_NO_DEVICE;
 	{ const int brc = E.bind(); if (brc != CSADP_OK) return brc; }
-	const int C = E.C(), R = E.R(), TR = E.TR(), W = C / 16;
 	const int nj = (int)jobs_.size();
 	extra_.assign(nj, Extra());
 	cells_ = dir_bytes_ = border_bytes_ = 0;
 	wide_ = false;
-	pk_ = false;
 	bits_ = false;
 	cells_mode_ = false;
 	if (bits_allowed_ && nj >= 1 && env_int("CSADP_BITS", 1) != 0) {
@@ -343,139 +329,16 @@ int FillBatch::layout()
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) bits_ = false;
 	}
 	if (bits_) return layout_bits();
-	if (nj >= 2 && C == 16 && R <= 2 && env_int("CSADP_PK16", 1) != 0) {
-		pk_ = true;
-		for (const FillJob &J : jobs_)
-			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) pk_ = false;
-	}
-	if (pk_) return layout_pk();
-	/* every other fill (profile steps, stale borders, pairs with the bit-parallel path switched off):
-	 * the persistent cell-per-lane wavefront; CSADP_CELLS=0 keeps the tiled 32-bit kernel */
-	if (env_int("CSADP_CELLS", 1) != 0) return layout_cells();
-
-	/* geometry + tile schedule */
-	int ndiag = 0;
-	std::vector<int> diag_count;
-	for (int j = 0; j < nj; ++j) {
-		FillJob &J = jobs_[j];
-		if (J.nrows <= 0 || J.ncols <= 0) return CSADP_ERR_ARG;
-		const long long nprev = J.nprev;
-		if (nprev < 1 || nprev > 63) return CSADP_ERR_ARG;
-		if (nprev * (2LL * J.nrows + J.ncols) * 4 + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
-		if (nprev > 31) wide_ = true;
-		const int lanes = (J.ncols + C - 1) / C;
-		J.nstrips = (lanes + kLanes - 1) / kLanes;
-		extra_[j].ncols_pad = J.nstrips * kLanes * C;
-		const int rsteps = (J.nrows + R - 1) / R;                 /* lane-steps that hold real rows */
-		J.steps_pad = (int)align_up((size_t)rsteps + (size_t)kLanes * J.nstrips, TR);
-		J.hpitch = J.steps_pad + 64;
-		J.padl = R * (kLanes * J.nstrips + 64);
-		for (int s = 0; s < J.nstrips; ++s) {
-			const int a0 = (kLanes * s) / TR;
-			const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
-			ndiag = std::max(ndiag, a1 + s + 1);
-			if ((int)diag_count.size() < a1 + s + 1) diag_count.resize(a1 + s + 1, 0);
-			for (int a = a0; a <= a1; ++a) diag_count[a + s]++;
-		}
-		cells_ += (long long)J.nrows * J.ncols;
-		dir_bytes_ += (long long)J.nrows * (long long)lanes * 4 * W;   /* 2 bit per cell, whole words */
-	}
-	diag_off_.assign((size_t)ndiag + 1, 0);
-	for (int d = 0; d < ndiag; ++d) diag_off_[d + 1] = diag_off_[d] + (size_t)diag_count[d];
-	tiles_.assign(diag_off_[ndiag], TileRef());
-	{
-		std::vector<size_t> cur(diag_off_.begin(), diag_off_.end() - 1);
-		for (int j = 0; j < nj; ++j) {
-			const FillJob &J = jobs_[j];
-			const int rsteps = (J.nrows + R - 1) / R;
-			for (int s = 0; s < J.nstrips; ++s) {
-				const int a0 = (kLanes * s) / TR;
-				const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
-				for (int a = a0; a <= a1; ++a) {
-					TileRef t;
-					t.job = j;
-					t.a = a;
-					t.s = s;
-					t.first = (a == a0);
-					tiles_[cur[a + s]++] = t;
-				}
-				/* hand-off ints written once and read once, lane state saved + restored per tile */
-				border_bytes_ += 2LL * 4 * (a1 - a0 + 1) * TR * R + 2LL * 4 * (a1 - a0 + 1) * (C + 1 + R) * kLanes;
-			}
-		}
-	}
-
-	/* arena offsets: shared inputs, then one result + scratch set per slot */
-	nslots_ = pipelined_ ? E.slots() : 1;
-	next_slot_ = 0;
-	size_t off = 0;
-	for (int sl = 0; sl < nslots_; ++sl) {          /* one contiguous job table: slot sl starts at sl * nj */
-		jobs_off_[sl] = off;
-		off += (size_t)nj * sizeof(FillJob);
-	}
-	off = align_up(off, 256);
-	tiles_off_ = off;
-	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
-	for (int j = 0; j < nj; ++j) {
-		FillJob &J = jobs_[j];
-		Extra &X = extra_[j];
-		X.in_coltab = J.coltab = off;
-		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
-		X.in_leftc = J.leftc = off;
-		off = align_up(off + (size_t)X.ncols_pad * 4, 256);
-		X.in_rowshift = J.rowshift = off;
-		off = align_up(off + (size_t)J.padl + (size_t)R * J.steps_pad + (size_t)R * 64 + 64, 256);
-		X.in_top = J.top = off;
-		off = align_up(off + ((size_t)X.ncols_pad + 1) * 4, 256);
-	}
-	in_bytes_ = off;
-	std::vector<std::vector<FillJob>> slot_jobs((size_t)nslots_, jobs_);
-	for (int sl = 0; sl < nslots_; ++sl) {
-		res_off_[sl] = off;
-		for (int j = 0; j < nj; ++j) {
-			FillJob &J = slot_jobs[(size_t)sl][(size_t)j];
-			Extra &X = extra_[j];
-			J.summary = off;
-			X.res_summary = off - res_off_[sl];
-			off += 64;
-			J.ops = off;
-			X.res_ops = off - res_off_[sl];
-			off = align_up(off + (size_t)J.nrows + J.ncols + 64, 256);
-		}
-		res_bytes_ = off - res_off_[sl];
-		for (int j = 0; j < nj; ++j) {
-			FillJob &J = slot_jobs[(size_t)sl][(size_t)j];
-			J.state = off;
-			off = align_up(off + (size_t)J.nstrips * (C + 1 + R) * kLanes * 4, 256);
-			J.handoff = off;
-			off = align_up(off + (size_t)J.nstrips * J.hpitch * R * 4, 256);
-			J.dirs = off;
-			off = align_up(off + (size_t)J.nstrips * J.steps_pad * R * W * kLanes * 4, 256);
-		}
-	}
-	total_bytes_ = off;
-
-	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
-	for (int sl = 0; sl < nslots_; ++sl)
-		for (auto &e : ev_[sl])
-			if (!e) HIP_TRY(hipEventCreate(&e));
-	memset(h_in_, 0, in_bytes_);
-	for (int sl = 0; sl < nslots_; ++sl)
-		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(FillJob));
-	jobs_ = slot_jobs[0];
-	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
-	laid_out_ = true;
-	ran_ = false;
-	pending_ = 0;
-	memset(slot_used_, 0, sizeof(slot_used_));
-	return CSADP_OK;
+	/* every other fill (profile steps, stale borders, pairs with the bit-parallel path switched off by CSADP_BITS=0 --
+	 * the 32-bit cross-check of the bit-parallel kernels): the persistent cell-per-lane wavefront */
+	return layout_cells();
 }
 
 uint32_t *FillBatch::coltab(int j) { return reinterpret_cast<uint32_t *>(h_in_ + extra_[j].in_coltab); }
 int32_t *FillBatch::leftc(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_leftc); }
-uint8_t *FillBatch::rowshift(int j) { return h_in_ + extra_[j].in_rowshift + jobs_[j].padl; }
+uint8_t *FillBatch::rowshift(int j) { return h_in_ + extra_[j].in_rowshift; }
 int32_t *FillBatch::top(int j) { return reinterpret_cast<int32_t *>(h_in_ + extra_[j].in_top); }
-int FillBatch::ncols_pad(int j) const { return pk_ ? pextra_[(size_t)pair_of_[(size_t)j]].ncols_pad : extra_[j].ncols_pad; }
+int FillBatch::ncols_pad(int j) const { return extra_[j].ncols_pad; }
 
 /* Cell-per-lane mode (csadp_cells.hip): one CellJob per fill, a work list of (job, chunk of kCellWaves
  * strips) -- the longest jobs first, a job's chunks in ascending order -- one launch per pass. */
@@ -505,7 +368,6 @@ int FillBatch::layout_cells()
 		C.steps_pad = (int)align_up((size_t)J.nrows + 64, kCellBlock);
 		J.nstrips = C.nstrips;
 		J.steps_pad = C.steps_pad;
-		J.padl = 0;
 		extra_[(size_t)j].ncols_pad = C.nstrips * kCellStripCols;
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)C.nstrips * kCellCols * (C.steps_pad / 16) * kLanes * 4;
@@ -577,8 +439,6 @@ int FillBatch::layout_cells()
 		}
 		res_bytes_ = off - res_off_[sl];
 		sum_bytes_ = res_bytes_;
-		flags_off_[sl] = off;
-		flags_bytes_ = 0;
 		for (int j = 0; j < nj; ++j) {
 			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
 			C.dirs = off;
@@ -601,210 +461,6 @@ int FillBatch::layout_cells()
 	memcpy(h_in_ + serial_off_, serial_tiles_.data(), serial_tiles_.size() * sizeof(TileRef));
 	cjobs_ = slot_jobs[0];
 	return CSADP_OK;
-}
-
-/* Packed-16 pair mode: jobs sorted by size are paired (A = low half word, B = high half word);
- * the pair uses the geometry of the larger matrix.  Same arena structure as layout(). */
-int FillBatch::layout_pk()
-{
-	Engine &E = *E_;
-	const int C = 16, R = E.R(), TR = E.TR();
-	const int nj = (int)jobs_.size();
-	std::vector<int> order((size_t)nj);
-	for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
-	std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-		if (jobs_[(size_t)a].ncols != jobs_[(size_t)b].ncols) return jobs_[(size_t)a].ncols > jobs_[(size_t)b].ncols;
-		return jobs_[(size_t)a].nrows > jobs_[(size_t)b].nrows;
-	});
-	const int np = (nj + 1) / 2;
-	pjobs_.assign((size_t)np, PairJob());
-	pextra_.assign((size_t)np, PairExtra());
-	pair_of_.assign((size_t)nj, 0);
-	half_of_.assign((size_t)nj, 0);
-	int ndiag = 0;
-	std::vector<int> diag_count;
-	for (int p = 0; p < np; ++p) {
-		PairJob &P = pjobs_[(size_t)p];
-		memset(&P, 0, sizeof(P));
-		PairExtra &X = pextra_[(size_t)p];
-		for (int h = 0; h < 2; ++h) {
-			const int idx = 2 * p + h;
-			X.job[h] = idx < nj ? order[(size_t)idx] : -1;
-			if (X.job[h] >= 0) {
-				const FillJob &J = jobs_[(size_t)X.job[h]];
-				if (4LL * (2LL * J.nrows + J.ncols) + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
-				P.nrows[h] = J.nrows;
-				P.ncols[h] = J.ncols;
-				P.leftmul[h] = J.leftmul;
-				pair_of_[(size_t)X.job[h]] = p;
-				half_of_[(size_t)X.job[h]] = h;
-				cells_ += (long long)J.nrows * J.ncols;
-				dir_bytes_ += (long long)J.nrows * (long long)((J.ncols + C - 1) / C) * 4;
-			}
-		}
-		P.nrows_max = std::max(P.nrows[0], P.nrows[1]);
-		P.ncols_max = std::max(P.ncols[0], P.ncols[1]);
-		const int lanes = (P.ncols_max + C - 1) / C;
-		P.nstrips = (lanes + kLanes - 1) / kLanes;
-		X.ncols_pad = P.nstrips * kLanes * C;
-		const int rsteps = (P.nrows_max + R - 1) / R;
-		P.steps_pad = (int)align_up((size_t)rsteps + (size_t)kLanes * P.nstrips, TR);
-		P.hpitch = P.steps_pad + 64;
-		P.padl = R * (kLanes * P.nstrips + 64);
-		for (int s = 0; s < P.nstrips; ++s) {
-			const int a0 = (kLanes * s) / TR;
-			const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
-			ndiag = std::max(ndiag, a1 + s + 1);
-			if ((int)diag_count.size() < a1 + s + 1) diag_count.resize((size_t)(a1 + s + 1), 0);
-			for (int a = a0; a <= a1; ++a) diag_count[(size_t)(a + s)]++;
-			border_bytes_ += 2LL * 8 * (a1 - a0 + 1) * TR * R + 2LL * 4 * (a1 - a0 + 1) * (C + 3 + R) * kLanes;
-		}
-	}
-	diag_off_.assign((size_t)ndiag + 1, 0);
-	for (int d = 0; d < ndiag; ++d) diag_off_[(size_t)d + 1] = diag_off_[(size_t)d] + (size_t)diag_count[(size_t)d];
-	tiles_.assign(diag_off_[(size_t)ndiag], TileRef());
-	{
-		std::vector<size_t> cur(diag_off_.begin(), diag_off_.end() - 1);
-		for (int p = 0; p < np; ++p) {
-			const PairJob &P = pjobs_[(size_t)p];
-			const int rsteps = (P.nrows_max + R - 1) / R;
-			for (int s = 0; s < P.nstrips; ++s) {
-				const int a0 = (kLanes * s) / TR;
-				const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
-				for (int a = a0; a <= a1; ++a) {
-					TileRef t;
-					t.job = p;
-					t.a = a;
-					t.s = s;
-					t.first = (a == a0);
-					tiles_[cur[(size_t)(a + s)]++] = t;
-				}
-			}
-		}
-	}
-
-	/* strip list of the persistent kernel: strip-major, so a strip's producer is dispatched first */
-	std::vector<TileRef> strips;
-	{
-		int maxstrips = 0;
-		for (const PairJob &P : pjobs_) maxstrips = std::max(maxstrips, P.nstrips);
-		for (int s = 0; s < maxstrips; ++s)
-			for (int p = 0; p < np; ++p)
-				if (s < pjobs_[(size_t)p].nstrips) {
-					TileRef t;
-					t.job = p;
-					t.a = 0;
-					t.s = s;
-					t.first = 1;
-					strips.push_back(t);
-				}
-	}
-	nstrips_total_ = strips.size();
-	/* The persistent kernel has the lower single-pass latency (one launch, no per-tile
-	 * prologue); overlapped passes on several streams are faster with the per-diagonal
-	 * launches (measured: 8.1 vs 6.8 TCUPS on the bench batch).  CSADP_PERSIST=0/1 forces. */
-	persist_ = env_int("CSADP_PERSIST", pipelined_ && E.slots() > 1 ? 0 : 1) != 0 && (R == 1 || R == 2) && (TR == 64 || TR == 128);
-
-	nslots_ = pipelined_ ? E.slots() : 1;
-	next_slot_ = 0;
-	size_t off = 0;
-	for (int sl = 0; sl < nslots_; ++sl) {          /* one contiguous job table: slot sl starts at sl * np */
-		jobs_off_[sl] = off;
-		off += (size_t)np * sizeof(PairJob);
-	}
-	off = align_up(off, 256);
-	tiles_off_ = off;
-	off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
-	strips_off_ = off;
-	off = align_up(off + strips.size() * sizeof(TileRef), 256);
-	for (int p = 0; p < np; ++p) {
-		PairJob &P = pjobs_[(size_t)p];
-		PairExtra &X = pextra_[(size_t)p];
-		for (int h = 0; h < 2; ++h) {
-			X.in_tab[h] = P.tab[h] = off;
-			off = align_up(off + (size_t)X.ncols_pad * 4, 256);
-		}
-		X.in_rowsel = P.rowsel = off;
-		off = align_up(off + ((size_t)P.padl + (size_t)R * P.steps_pad + (size_t)R * 64 + 64) * 4, 256);
-		for (int h = 0; h < 2; ++h) {
-			X.in_top[h] = P.top[h] = off;
-			off = align_up(off + ((size_t)X.ncols_pad + 1) * 4, 256);
-		}
-	}
-	in_bytes_ = off;
-	std::vector<std::vector<PairJob>> slot_jobs((size_t)nslots_, pjobs_);
-	for (int sl = 0; sl < nslots_; ++sl) {
-		res_off_[sl] = off;
-		for (int j = 0; j < nj; ++j) {
-			const FillJob &J = jobs_[(size_t)j];
-			Extra &X = extra_[(size_t)j];
-			PairJob &P = slot_jobs[(size_t)sl][(size_t)pair_of_[(size_t)j]];
-			const int h = half_of_[(size_t)j];
-			P.summary[h] = off;
-			X.res_summary = off - res_off_[sl];
-			off += 64;
-			P.ops[h] = off;
-			X.res_ops = off - res_off_[sl];
-			off = align_up(off + (size_t)J.nrows + J.ncols + 64, 256);
-		}
-		const size_t dummy = off;                 /* unpaired high half: nothing to trace, summary goes here */
-		off += 256;
-		res_bytes_ = off - res_off_[sl];
-		flags_off_[sl] = off;                     /* [abort word, pad to 256 B | progress counters] */
-		off += 256;
-		for (int p = 0; p < np; ++p) {
-			slot_jobs[(size_t)sl][(size_t)p].progress = off;
-			off = align_up(off + (size_t)pjobs_[(size_t)p].nstrips * 4, 64);
-		}
-		off = align_up(off, 256);
-		flags_bytes_ = off - flags_off_[sl];
-		for (int p = 0; p < np; ++p) {
-			PairJob &P = slot_jobs[(size_t)sl][(size_t)p];
-			if (pextra_[(size_t)p].job[1] < 0) { P.summary[1] = dummy; P.ops[1] = dummy + 64; }
-			P.state = off;
-			off = align_up(off + (size_t)P.nstrips * (C + 3 + R) * kLanes * 4, 256);
-			P.handoff = off;
-			off = align_up(off + (size_t)P.nstrips * P.hpitch * R * 8, 256);
-			P.dirs = off;
-			off = align_up(off + (size_t)P.nstrips * P.steps_pad * R * 2 * kLanes * 4, 256);
-		}
-	}
-	total_bytes_ = off;
-
-	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
-	for (int sl = 0; sl < nslots_; ++sl)
-		for (auto &e : ev_[sl])
-			if (!e) HIP_TRY(hipEventCreate(&e));
-	memset(h_in_, 0, in_bytes_);
-	for (int p = 0; p < np; ++p) {                /* selector bytes default to 0x0c = constant zero byte */
-		const PairJob &P = pjobs_[(size_t)p];
-		memset(h_in_ + pextra_[(size_t)p].in_rowsel, 0x0c, ((size_t)P.padl + (size_t)R * P.steps_pad + (size_t)R * 64 + 64) * 4);
-	}
-	for (int sl = 0; sl < nslots_; ++sl)
-		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)np * sizeof(PairJob));
-	memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
-	memcpy(h_in_ + strips_off_, strips.data(), strips.size() * sizeof(TileRef));
-	pjobs_ = slot_jobs[0];
-	laid_out_ = true;
-	ran_ = false;
-	pending_ = 0;
-	memset(slot_used_, 0, sizeof(slot_used_));
-	return CSADP_OK;
-}
-
-uint32_t *FillBatch::pk_tab(int j)
-{
-	return reinterpret_cast<uint32_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_tab[half_of_[(size_t)j]]);
-}
-uint8_t *FillBatch::pk_rowsel(int j)
-{
-	const int p = pair_of_[(size_t)j];
-	return h_in_ + pextra_[(size_t)p].in_rowsel + (size_t)pjobs_[(size_t)p].padl * 4 + (half_of_[(size_t)j] ? 2 : 0);
-}
-int FillBatch::pk_selbase(int j) const { return half_of_[(size_t)j] ? 4 : 0; }
-int32_t *FillBatch::pk_top(int j)
-{
-	return reinterpret_cast<int32_t *>(h_in_ + pextra_[(size_t)pair_of_[(size_t)j]].in_top[half_of_[(size_t)j]]);
 }
 
 /* Bit-parallel mode: one BitJob per fill, the whole matrix in one launch (csadp_bits.hip). */
@@ -1033,8 +689,6 @@ int FillBatch::layout_bits()
 				off = align_up(off + (size_t)2 * B.rowwords * 4, 256);
 			}
 		}
-		flags_off_[sl] = off;
-		flags_bytes_ = 0;
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
 			const size_t blocks = (size_t)B.nstrips * (B.steps_pad / kBitBlock);
@@ -1203,14 +857,12 @@ int FillBatch::flush()
 	const int k = pending_;
 	pending_ = 0;
 	if (bits_) return flush_bits(k);
-	/* pass i goes to slot i % slots on that slot's own stream; kernels of different streams overlap.
-	 * (A single-stream schedule that merged the current anti-diagonal of every pass in flight into
-	 * one launch was measured slower, 5.3 vs 4.2 ms per pass, and removed.) */
+	/* cell-per-lane batches: pass i goes to slot i % slots on that slot's own stream; kernels of different streams overlap */
 	for (int i = 0; i < k; ++i) {
 		const int sl = next_slot_;
 		next_slot_ = (next_slot_ + 1) % nslots_;
 		last_slot_ = sl;
-		const int rc = run_slot(sl, pk_ && persist_);
+		const int rc = run_slot_cells(sl, false);
 		if (rc != CSADP_OK) return rc;
 	}
 	return CSADP_OK;
@@ -1366,44 +1018,6 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	return CSADP_OK;
 }
 
-int FillBatch::run_slot(int sl, bool persistent)
-{
-	Engine &E = *E_;
-	if (cells_mode_) return run_slot_cells(sl, false);
-	hipStream_t st = E.stream(sl);
-	hipEvent_t *ev = ev_[sl];
-	const FillJob *djobs = reinterpret_cast<const FillJob *>(arena_ + jobs_off_[0]);
-	const PairJob *dpairs = reinterpret_cast<const PairJob *>(arena_ + jobs_off_[0]);
-	const int per_slot = pk_ ? (int)pjobs_.size() : (int)jobs_.size();
-	if (slot_used_[sl]) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));     /* the slot's previous pass */
-	HIP_TRY(hipEventRecord(ev[0], st));
-	if (persistent) {
-		/* one launch: a wave per (pair job, strip), strips synchronise through progress counters */
-		HIP_TRY(hipMemsetAsync(arena_ + flags_off_[sl], 0, flags_bytes_, st));
-		HIP_TRY(launch_fill_strips_pk(E.R(), E.TR(), arena_, reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]),
-		                              reinterpret_cast<const TileRef *>(arena_ + strips_off_), (int)nstrips_total_,
-		                              reinterpret_cast<int *>(arena_ + flags_off_[sl]), st));
-	} else {
-		const int ndiag = (int)diag_off_.size() - 1;
-		for (int d = 0; d < ndiag; ++d) {
-			SegList segs;
-			memset(&segs, 0, sizeof(segs));
-			segs.n = 1;
-			segs.seg[0].tiles = tiles_off_ + diag_off_[(size_t)d] * sizeof(TileRef);
-			segs.seg[0].count = (int)(diag_off_[(size_t)d + 1] - diag_off_[(size_t)d]);
-			segs.seg[0].job_base = sl * per_slot;
-			if (pk_) HIP_TRY(launch_fill_pk(E.R(), E.TR(), arena_, dpairs, segs, st));
-			else HIP_TRY(launch_fill(E.C(), E.R(), E.TR(), wide_, arena_, djobs, segs, st));
-		}
-	}
-	HIP_TRY(hipEventRecord(ev[1], st));
-	if (pk_) HIP_TRY(launch_traceback_pk(E.R(), arena_, reinterpret_cast<const PairJob *>(arena_ + jobs_off_[sl]), (int)pjobs_.size(), st));
-	else HIP_TRY(launch_traceback(E.C(), E.R(), arena_, reinterpret_cast<const FillJob *>(arena_ + jobs_off_[sl]), (int)jobs_.size(), st));
-	HIP_TRY(hipEventRecord(ev[2], st));
-	slot_used_[sl] = true;
-	return CSADP_OK;
-}
-
 int FillBatch::sync()
 {
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
@@ -1456,18 +1070,6 @@ int FillBatch::download()
 		if (rc != CSADP_OK) return rc;
 	}
 	hipStream_t st = E_->stream(bits_ ? last_stream_ : last_slot_);
-	if (pk_ && persist_) {
-		/* did a bounded spin of the persistent kernel run out?  Then its directions are
-		 * incomplete: repeat the pass with the launch-per-diagonal kernels (no in-kernel waits) */
-		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + flags_off_[last_slot_], 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(hipStreamSynchronize(st));
-		if (*h_abort_ != 0) {
-			fprintf(stderr, "csadp: persistent fill kernel timed out; repeating the pass with per-diagonal launches\n");
-			persist_ = false;
-			const int rc = run_slot(last_slot_, false);
-			if (rc != CSADP_OK) return rc;
-		}
-	}
 	const size_t want = (io_ && !want_strings_) ? sum_bytes_ : res_bytes_;
 	if (bits_) st = E_->copy_stream();            /* sync() has waited for the batch: nothing to order the copy behind */
 	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], want, hipMemcpyDeviceToHost, st));

@@ -50,9 +50,6 @@ public:
 	/* result downloads and abort-word reads of batches that have finished: a stream of its own, so that they never
 	 * queue behind what LATER batches have put on the compute streams */
 	hipStream_t copy_stream() const { return copy_stream_; }
-	int C() const { return C_; }
-	int R() const { return R_; }
-	int TR() const { return TR_; }
 	int device() const { return device_; }
 	const char *name() const { return name_; }
 	int compute_units() const { return cus_; }
@@ -75,7 +72,6 @@ private:
 	bool ready_ = false;
 	bool verbose_ = false;
 	int device_ = 0;
-	int C_ = 16, R_ = 2, TR_ = 128;
 	int cus_ = 0;
 	char name_[256] = {0};
 	int slots_ = 2, nstreams_ = 0;
@@ -119,13 +115,6 @@ public:
 	uint32_t *coltab(int j);
 	int32_t *leftc(int j);
 	bool wide() const { return wide_; }   /* table format of this batch (csadp_device.h) */
-	/* packed-16 pair mode (PairJob): every job is pairwise (i = 1, fresh borders) and two jobs
-	 * share a register set.  Host tables then go through the *_pk accessors. */
-	bool packed() const { return pk_; }
-	uint32_t *pk_tab(int j);
-	uint8_t *pk_rowsel(int j);         /* byte of row 1, element stride 4 */
-	int pk_selbase(int j) const;       /* 0 for the low half, 4 for the high half */
-	int32_t *pk_top(int j);
 	/* bit-parallel mode (BitJob): every job is a first fill with unit borders (the caller vouches
 	 * for the borders with allow_bits) and at most kBitMaxStrips*2048 columns wide.  Host tables:
 	 * two bit planes of the column letters and two of the row letters. */
@@ -171,7 +160,6 @@ public:
 private:
 	Engine *E_;
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
-	struct PairExtra { int ncols_pad; int job[2]; size_t in_tab[2], in_rowsel, in_top[2]; };
 	struct BitExtra { size_t in_cols, in_rows; size_t res_out[2]; };
 	struct TextRef { const char *ptr; int size; size_t off; };
 	struct PairIo { int text[2], first[2]; };
@@ -179,7 +167,6 @@ private:
 	std::vector<PairIo> pairio_;
 	bool io_ = false, want_strings_ = true;
 	size_t sum_bytes_ = 0;             /* leading part of a slot's result region that holds the summaries */
-	int layout_pk();
 	int layout_bits();
 	int layout_cells();
 	int run_slot_cells(int sl, bool serial);
@@ -206,16 +193,6 @@ private:
 	std::vector<BitExtra> bextra_;
 	bool bits_ = false, bits_allowed_ = false, bits_wide_ = false, want_scores_ = false;
 	int bits_maxstrips_ = 1, bits_chunk_ = kBitMaxStrips;
-	int run_slot(int sl, bool persistent);
-	std::vector<PairJob> pjobs_;
-	std::vector<PairExtra> pextra_;
-	std::vector<int> pair_of_, half_of_;
-	bool pk_ = false;
-	/* persistent packed kernel: strip list (strip-major), per-slot flag region
-	 * [abort word | progress counters], zeroed by a memset node before every pass */
-	size_t strips_off_ = 0, nstrips_total_ = 0;
-	size_t flags_off_[Engine::kMaxSlots] = {}, flags_bytes_ = 0;
-	bool persist_ = false;
 	int *h_abort_ = nullptr;
 	std::vector<FillJob> jobs_;
 	std::vector<Extra> extra_;

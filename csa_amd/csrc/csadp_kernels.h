@@ -1,4 +1,4 @@
-/* csadp_kernels.h -- host-callable launchers of the HIP kernels (csadp_kernels.hip). */
+/* csadp_kernels.h -- host-callable launchers of the HIP kernels (csadp_bits.hip, csadp_cells.hip, csadp_pairio.hip, csadp_kernels.hip). */
 #ifndef CSADP_KERNELS_H
 #define CSADP_KERNELS_H
 
@@ -8,26 +8,6 @@
 
 namespace csadp {
 
-/* Launch the tiles of one or more tile anti-diagonals (one segment per pass in flight) as
- * single-wave workgroups.  C = columns per lane (16 or 32), R = rows per lane-step (1, 2 or 4),
- * TR = steps per tile (64, 128 or 256); wide = 6-bit count fields (needed when some job has
- * i >= 32), else pre-scaled bytes. */
-hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, hipStream_t st);
-
-/* Launch the direction walk: one wave per job. */
-hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st);
-
-/* Packed-16 pair mode (PairJob): C is fixed to 16 columns per lane. */
-hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const SegList &segs, hipStream_t st);
-/* persistent variant: one launch per pass, one wave per (pair job, strip); strips must be sorted
- * strip-major; *abort_word (zeroed before the launch) is set if a bounded spin ran out.
- * Supported: R in {1,2}, TR in {64,128}. */
-hipError_t launch_fill_strips_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *strips, int nstrips,
-                                 int *abort_word, hipStream_t st);
-hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int npairs, hipStream_t st);
-
-/* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;
- * chars = nseq x length bytes, sequence-major; out must be zeroed. */
 /* csadp_bits.hip: bit-parallel first fills and their traceback; words = 32-column words per lane (1, 2 or 4: BitJob::wpl
  * of every job of the table).  One workgroup per job (at most 16 strips each) ... */
 hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st);
@@ -52,6 +32,8 @@ hipError_t launch_pack_planes(uint8_t *arena, const BitJob *jobs, int njobs, hip
 hipError_t launch_expand_rows(uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st);
 /* once per device (function attributes), with that device current */
 hipError_t configure_kernels();
+/* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;
+ * chars = nseq x length bytes, sequence-major; out must be zeroed. */
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st);
 
 }  // namespace csadp

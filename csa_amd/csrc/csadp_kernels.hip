@@ -1,30 +1,8 @@
 /*
- * csadp_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the DP hot path.
- *
- *   nw_fill_tiles   K1: the fill of dynamicprogramming.c:990-1029 (int32 max-of-3 with the
- *                   reference's D >= L >= U tie-break), directions packed 2 bit/cell.
- *   nw_traceback    K2: the direction walk of dynamicprogramming.c:1037-1047 / :1072-1114,
- *                   emitting one op per visited cell; the host applies the ops to the
- *                   strings and the profile (csadp_progressive.c).
- *
- * Mapping.  A wave owns a strip of 64*C columns; lane l keeps the C cells of its columns of
- * the previous row in registers.  The wave is skewed: at global step T lane L (global lane
- * index over all strips) computes the R rows R*(T-L) .. R*(T-L)+R-1, so the left
- * neighbour's values of the same rows were produced one step earlier and arrive with one
- * cross-lane instruction per row (v_mov_b32_dpp wave_shr:1); lane 0 takes the values of the
- * previous strip (or the border column) through the DPP "old" operand, pre-loaded from
- * LDS.  A tile is TR consecutive steps of one strip -- a parallelogram in (row, column) space, so there is no per-tile
- * pipeline ramp; the ramp exists once per matrix.  Tile (a, s) needs tiles (a-1, s) [lane
- * registers, via FillJob::state] and (a, s-1), (a-1, s-1) [right edge, via
- * FillJob::handoff]: the host launches one grid per tile anti-diagonal a+s, for all tasks
- * of a batch at once; no workgroup waits on another inside a launch.
- *
- * Per cell: v_bfe_u32 (diag gain of the row letter) + 2 v_add (diag, left; the up move is
- * free in the gain form of csadp_device.h) + v_max3_i32 + v_alignbit_b32 (shift the 2-bit
- * tag into the direction word) + v_and (clear the tag) = 6 VALU instructions, 18 issue
- * cycles per 64 cells on gfx950 (bfe/max3/alignbit are half rate: tools/valu_microbench.hip).
- * Directions are stored in the order they are produced (strip, step, row, lane): coalesced
- * 256-byte stores; the traceback kernel addresses the same layout.
+ * csadp_kernels.hip -- column statistics of a finished alignment on the device (tools.c:194-293,
+ * CalculateSumOfPairsScore): SURVEY 8(f-4).  gfx950, wave64.  The matrix fills live in csadp_bits.hip
+ * (bit-parallel first fills) and csadp_cells.hip (every other fill); the tiled 32-bit and packed-16
+ * families of rounds 1-2 were reachable only through environment switches and were retired in round 3.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -33,807 +11,6 @@
 #include "csadp_kernels.h"
 
 namespace csadp {
-
-#define DPP_WAVE_SHR1 0x138
-
-/* block index -> (tile, first job of its pass): a launch carries up to kMaxSegs tile lists */
-__device__ __forceinline__ TileRef resolve_tile(const uint8_t *arena, const SegList &segs, int *job_base)
-{
-	int b = blockIdx.x, i = 0;
-	while (i + 1 < segs.n && b >= segs.seg[i].count) {
-		b -= segs.seg[i].count;
-		++i;
-	}
-	*job_base = segs.seg[i].job_base;
-	return reinterpret_cast<const TileRef *>(arena + segs.seg[i].tiles)[b];
-}
-
-static int seg_tiles(const SegList &segs)     /* host: grid size of a launch */
-{
-	int n = 0;
-	for (int i = 0; i < segs.n; ++i) n += segs.seg[i].count;
-	return n;
-}
-
-/*
- * TR steps of one strip.  One step = R consecutive rows x C columns per lane.  The R rows
- * form R dependency chains that run one column apart (row rho works on column j while row
- * rho+1 works on column j-1), so a single wave always has R independent instruction
- * streams in flight -- the integer ops of the recurrence issue at one per ~9 cycles when
- * dependent and one per 4-5 cycles when independent on gfx950 (tools/valu_microbench.hip).
- *
- * RAMP = the strip's first tile: lanes whose row index is still negative must keep the
- * border values they were initialised with, so the cell block is predicated.  All other
- * tiles (STEADY) run the cell block unconditionally: lanes that have passed the last row
- * compute values nobody reads (dependencies only point up and left), which removes the
- * per-step branch and the register copies it forces.  LDS operands of step t+1 (lane-0
- * feed, row letters) are fetched during step t.
- */
-template <int C, int R, int TR, bool WIDE, bool RAMP>
-__device__ __forceinline__ void fill_steps(const uint32_t (&tab)[C], const int32_t (&leftc)[C], int32_t (&hup)[C],
-                                           int32_t &diag_in, int32_t (&last)[R], const int32_t *feed,
-                                           const uint8_t *myrsh, int32_t *edge, uint32_t *dirs, int r0s,
-                                           int lane)
-{
-	constexpr int W = C / 16;
-	int32_t fnext[R];
-	uint32_t snext[R];
-#pragma unroll
-	for (int q = 0; q < R; ++q) {
-		fnext[q] = feed[q];
-		snext[q] = myrsh[q];
-	}
-#pragma unroll 2
-	for (int t = 0; t < TR; ++t) {
-		int32_t inl[R];
-		uint32_t sh[R];
-		/* right edge of the strip after the PREVIOUS step: written first so that the wait for
-		 * this step's LDS reads (issued next, consumed a whole step later) also covers it */
-		if (t > 0 && lane == kLanes - 1) {
-#pragma unroll
-			for (int q = 0; q < R; ++q) edge[(t - 1) * R + q] = last[q];
-		}
-#pragma unroll
-		for (int q = 0; q < R; ++q) {
-			sh[q] = snext[q];
-			inl[q] = __builtin_amdgcn_update_dpp(fnext[q], last[q], DPP_WAVE_SHR1, 0xf, 0xf, false);
-		}
-#pragma unroll
-		for (int q = 0; q < R; ++q) {
-			fnext[q] = feed[(t + 1) * R + q];
-			snext[q] = myrsh[(t + 1) * R + q];
-		}
-		uint32_t acc[R][W];
-#pragma unroll
-		for (int q = 0; q < R; ++q)
-#pragma unroll
-			for (int w = 0; w < W; ++w) acc[q][w] = 0;
-		if (!RAMP || r0s + t >= 0) {
-			int32_t cd[R], cl[R];
-			cd[0] = diag_in;
-#pragma unroll
-			for (int q = 1; q < R; ++q) cd[q] = inl[q - 1];
-#pragma unroll
-			for (int q = 0; q < R; ++q) cl[q] = inl[q];
-			/* skewed sweep: iteration i touches cell (row q, column i - q) of every row */
-#pragma unroll
-			for (int i = 0; i < C + R - 1; ++i) {
-#pragma unroll
-				for (int q = 0; q < R; ++q) {
-					const int c = i - q;
-					if (c < 0 || c >= C) continue;
-					int32_t dg;
-					if constexpr (WIDE) {      /* i >= 32: 6-bit counts, gain = 8*sv + 2 */
-						const uint32_t f = __builtin_amdgcn_ubfe(tab[c], sh[q], 6);
-						dg = (int32_t)(f << 3) + cd[q] + 2;
-					} else {                   /* pre-scaled byte 8*sv + 2 */
-						dg = cd[q] + (int32_t)__builtin_amdgcn_ubfe(tab[c], sh[q], 8);
-					}
-					const int32_t lf = cl[q] + leftc[c];
-					int32_t h = max(max(dg, hup[c]), lf);
-					acc[q][c / 16] = __builtin_amdgcn_alignbit((uint32_t)h, acc[q][c / 16], 2);
-					cd[q] = hup[c];
-					h &= ~3;
-					hup[c] = h;
-					cl[q] = h;
-				}
-			}
-#pragma unroll
-			for (int q = 0; q < R; ++q) last[q] = cl[q];
-		}
-		diag_in = inl[R - 1];
-#pragma unroll
-		for (int q = 0; q < R; ++q)
-#pragma unroll
-			for (int w = 0; w < W; ++w) dirs[((size_t)t * R + q) * (W * kLanes) + w * kLanes] = acc[q][w];
-	}
-	if (lane == kLanes - 1) {
-#pragma unroll
-		for (int q = 0; q < R; ++q) edge[(TR - 1) * R + q] = last[q];
-	}
-}
-
-template <int C, int R, int TR, bool WIDE>
-__global__ __launch_bounds__(64) void nw_fill_tiles(uint8_t *__restrict__ arena,
-                                                    const FillJob *__restrict__ jobs, const SegList segs)
-{
-	static_assert(C % 16 == 0, "a lane-step must fill whole direction words");
-	static_assert(TR % 64 == 0, "tile inputs are staged 64 lanes at a time");
-	static_assert(R == 1 || R == 2 || R == 4, "rows per step");
-	constexpr int W = C / 16;
-
-	__shared__ __attribute__((aligned(16))) int32_t feed[R * (TR + 1) + 4];    /* lane-0 inputs        */
-	__shared__ __attribute__((aligned(16))) int32_t edge[R * TR];              /* lane-63 outputs      */
-	__shared__ __attribute__((aligned(16))) uint8_t rsh[R * (TR + 64) + 16];   /* 6*code of tile rows  */
-
-	int job_base;
-	const TileRef tr = resolve_tile(arena, segs, &job_base);
-	const FillJob &J = jobs[job_base + tr.job];
-	const int lane = threadIdx.x;
-	const int s = tr.s;
-	const int T0 = tr.a * TR;
-	const int L = s * kLanes + lane;
-
-	/* ---- stage the tile inputs in LDS ------------------------------------------------ */
-	if (s == 0) {
-		const int lm = J.leftmul;                 /* border column: X[r][0] = leftmul * r */
-		for (int e = lane; e < R * TR; e += kLanes) feed[e] = lm * (R * T0 + e + 1);
-	} else {
-		/* value after step T-1 of row q sits at index R*T + q */
-		const int32_t *h = reinterpret_cast<const int32_t *>(arena + J.handoff) + ((size_t)(s - 1) * J.hpitch + T0) * R;
-		for (int e = lane; e < R * TR; e += kLanes) feed[e] = h[e];
-	}
-	{
-		/* rsh[j] holds row R*(T0 - 64*s - 64) + j; lane l at local step t, row q reads
-		 * j = R*(t + 64 - l) + q */
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowshift + (J.padl + R * (T0 - s * kLanes - 64)));
-		uint32_t *dst = reinterpret_cast<uint32_t *>(rsh);
-		for (int j = lane; j < R * (TR + 64) / 4; j += kLanes) dst[j] = src[j];
-	}
-
-	/* ---- per-lane column tables and the row above, in registers ----------------------- */
-	uint32_t tab[C];
-	int32_t leftc[C];
-	int32_t hup[C];
-	int32_t diag_in, last[R];
-	{
-		const uint32_t *ct = reinterpret_cast<const uint32_t *>(arena + J.coltab) + (size_t)L * C;
-		const int32_t *lc = reinterpret_cast<const int32_t *>(arena + J.leftc) + (size_t)L * C;
-#pragma unroll
-		for (int c = 0; c < C; ++c) {
-			tab[c] = ct[c];
-			leftc[c] = lc[c];
-		}
-	}
-	int32_t *st = reinterpret_cast<int32_t *>(arena + J.state) + (size_t)s * (C + 1 + R) * kLanes + lane;
-	if (tr.first) {
-		const int32_t *tp = reinterpret_cast<const int32_t *>(arena + J.top) + (size_t)L * C;     /* tp[0] = column left of the lane's first */
-		diag_in = tp[0];
-#pragma unroll
-		for (int c = 0; c < C; ++c) hup[c] = tp[c + 1];
-#pragma unroll
-		for (int q = 0; q < R; ++q) last[q] = hup[C - 1];
-	} else {
-#pragma unroll
-		for (int c = 0; c < C; ++c) hup[c] = st[c * kLanes];
-		diag_in = st[C * kLanes];
-#pragma unroll
-		for (int q = 0; q < R; ++q) last[q] = st[(C + 1 + q) * kLanes];
-	}
-	__syncthreads();
-
-	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (R * W * kLanes) + lane;
-	const uint8_t *myrsh = rsh + R * (64 - lane);
-	const int r0s = T0 - L;                           /* step-units row index of this lane at local step 0 */
-
-	if (tr.first)
-		fill_steps<C, R, TR, WIDE, true>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, lane);
-	else
-		fill_steps<C, R, TR, WIDE, false>(tab, leftc, hup, diag_in, last, feed, myrsh, edge, dirs, r0s, lane);
-
-#pragma unroll
-	for (int c = 0; c < C; ++c) st[c * kLanes] = hup[c];
-	st[C * kLanes] = diag_in;
-#pragma unroll
-	for (int q = 0; q < R; ++q) st[(C + 1 + q) * kLanes] = last[q];
-	__syncthreads();
-	{
-		/* value after step T is read by the next strip at index R*(T+1) + q */
-		int32_t *hand = reinterpret_cast<int32_t *>(arena + J.handoff) + ((size_t)s * J.hpitch + T0 + 1) * R;
-		for (int e = lane; e < R * TR; e += kLanes) hand[e] = edge[e];
-	}
-}
-
-/*
- * K2.  One wave per fill.  The walk of dynamicprogramming.c:1037-1047 is serial, but on real
- * sequences it is dominated by long diagonal runs, and a diagonal run is predictable: its
- * i-th cell is (r-i, k-i).  Every iteration lane i looks up the direction code of that cell
- * (in a TALL, NARROW LDS window of WT steps x 16 direction-word columns -- in (step, word)
- * storage coordinates a diagonal is almost vertical) and a ballot finds the first lane whose
- * cell is not 'D' (or lies outside the window / on a border): all cells before it are
- * emitted as one coalesced run of 'D' ops; a single 'L' or 'U' op is then taken by lane 0's
- * code.  Cost is per RUN, not per cell.
- */
-template <int C, int R>
-__global__ __launch_bounds__(64) void nw_traceback(uint8_t *__restrict__ arena,
-                                                   const FillJob *__restrict__ jobs)
-{
-	constexpr int W = C / 16;          /* direction words per lane and row                  */
-	constexpr int WQ = 16;             /* word columns per window (16 matrix columns each)   */
-	constexpr int RW = R * WQ;         /* words per window step                              */
-	constexpr int WT = 16384 / RW;     /* steps per window: 64 KiB of direction words        */
-	/* The window is skewed along the main diagonal: d cells down a perfect diagonal the step
-	 * drops by d/R + d/(16W) and the word column by d/16, so window step i starts
-	 * skew(i) = i*R / (16W + R) word columns further left (rounded down to a multiple of 4 to
-	 * keep 16-byte loads aligned).  The current cell enters 8..11 columns from the left
-	 * edge, leaving +-128 matrix columns of slack for indels before a reload. */
-	__shared__ __attribute__((aligned(16))) uint32_t win[WT * RW];
-
-	const FillJob &J = jobs[blockIdx.x];
-	uint8_t *ops = arena + J.ops;
-	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
-	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
-	const int lane = threadIdx.x;
-	const size_t strip_words = (size_t)J.steps_pad * (R * W * kLanes);
-	const int qmax = J.nstrips * kLanes * W;               /* allocated word columns */
-	int r = J.nrows, k = J.ncols;
-	int n = 0;
-
-	while (r > 0 && k > 0) {
-		const int q0 = (k - 1) >> 4;                       /* word column of the current cell */
-		const int Ttop = (r - 1) / R + q0 / W;             /* its step                         */
-		const int qbase = (q0 & ~3) - 8;
-		if constexpr (W == 1) {
-			/* 16-byte loads: unit u = (step i, row, group of 4 word columns) */
-			constexpr int UNITS = WT * RW / 4;
-			constexpr int BATCH = 16;
-			for (int b0 = 0; b0 < UNITS / kLanes; b0 += BATCH) {
-				uint4 v[BATCH];
-#pragma unroll
-				for (int b = 0; b < BATCH; ++b) {
-					const int u = (b0 + b) * kLanes + lane;
-					const int i = u / (4 * R);
-					const int row = (u / 4) % R;
-					const int T = Ttop - i;
-					const int q = qbase - (((i * R) / (16 * W + R)) & ~3) + 4 * (u % 4);
-					v[b] = make_uint4(0, 0, 0, 0);
-					if (T >= 0 && q >= 0 && q < qmax)
-						v[b] = *reinterpret_cast<const uint4 *>(dirs + (size_t)(q >> 6) * strip_words +
-						                                        ((size_t)T * R + row) * kLanes + (q & 63));
-				}
-#pragma unroll
-				for (int b = 0; b < BATCH; ++b)
-					reinterpret_cast<uint4 *>(win)[(b0 + b) * kLanes + lane] = v[b];
-			}
-		} else {
-			for (int it = 0; it < WT * RW / kLanes; ++it) {
-				const int e = it * kLanes + lane;
-				const int i = e / RW;
-				const int T = Ttop - i;
-				const int row = (e / WQ) % R;
-				const int q = qbase - (((i * R) / (16 * W + R)) & ~3) + e % WQ;
-				uint32_t v = 0;
-				if (T >= 0 && q >= 0 && q < qmax) {
-					const int Lg = q / W;
-					v = dirs[(size_t)(Lg >> 6) * strip_words + (((size_t)T * R + row) * W + (q - Lg * W)) * kLanes + (Lg & 63)];
-				}
-				win[e] = v;
-			}
-		}
-		__syncthreads();
-		for (;;) {
-			/* lane i inspects the i-th cell of the diagonal through (r, k) */
-			const int ri = r - lane, ki = k - lane;
-			uint32_t code = 3;                             /* 3 = stop: border or outside window */
-			if (ri > 0 && ki > 0) {
-				const int kc = ki - 1;
-				const int q = kc >> 4;
-				const int i = Ttop - ((ri - 1) / R + q / W);
-				if (i >= 0 && i < WT) {
-					const int j = q - (qbase - (((i * R) / (16 * W + R)) & ~3));
-					if (j >= 0 && j < WQ) {
-						const uint32_t word = win[(i * R + (ri - 1) % R) * WQ + j];
-						code = (word >> (2 * (kc & 15))) & 3u;
-					}
-				}
-			}
-			const unsigned long long stop = __ballot(code != DIR_D);
-			const int run = stop ? __builtin_ctzll(stop) : kLanes;
-			if (run > 0) {
-				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
-				n += run;
-				r -= run;
-				k -= run;
-				continue;
-			}
-			const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
-			if (c0 == 3) break;                            /* border reached or window exhausted */
-			if (lane == 0) ops[n] = (uint8_t)c0;
-			++n;
-			if (c0 == DIR_L) --k; else --r;
-		}
-		__syncthreads();
-	}
-	if (lane == 0) {
-		summary[0] = n;
-		summary[1] = r;
-		summary[2] = k;
-		summary[3] = 0;
-	}
-}
-
-/* =========================================================================================
- * Packed-16 pair mode (PairJob, csadp_device.h): the same skewed wavefront, two pairwise
- * matrices per register.  Per 2 cells: v_perm_b32 (both diag gains in one byte permute),
- * v_pk_add_i16 x2, v_pk_max_i16 x2, v_and (tags), v_lshl_add (pack 2 bits of both
- * matrices), v_and (clear tags) = 8 VALU instructions.
- * ========================================================================================= */
-
-typedef short pk16 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
-{
-	return __builtin_bit_cast(uint32_t, (pk16)(__builtin_bit_cast(pk16, a) + __builtin_bit_cast(pk16, b)));
-}
-__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b)
-{
-	return __builtin_bit_cast(uint32_t, (pk16)(__builtin_bit_cast(pk16, a) - __builtin_bit_cast(pk16, b)));
-}
-__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b)
-{
-	return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk16, a), __builtin_bit_cast(pk16, b)));
-}
-__device__ __forceinline__ uint32_t pk_pack(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
-__device__ __forceinline__ int pk_lo(uint32_t v) { return (int)(short)(v & 0xffffu); }
-__device__ __forceinline__ int pk_hi(uint32_t v) { return (int)v >> 16; }
-
-constexpr int CP = 16;                 /* columns per lane in packed mode */
-
-/* left gain of a pairwise fill: the seed sequence carries no gaps, so 4*(sv[4]-i)+1 = -3 in
- * every column of both matrices */
-constexpr uint32_t kLeftGainPk = 0xfffdfffdu;
-
-template <int R, int TR, bool RAMP>
-__device__ __forceinline__ void fill_steps_pk(const uint32_t (&tabA)[CP], const uint32_t (&tabB)[CP],
-                                              uint32_t (&hup)[CP], uint32_t &diag_in,
-                                              uint32_t (&last)[R], const uint32_t *feed, const uint32_t *mysel,
-                                              uint32_t *edge, uint32_t *dirs, int r0s, int lane)
-{
-	uint32_t fnext[R], snext[R];
-	/* the tag mask is made opaque so that the compiler keeps "(acc << 2) + tags" as ONE
-	 * v_lshl_add_u32 instead of proving the operands disjoint and splitting it into shift + or */
-	uint32_t tagmask = 0x00030003u;
-	asm volatile("" : "+v"(tagmask));
-	const uint32_t leftgain = kLeftGainPk;
-#pragma unroll
-	for (int q = 0; q < R; ++q) {
-		fnext[q] = feed[q];
-		snext[q] = mysel[q];
-	}
-#pragma unroll 2
-	for (int t = 0; t < TR; ++t) {
-		uint32_t inl[R], sel[R];
-		if (t > 0 && lane == kLanes - 1) {
-#pragma unroll
-			for (int q = 0; q < R; ++q) edge[(t - 1) * R + q] = last[q];
-		}
-#pragma unroll
-		for (int q = 0; q < R; ++q) {
-			sel[q] = snext[q];
-			inl[q] = (uint32_t)__builtin_amdgcn_update_dpp((int)fnext[q], (int)last[q], DPP_WAVE_SHR1, 0xf, 0xf, false);
-		}
-#pragma unroll
-		for (int q = 0; q < R; ++q) {
-			fnext[q] = feed[(t + 1) * R + q];
-			snext[q] = mysel[(t + 1) * R + q];
-		}
-		uint32_t acc[R][2];
-#pragma unroll
-		for (int q = 0; q < R; ++q) acc[q][0] = acc[q][1] = 0;
-		if (!RAMP || r0s + t >= 0) {
-			uint32_t cd[R], cl[R];
-			cd[0] = diag_in;
-#pragma unroll
-			for (int q = 1; q < R; ++q) cd[q] = inl[q - 1];
-#pragma unroll
-			for (int q = 0; q < R; ++q) cl[q] = inl[q];
-#pragma unroll
-			for (int i = 0; i < CP + R - 1; ++i) {
-#pragma unroll
-				for (int q = 0; q < R; ++q) {
-					const int c = i - q;
-					if (c < 0 || c >= CP) continue;
-					const uint32_t g = __builtin_amdgcn_perm(tabB[c], tabA[c], sel[q]);   /* gain of A | gain of B << 16 */
-					const uint32_t dg = pk_add(cd[q], g);
-					const uint32_t lf = pk_add(cl[q], leftgain);
-					uint32_t h = pk_max(pk_max(dg, hup[c]), lf);
-					acc[q][c / 8] = (acc[q][c / 8] << 2) + (h & tagmask);       /* v_lshl_add_u32 */
-					cd[q] = hup[c];
-					h &= 0xfffcfffcu;
-					hup[c] = h;
-					cl[q] = h;
-				}
-			}
-#pragma unroll
-			for (int q = 0; q < R; ++q) last[q] = cl[q];
-		}
-		diag_in = inl[R - 1];
-#pragma unroll
-		for (int q = 0; q < R; ++q)
-			*reinterpret_cast<uint2 *>(dirs + ((size_t)t * R + q) * (2 * kLanes)) = make_uint2(acc[q][0], acc[q][1]);
-	}
-	if (lane == kLanes - 1) {
-#pragma unroll
-		for (int q = 0; q < R; ++q) edge[(TR - 1) * R + q] = last[q];
-	}
-}
-
-template <int R, int TR>
-__global__ __launch_bounds__(64, 4) void nw_fill_tiles_pk(uint8_t *__restrict__ arena,
-                                                       const PairJob *__restrict__ jobs, const SegList segs)
-{
-	constexpr int NST = CP + 1 + R + 2;                                        /* state words per lane */
-	__shared__ __attribute__((aligned(16))) uint32_t feed[R * (TR + 1) + 4];   /* lane-0 inputs (packed) */
-	__shared__ __attribute__((aligned(16))) uint32_t edge[R * TR];             /* lane-63 outputs        */
-	__shared__ __attribute__((aligned(16))) uint32_t selb[R * (TR + 64) + 16]; /* row selectors          */
-
-	int job_base;
-	const TileRef tr = resolve_tile(arena, segs, &job_base);
-	const PairJob &J = jobs[job_base + tr.job];
-	const int lane = threadIdx.x;
-	const int s = tr.s;
-	const int T0 = tr.a * TR;
-	const int L = s * kLanes + lane;
-
-	{
-		const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowsel) + (J.padl + R * (T0 - s * kLanes - 64));
-		for (int j = lane; j < R * (TR + 64); j += kLanes) selb[j] = src[j];
-	}
-
-	uint32_t tabA[CP], tabB[CP], hup[CP];
-	uint32_t diag_in, last[R];
-	int32_t baseA, baseB;
-	{
-		const uint32_t *ta = reinterpret_cast<const uint32_t *>(arena + J.tab[0]) + (size_t)L * CP;
-		const uint32_t *tb = reinterpret_cast<const uint32_t *>(arena + J.tab[1]) + (size_t)L * CP;
-#pragma unroll
-		for (int c = 0; c < CP; ++c) {
-			tabA[c] = ta[c];
-			tabB[c] = tb[c];
-		}
-	}
-	uint32_t *st = reinterpret_cast<uint32_t *>(arena + J.state) + (size_t)s * NST * kLanes + lane;
-	if (tr.first) {
-		const int32_t *tpa = reinterpret_cast<const int32_t *>(arena + J.top[0]) + (size_t)L * CP;
-		const int32_t *tpb = reinterpret_cast<const int32_t *>(arena + J.top[1]) + (size_t)L * CP;
-		/* base of the strip = border value left of its first column (wave-uniform) */
-		baseA = reinterpret_cast<const int32_t *>(arena + J.top[0])[(size_t)s * kLanes * CP];
-		baseB = reinterpret_cast<const int32_t *>(arena + J.top[1])[(size_t)s * kLanes * CP];
-		diag_in = pk_pack(tpa[0] - baseA, tpb[0] - baseB);
-#pragma unroll
-		for (int c = 0; c < CP; ++c) hup[c] = pk_pack(tpa[c + 1] - baseA, tpb[c + 1] - baseB);
-#pragma unroll
-		for (int q = 0; q < R; ++q) last[q] = hup[CP - 1];
-	} else {
-#pragma unroll
-		for (int c = 0; c < CP; ++c) hup[c] = st[c * kLanes];
-		diag_in = st[CP * kLanes];
-#pragma unroll
-		for (int q = 0; q < R; ++q) last[q] = st[(CP + 1 + q) * kLanes];
-		baseA = (int32_t)st[(CP + 1 + R) * kLanes];
-		baseB = (int32_t)st[(CP + 2 + R) * kLanes];
-		/* re-centre: move both bases to the value held by the middle lane */
-		const uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)hup[CP / 2], kLanes / 2);
-		const int dA = pk_lo(rep) & ~3, dB = pk_hi(rep) & ~3;
-		const uint32_t delta = pk_pack(dA, dB);
-		baseA += dA;
-		baseB += dB;
-#pragma unroll
-		for (int c = 0; c < CP; ++c) hup[c] = pk_sub(hup[c], delta);
-		diag_in = pk_sub(diag_in, delta);
-#pragma unroll
-		for (int q = 0; q < R; ++q) last[q] = pk_sub(last[q], delta);
-	}
-	/* lane-0 inputs of this tile, converted from absolute X to this tile's bases */
-	if (s == 0) {
-		const int la = J.leftmul[0], lb = J.leftmul[1];
-		for (int e = lane; e < R * TR; e += kLanes) {
-			const int r = R * T0 + e + 1;
-			feed[e] = pk_pack(la * r - baseA, lb * r - baseB);
-		}
-	} else {
-		const int2 *h = reinterpret_cast<const int2 *>(arena + J.handoff) + ((size_t)(s - 1) * J.hpitch + T0) * R;
-		for (int e = lane; e < R * TR; e += kLanes) {
-			const int2 v = h[e];
-			feed[e] = pk_pack(v.x - baseA, v.y - baseB);
-		}
-	}
-	__syncthreads();
-
-	uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (R * 2 * kLanes) + lane * 2;
-	const uint32_t *mysel = selb + R * (64 - lane);
-	const int r0s = T0 - L;
-
-	if (tr.first)
-		fill_steps_pk<R, TR, true>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
-	else
-		fill_steps_pk<R, TR, false>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
-
-#pragma unroll
-	for (int c = 0; c < CP; ++c) st[c * kLanes] = hup[c];
-	st[CP * kLanes] = diag_in;
-#pragma unroll
-	for (int q = 0; q < R; ++q) st[(CP + 1 + q) * kLanes] = last[q];
-	st[(CP + 1 + R) * kLanes] = (uint32_t)baseA;
-	st[(CP + 2 + R) * kLanes] = (uint32_t)baseB;
-	__syncthreads();
-	{
-		int2 *hand = reinterpret_cast<int2 *>(arena + J.handoff) + ((size_t)s * J.hpitch + T0 + 1) * R;
-		for (int e = lane; e < R * TR; e += kLanes) {
-			const uint32_t v = edge[e];
-			hand[e] = make_int2(pk_lo(v) + baseA, pk_hi(v) + baseB);
-		}
-	}
-}
-
-/*
- * Persistent variant: ONE launch per pass, one single-wave workgroup per (pair job, strip),
- * dispatched strip-major so that a strip's producer (the strip to its left) always has a
- * lower block index.  A strip keeps its lane registers for the whole matrix and hands its
- * right edge to the next strip chunk by chunk (TR steps): payload with agent-scope (sc1)
- * stores, every lane drains (s_waitcnt vmcnt(0)), one lane publishes the chunk counter; the
- * consumer polls that ONE word relaxed, issues ONE agent-scope acquire, then reads the payload
- * with agent-scope loads (cdna_hip_programming.md, Guideline 16, R1).  Every spin is bounded:
- * on a timeout (or when another wave raised it) the abort word is set, all waves drain, and the
- * host repeats the pass with the launch-per-diagonal kernels -- the result never depends on
- * dispatch order, only the speed does.
- */
-#define CSADP_SPIN_LIMIT (1 << 22)
-
-template <int R, int TR>
-__global__ __launch_bounds__(64, 4) void nw_fill_strips_pk(uint8_t *__restrict__ arena,
-                                                           const PairJob *__restrict__ jobs,
-                                                           const TileRef *__restrict__ strips,
-                                                           int *__restrict__ abort_word)
-{
-	__shared__ __attribute__((aligned(16))) uint32_t feed[R * (TR + 1) + 4];
-	__shared__ __attribute__((aligned(16))) uint32_t edge[R * TR];
-	__shared__ __attribute__((aligned(16))) uint32_t selb[R * (TR + 64) + 16];
-
-	const TileRef tr = strips[blockIdx.x];
-	const PairJob &J = jobs[tr.job];
-	const int lane = threadIdx.x;
-	const int s = tr.s;
-	const int L = s * kLanes + lane;
-	const int rsteps = (J.nrows_max + R - 1) / R;
-	const int a0 = (kLanes * s) / TR;
-	const int a1 = (rsteps - 1 + kLanes * s + 63) / TR;
-	const int pa1 = s > 0 ? (rsteps - 1 + kLanes * (s - 1) + 63) / TR : 0;     /* producer's last chunk */
-	int *progress = reinterpret_cast<int *>(arena + J.progress);
-	unsigned long long *hand_out = reinterpret_cast<unsigned long long *>(arena + J.handoff) + (size_t)s * J.hpitch * R;
-	const unsigned long long *hand_in =
-	    reinterpret_cast<const unsigned long long *>(arena + J.handoff) + (size_t)(s > 0 ? s - 1 : 0) * J.hpitch * R;
-
-	uint32_t tabA[CP], tabB[CP], hup[CP];
-	uint32_t diag_in, last[R];
-	int32_t baseA, baseB;
-	{
-		const uint32_t *ta = reinterpret_cast<const uint32_t *>(arena + J.tab[0]) + (size_t)L * CP;
-		const uint32_t *tb = reinterpret_cast<const uint32_t *>(arena + J.tab[1]) + (size_t)L * CP;
-		const int32_t *tpa = reinterpret_cast<const int32_t *>(arena + J.top[0]) + (size_t)L * CP;
-		const int32_t *tpb = reinterpret_cast<const int32_t *>(arena + J.top[1]) + (size_t)L * CP;
-		baseA = reinterpret_cast<const int32_t *>(arena + J.top[0])[(size_t)s * kLanes * CP];
-		baseB = reinterpret_cast<const int32_t *>(arena + J.top[1])[(size_t)s * kLanes * CP];
-#pragma unroll
-		for (int c = 0; c < CP; ++c) {
-			tabA[c] = ta[c];
-			tabB[c] = tb[c];
-			hup[c] = pk_pack(tpa[c + 1] - baseA, tpb[c + 1] - baseB);
-		}
-		diag_in = pk_pack(tpa[0] - baseA, tpb[0] - baseB);
-#pragma unroll
-		for (int q = 0; q < R; ++q) last[q] = hup[CP - 1];
-	}
-	const uint32_t *mysel = selb + R * (64 - lane);
-
-	for (int a = a0; a <= a1; ++a) {
-		const int T0 = a * TR;
-		if (a > a0) {       /* re-centre both bases on the middle lane */
-			const uint32_t rep = (uint32_t)__builtin_amdgcn_readlane((int)hup[CP / 2], kLanes / 2);
-			const int dA = pk_lo(rep) & ~3, dB = pk_hi(rep) & ~3;
-			const uint32_t delta = pk_pack(dA, dB);
-			baseA += dA;
-			baseB += dB;
-#pragma unroll
-			for (int c = 0; c < CP; ++c) hup[c] = pk_sub(hup[c], delta);
-			diag_in = pk_sub(diag_in, delta);
-#pragma unroll
-			for (int q = 0; q < R; ++q) last[q] = pk_sub(last[q], delta);
-		}
-		{
-			const uint32_t *src = reinterpret_cast<const uint32_t *>(arena + J.rowsel) + (J.padl + R * (T0 - s * kLanes - 64));
-			for (int j = lane; j < R * (TR + 64); j += kLanes) selb[j] = src[j];
-		}
-		if (s == 0) {
-			const int la = J.leftmul[0], lb = J.leftmul[1];
-			for (int e = lane; e < R * TR; e += kLanes) {
-				const int r = R * T0 + e + 1;
-				feed[e] = pk_pack(la * r - baseA, lb * r - baseB);
-			}
-		} else {
-			/* wait until the producer strip has published what this chunk reads */
-			const int need = (a + 1 < pa1 + 1) ? a + 1 : pa1 + 1;
-			int have = 0, spins = 0;
-			do {
-				have = __hip_atomic_load(progress + (s - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (have >= need) break;
-				__builtin_amdgcn_s_sleep(4);
-				if ((++spins & 255) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) spins = CSADP_SPIN_LIMIT;
-			} while (spins < CSADP_SPIN_LIMIT);
-			if (have < need) {          /* wave-uniform: every lane polled the same word */
-				if (lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				return;
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-			const unsigned long long *h = hand_in + (size_t)T0 * R;
-			for (int e = lane; e < R * TR; e += kLanes) {
-				const unsigned long long v = __hip_atomic_load(h + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				feed[e] = pk_pack((int)(uint32_t)v - baseA, (int)(uint32_t)(v >> 32) - baseB);
-			}
-		}
-		__syncthreads();
-
-		uint32_t *dirs = reinterpret_cast<uint32_t *>(arena + J.dirs) + ((size_t)s * J.steps_pad + T0) * (R * 2 * kLanes) + lane * 2;
-		const int r0s = T0 - L;
-		if (a == a0)
-			fill_steps_pk<R, TR, true>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
-		else
-			fill_steps_pk<R, TR, false>(tabA, tabB, hup, diag_in, last, feed, mysel, edge, dirs, r0s, lane);
-		__syncthreads();
-
-		/* publish the right edge of this chunk (absolute X, A | B << 32), then the chunk counter */
-		{
-			unsigned long long *ho = hand_out + (size_t)(T0 + 1) * R;
-			for (int e = lane; e < R * TR; e += kLanes) {
-				const uint32_t v = edge[e];
-				const unsigned long long w = (unsigned long long)(uint32_t)(pk_lo(v) + baseA) |
-				                             ((unsigned long long)(uint32_t)(pk_hi(v) + baseB) << 32);
-				__hip_atomic_store(ho + e, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-			if (lane == 0) __hip_atomic_store(progress + s, a + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		__syncthreads();
-	}
-}
-
-/* Traceback of one matrix of a pair job: blockIdx = 2*pair + half.  Same run-batched walk as
- * nw_traceback; a word column covers 8 matrix columns, the window is 32 word columns wide. */
-template <int R>
-__global__ __launch_bounds__(64) void nw_traceback_pk(uint8_t *__restrict__ arena,
-                                                      const PairJob *__restrict__ jobs)
-{
-	constexpr int WQ = 32;
-	constexpr int RW = R * WQ;
-	constexpr int WT = 16384 / RW;
-	__shared__ __attribute__((aligned(16))) uint32_t win[WT * RW];
-
-	const PairJob &J = jobs[blockIdx.x >> 1];
-	const int half = blockIdx.x & 1;
-	uint8_t *ops = arena + J.ops[half];
-	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary[half]);
-	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
-	const int lane = threadIdx.x;
-	const size_t strip_words = (size_t)J.steps_pad * (R * 2 * kLanes);
-	const int qmax = J.nstrips * 2 * kLanes;
-	const int hshift = 16 * half;
-	int r = J.nrows[half], k = J.ncols[half];
-	int n = 0;
-
-	while (r > 0 && k > 0) {
-		const int q0 = (k - 1) >> 3;
-		const int Ttop = (r - 1) / R + (q0 >> 1);
-		const int qbase = (q0 & ~3) - 16;
-		constexpr int UNITS = WT * RW / 4;
-		constexpr int BATCH = 16;
-		for (int b0 = 0; b0 < UNITS / kLanes; b0 += BATCH) {
-			uint4 v[BATCH];
-#pragma unroll
-			for (int b = 0; b < BATCH; ++b) {
-				const int u = (b0 + b) * kLanes + lane;
-				const int i = u / (8 * R);
-				const int row = (u / 8) % R;
-				const int T = Ttop - i;
-				const int q = qbase - (((i * 2 * R) / (16 + R)) & ~3) + 4 * (u % 8);
-				v[b] = make_uint4(0, 0, 0, 0);
-				if (T >= 0 && q >= 0 && q < qmax)
-					v[b] = *reinterpret_cast<const uint4 *>(dirs + (size_t)(q >> 7) * strip_words +
-					                                        ((size_t)T * R + row) * (2 * kLanes) + (q & 127));
-			}
-#pragma unroll
-			for (int b = 0; b < BATCH; ++b)
-				reinterpret_cast<uint4 *>(win)[(b0 + b) * kLanes + lane] = v[b];
-		}
-		__syncthreads();
-		for (;;) {
-			const int ri = r - lane, ki = k - lane;
-			uint32_t code = 3;
-			if (ri > 0 && ki > 0) {
-				const int kc = ki - 1;
-				const int q = kc >> 3;
-				const int i = Ttop - ((ri - 1) / R + (q >> 1));
-				if (i >= 0 && i < WT) {
-					const int j = q - (qbase - (((i * 2 * R) / (16 + R)) & ~3));
-					if (j >= 0 && j < WQ) {
-						const uint32_t word = win[(i * R + (ri - 1) % R) * WQ + j];
-						code = (word >> (hshift + 2 * (7 - (kc & 7)))) & 3u;
-					}
-				}
-			}
-			const unsigned long long stop = __ballot(code != DIR_D);
-			const int run = stop ? __builtin_ctzll(stop) : kLanes;
-			if (run > 0) {
-				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
-				n += run;
-				r -= run;
-				k -= run;
-				continue;
-			}
-			const uint32_t c0 = __builtin_amdgcn_readfirstlane(code);
-			if (c0 == 3) break;
-			if (lane == 0) ops[n] = (uint8_t)c0;
-			++n;
-			if (c0 == DIR_L) --k; else --r;
-		}
-		__syncthreads();
-	}
-	if (lane == 0) {
-		summary[0] = n;
-		summary[1] = r;
-		summary[2] = k;
-		summary[3] = 0;
-	}
-}
-
-template <int R>
-static hipError_t launch_fill_pk_r(int TR, uint8_t *arena, const PairJob *jobs, const SegList &segs, int ntiles, hipStream_t st)
-{
-	if (TR == 64) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 64>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
-	else if (TR == 128) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 128>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
-	else if (TR == 256) hipLaunchKernelGGL((nw_fill_tiles_pk<R, 256>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
-	else return hipErrorInvalidValue;
-	return hipGetLastError();
-}
-
-hipError_t launch_fill_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const SegList &segs, hipStream_t st)
-{
-	const int ntiles = seg_tiles(segs);
-	if (ntiles <= 0) return hipSuccess;
-	if (R == 1) return launch_fill_pk_r<1>(TR, arena, jobs, segs, ntiles, st);
-	if (R == 2) return launch_fill_pk_r<2>(TR, arena, jobs, segs, ntiles, st);
-	return hipErrorInvalidValue;
-}
-
-hipError_t launch_fill_strips_pk(int R, int TR, uint8_t *arena, const PairJob *jobs, const TileRef *strips, int nstrips,
-                                 int *abort_word, hipStream_t st)
-{
-	if (nstrips <= 0) return hipSuccess;
-	if (R == 2 && TR == 64) hipLaunchKernelGGL((nw_fill_strips_pk<2, 64>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
-	else if (R == 2 && TR == 128) hipLaunchKernelGGL((nw_fill_strips_pk<2, 128>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
-	else if (R == 1 && TR == 64) hipLaunchKernelGGL((nw_fill_strips_pk<1, 64>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
-	else if (R == 1 && TR == 128) hipLaunchKernelGGL((nw_fill_strips_pk<1, 128>), dim3(nstrips), dim3(kLanes), 0, st, arena, jobs, strips, abort_word);
-	else return hipErrorInvalidValue;
-	return hipGetLastError();
-}
-
-hipError_t launch_traceback_pk(int R, uint8_t *arena, const PairJob *jobs, int npairs, hipStream_t st)
-{
-	if (npairs <= 0) return hipSuccess;
-	if (R == 1) hipLaunchKernelGGL((nw_traceback_pk<1>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
-	else if (R == 2) hipLaunchKernelGGL((nw_traceback_pk<2>), dim3(2 * npairs), dim3(kLanes), 0, st, arena, jobs);
-	else return hipErrorInvalidValue;
-	return hipGetLastError();
-}
 
 /*
  * K3.  Column statistics of a finished alignment, tools.c:259-281 (CalculateSumOfPairsScore):
@@ -878,52 +55,5 @@ hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long lo
 }
 
 /* ---- launch wrappers (host) ----------------------------------------------------------- */
-
-template <int C, int R, int TR>
-static hipError_t launch_fill_t(bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, int ntiles, hipStream_t st)
-{
-	if (wide) hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, true>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
-	else hipLaunchKernelGGL((nw_fill_tiles<C, R, TR, false>), dim3(ntiles), dim3(kLanes), 0, st, arena, jobs, segs);
-	return hipGetLastError();
-}
-
-template <int C, int R>
-static hipError_t launch_fill_r(int TR, bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, int ntiles, hipStream_t st)
-{
-	if (TR == 64) return launch_fill_t<C, R, 64>(wide, arena, jobs, segs, ntiles, st);
-	if (TR == 128) return launch_fill_t<C, R, 128>(wide, arena, jobs, segs, ntiles, st);
-	if (TR == 256) return launch_fill_t<C, R, 256>(wide, arena, jobs, segs, ntiles, st);
-	return hipErrorInvalidValue;
-}
-
-hipError_t launch_fill(int C, int R, int TR, bool wide, uint8_t *arena, const FillJob *jobs, const SegList &segs, hipStream_t st)
-{
-	const int ntiles = seg_tiles(segs);
-	if (ntiles <= 0) return hipSuccess;
-	if (C == 16 && R == 1) return launch_fill_r<16, 1>(TR, wide, arena, jobs, segs, ntiles, st);
-	if (C == 16 && R == 2) return launch_fill_r<16, 2>(TR, wide, arena, jobs, segs, ntiles, st);
-	if (C == 16 && R == 4) return launch_fill_r<16, 4>(TR, wide, arena, jobs, segs, ntiles, st);
-	if (C == 32 && R == 1) return launch_fill_r<32, 1>(TR, wide, arena, jobs, segs, ntiles, st);
-	if (C == 32 && R == 2) return launch_fill_r<32, 2>(TR, wide, arena, jobs, segs, ntiles, st);
-	return hipErrorInvalidValue;
-}
-
-template <int C, int R>
-static hipError_t launch_tb_t(uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st)
-{
-	hipLaunchKernelGGL((nw_traceback<C, R>), dim3(njobs), dim3(kLanes), 0, st, arena, jobs);
-	return hipGetLastError();
-}
-
-hipError_t launch_traceback(int C, int R, uint8_t *arena, const FillJob *jobs, int njobs, hipStream_t st)
-{
-	if (njobs <= 0) return hipSuccess;
-	if (C == 16 && R == 1) return launch_tb_t<16, 1>(arena, jobs, njobs, st);
-	if (C == 16 && R == 2) return launch_tb_t<16, 2>(arena, jobs, njobs, st);
-	if (C == 16 && R == 4) return launch_tb_t<16, 4>(arena, jobs, njobs, st);
-	if (C == 32 && R == 1) return launch_tb_t<32, 1>(arena, jobs, njobs, st);
-	if (C == 32 && R == 2) return launch_tb_t<32, 2>(arena, jobs, njobs, st);
-	return hipErrorInvalidValue;
-}
 
 }  // namespace csadp

@@ -164,22 +164,6 @@ void Progressive::write_tables(uint32_t *coltab, int32_t *leftc, int ncols_pad, 
 	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
 }
 
-void Progressive::write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel, int selbase, int32_t *top) const
-{
-	const int ncols = consensus_;
-	for (int k = 1; k <= ncols; ++k) {
-		const int *col = &sv_[(size_t)k * kSym];
-		uint32_t w = 0;
-		for (int c = 0; c < 4; ++c) w |= (uint32_t)((8 * col[c] + 2) & 255) << (8 * c);
-		tab[k - 1] = w;
-	}
-	const int n = order_[step_];
-	const int start = starts_[n];
-	for (int j = 0; j < nrows_; ++j) rowsel[4 * (size_t)j] = (uint8_t)(selbase + code_of(char_at(start + j, n)));
-	for (int k = 0; k <= ncols; ++k) top[k] = 4 * border_top_[k];
-	for (int k = ncols + 1; k <= ncols_pad; ++k) top[k] = top[ncols];
-}
-
 void Progressive::write_tables_bits(uint32_t *cols, int nwords, uint32_t *rows, int rowwords) const
 {
 	/* the destination is pinned staging memory: one store per finished word, no read-modify-write */

@@ -40,10 +40,6 @@ public:
 	 *   top[0..ncols_pad]         X of border row 0 = 4*H[0][k]; beyond ncols: last value */
 	void write_tables(uint32_t *coltab, int32_t *leftc, int ncols_pad, uint8_t *rowshift, int32_t *top, bool wide) const;
 
-	/* Same inputs for the packed-16 pair mode (PairJob; pairwise fills only, left gain is the
-	 * constant -3): narrow byte gains, one v_perm selector byte per row at stride 4
-	 * (selbase + letter). */
-	void write_tables_pk(uint32_t *tab, int ncols_pad, uint8_t *rowsel, int selbase, int32_t *top) const;
 	/* first fill with fresh borders: H[0][k] = -k, H[r][0] = -r, every column one letter (the
 	 * conditions of the bit-parallel kernel, csadp_bits.hip) */
 	bool unit_borders() const { return step_ == 1 && border_i_ == 1 && !stale_; }

@@ -42,7 +42,7 @@ typedef struct csadp_config {
 	int device;        /* HIP device ordinal of the PRIMARY device; -1 = take LOCAL_RANK / 0.  An   */
 	                   /* ordinal that does not exist is CSADP_ERR_NO_DEVICE (CSADP_SHARE_DEVICE=1 */
 	                   /* maps it onto the visible devices instead: multi-rank rehearsals only)    */
-	int tile_rows;     /* DP steps per tile launch (0 = default)                           */
+	int tile_rows;     /* ignored since round 3 (the tiled kernels it tuned are gone); kept for ABI    */
 	int verbose;       /* 1 = print the reference's progress tokens in the drop-in adapter */
 } csadp_config;
 

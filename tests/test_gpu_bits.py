@@ -72,9 +72,8 @@ def test_many_strips_few_rows_and_few_strips_many_rows(bits_mode):
 
 
 def test_sixteen_strips_and_beyond(bits_mode):
-    """32768 columns = 16 waves in one workgroup.  Wider jobs: in checkpoint mode a workgroup per
-    chunk of 16 strips, chained through the recorded hand-off words and a progress counter in HBM;
-    with direction planes on the tiled kernels."""
+    """32768 columns = 16 waves of one word per lane in one workgroup.  Wider jobs: a workgroup per chunk of
+    strips, chained through epoch-tagged granules in HBM."""
     r = rng(103)
 
     def wide_task(cols):
@@ -235,7 +234,7 @@ def test_extreme_aspect_ratios(bits_mode):
         ([long, long[70000:70016]], None, None, None),      # 16 columns x 150 k rows: 4690 blocks, one strip
         ([long[:9], long[:120000]], None, None, None),      # 9 columns again (the shorter one is the profile)
         ([long[:1], long[5:6]], None, None, None),
-        ([long[:40000], long[100:40100]], None, None, None),   # 40 k x 40 k: 20 strips, tiled kernels (1 wide job)
+        ([long[:40000], long[100:40100]], None, None, None),   # 40 k x 40 k: 20 strips of one word per lane (1 wide job)
     ]
     got = csa_amd.align_batch(tasks)
     _properties(tasks, got)

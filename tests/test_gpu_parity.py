@@ -20,30 +20,24 @@ def device():
 
 
 # First fills (every pairwise task, and step 1 of every progressive task) run the bit-parallel
-# kernels by default (csadp_bits.hip); CSADP_BITS=0 sends them to the packed-16 pair kernel and
-# CSADP_BITS=0 CSADP_PK16=0 to the 32-bit profile kernel.  The environment is read at every batch
-# layout, so the tests below that take `fill_mode` cover all three.  Batches of 2-sequence tasks in
-# bit-parallel mode also pack their inputs and build their rows on the device (csadp_pairio.hip);
-# "bits-hostio" switches that off: tables written and traces applied by the host, as for N sequences.
-@pytest.fixture(params=["bits", "bits-hostio", "packed16", "cells", "tiles32"])
+# kernels by default (csadp_bits.hip); CSADP_BITS=0 sends them to the 32-bit cell-per-lane kernel that
+# serves every other fill (csadp_cells.hip) -- the independent cross-check of the bit-parallel path.
+# The environment is read at every batch layout, so the tests below that take `fill_mode` cover both
+# families.  Batches of 2-sequence tasks in bit-parallel mode also pack their inputs and build their rows
+# on the device (csadp_pairio.hip); "bits-hostio" switches that off: tables written and traces applied by
+# the host, as for N sequences.  (The tiled 32-bit and packed-16 families of rounds 1-2 are gone.)
+@pytest.fixture(params=["bits", "bits-hostio", "cells"])
 def fill_mode(request, monkeypatch):
     if request.param == "bits-hostio":
         monkeypatch.setenv("CSADP_DEVICE_IO", "0")
     elif request.param != "bits":
         monkeypatch.setenv("CSADP_BITS", "0")
-    if request.param in ("cells", "tiles32"):          # the general 32-bit kernels, here on pairs
-        monkeypatch.setenv("CSADP_PK16", "0")
-    if request.param == "tiles32":
-        monkeypatch.setenv("CSADP_CELLS", "0")
     return request.param
 
 
-# Profile steps (i >= 2, stale borders) run the persistent cell-per-lane kernel (csadp_cells.hip);
-# CSADP_CELLS=0 keeps the tiled kernel with one launch per tile anti-diagonal.
-@pytest.fixture(params=["cells", "tiles"])
-def profile_mode(request, monkeypatch):
-    if request.param == "tiles":
-        monkeypatch.setenv("CSADP_CELLS", "0")
+# Profile steps (i >= 2, stale borders) run the persistent cell-per-lane kernel (csadp_cells.hip).
+@pytest.fixture(params=["cells"])
+def profile_mode(request):
     return request.param
 
 
@@ -339,9 +333,9 @@ def test_config5_mixed_lengths_sample():
 
 @pytest.mark.parametrize("nseq", [22, 23, 24, 33, 40, 64])
 def test_wide_profile_more_than_32_sequences(nseq, profile_mode):
-    """Many sequences switch a round to the 6-bit-count table format (csadp_device.h): the tiled kernel from
-    i = 32 on, nw_fill_cells from i = 22 on (its byte form folds the column's gap term into the gain bytes:
-    12 i + 1 <= 255); 22 / 23 / 24 sequences sit on that boundary.  64 is the reference's MAXNUMBEROFSEQS
+    """Many sequences switch a round to the 6-bit-count table format (csadp_device.h): nw_fill_cells from
+    i = 22 on (its byte form folds the column's gap term into the gain bytes: 12 i + 1 <= 255); 22 / 23 / 24
+    sequences sit on that boundary.  64 is the reference's MAXNUMBEROFSEQS
     (csamsa.c:23)."""
     r = rng(1000 + nseq)
     fam = random_family(r, nseq, 150, mut=0.08, indel=0.05)
@@ -372,11 +366,9 @@ def test_folded_gain_bytes_at_their_bounds(profile_mode):
         assert g["score"] == st.last_score and g["fills"] == st.fills
 
 
-def test_packed_mode_adversarial_pairs_vs_oracle(fill_mode):
-    """Inputs chosen to stress the packed-16 pair kernel (two matrices per register, 16-bit values
-    around re-centred int32 bases): homopolymers (steepest growth along the diagonal), all
-    mismatches, periodic sequences (many ties), and partners of very different sizes paired in
-    the same registers.  Everything is compared with the oracle string for string."""
+def test_adversarial_pairs_vs_oracle(fill_mode):
+    """Homopolymers (steepest growth along the diagonal), all mismatches, periodic sequences (many ties), and
+    partners of very different sizes in one batch.  Everything is compared with the oracle string for string."""
     r = rng(77)
     n = 5000
     rnd = bytes(r.choice(b"ACGT") for _ in range(n))
@@ -399,9 +391,8 @@ def test_packed_mode_adversarial_pairs_vs_oracle(fill_mode):
         assert g["score"] == st.last_score
 
 
-def test_packed_mode_long_homopolymers(fill_mode):
-    """60 kbp of the same letter: X grows by 8 per row for 60 k rows (480 k in total), far
-    beyond 16 bits -- only the per-tile re-centring keeps the packed kernel exact."""
+def test_long_homopolymers(fill_mode):
+    """60 kbp of the same letter: in gain form X grows by 8 per row for 60 k rows (480 k in total)."""
     n = 60000
     got = csa_amd.align_batch([([b"T" * n, b"T" * n], None, None, None),
                                ([b"T" * n, b"T" * (n - 100)], None, None, None)])
