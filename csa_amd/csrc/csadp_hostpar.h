@@ -17,6 +17,7 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 namespace csadp {
 
@@ -28,22 +29,23 @@ public:
 		return *pool;
 	}
 	int size() const { return nthreads_; }
-	/* run body() on `workers` - 1 pool threads and on the caller, return when every one has finished */
+	/* run body() on `workers` - 1 pool threads and on the caller, return when every one has finished.  Only the threads
+	 * that take part are woken (each waits on its own condition variable): a region of 16 on a pool of 64 does not pay
+	 * for 48 wake-ups that go straight back to sleep. */
 	void run(const std::function<void()> &body, int workers)
 	{
 		std::unique_lock<std::mutex> busy(run_mutex_);       /* one parallel region at a time */
+		const int want = std::min(workers, nthreads_) - 1;
 		{
 			std::lock_guard<std::mutex> lock(m_);
 			body_ = &body;
-			want_ = std::min(workers, nthreads_) - 1;
-			started_ = 0;
 			done_ = 0;
-			++epoch_;
+			for (int w = 1; w <= want; ++w) ++go_[(size_t)w];
 		}
-		cv_.notify_all();
+		for (int w = 1; w <= want; ++w) cv_[(size_t)w].notify_one();
 		body();
 		std::unique_lock<std::mutex> lock(m_);
-		cv_done_.wait(lock, [&] { return done_ == want_; });
+		cv_done_.wait(lock, [&] { return done_ == want; });
 		body_ = nullptr;
 	}
 
@@ -53,19 +55,19 @@ private:
 		const char *e = getenv("CSADP_HOST_THREADS");
 		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
 		nthreads_ = t < 1 ? 1 : (t > 64 ? 64 : t);
-		for (int w = 1; w < nthreads_; ++w) std::thread([this] { loop(); }).detach();
+		go_.assign((size_t)nthreads_, 0);
+		cv_ = std::vector<std::condition_variable>((size_t)nthreads_);
+		for (int w = 1; w < nthreads_; ++w) std::thread([this, w] { loop(w); }).detach();
 	}
-	void loop()
+	void loop(int w)
 	{
 		unsigned long long seen = 0;
 		for (;;) {
 			const std::function<void()> *body = nullptr;
 			{
 				std::unique_lock<std::mutex> lock(m_);
-				cv_.wait(lock, [&] { return epoch_ != seen; });
-				seen = epoch_;
-				if (started_ >= want_) continue;             /* this region needs fewer workers */
-				++started_;
+				cv_[(size_t)w].wait(lock, [&] { return go_[(size_t)w] != seen; });
+				seen = go_[(size_t)w];
 				body = body_;
 			}
 			(*body)();
@@ -78,10 +80,11 @@ private:
 	}
 	int nthreads_ = 1;
 	std::mutex run_mutex_, m_;
-	std::condition_variable cv_, cv_done_;
+	std::vector<std::condition_variable> cv_;
+	std::condition_variable cv_done_;
+	std::vector<unsigned long long> go_;
 	const std::function<void()> *body_ = nullptr;
-	int want_ = 0, started_ = 0, done_ = 0;
-	unsigned long long epoch_ = 0;
+	int done_ = 0;
 };
 
 inline bool &host_in_region()

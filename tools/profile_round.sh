@@ -1,12 +1,10 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence of one round on the GPU box:
-#   tools/profile_round.sh gpurun_out/r02   (then: python tools/summarize_profile.py gpurun_out/r02 profiles/r02)
+#   tools/profile_round.sh gpurun_out/r03   (then: python tools/summarize_profile.py gpurun_out/r03 profiles/r03)
 # Per workload one --kernel-trace --stats run, then separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not
 # fit one pass on gfx950, MI355X_MICROARCH.md).  The program itself follows "--".
 #   bench    bench.py's timed region: nw_pack_planes, nw_fill_bits, nw_traceback_replay, nw_expand_rows
 #   msa      tools/msa_probe.py (mode N of the example sets): nw_fill_cells, nw_traceback_cells
-#   tiles    the same with CSADP_CELLS=0: nw_fill_tiles, nw_traceback (the launch-per-diagonal kernels)
-#   pk       bench.py with CSADP_BITS=0: nw_fill_tiles_pk, nw_traceback_pk (packed-16 pair kernels)
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/$1
@@ -29,16 +27,4 @@ for C in "${PMC[@]}"; do
 	rocprofv3 --kernel-trace --output-format csv --pmc $C -d "$OUT" -o msa_pmc_$TAG -- python3 $ROOT/tools/msa_probe.py Set3 > "$OUT/log_msa_$TAG.txt" 2>&1
 done
 echo msa done
-CSADP_CELLS=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o tiles_stats -- python3 $ROOT/tools/msa_probe.py > "$OUT/log_tiles_stats.txt" 2>&1
-for C in "WRITE_SIZE" "FETCH_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
-	TAG=$(echo $C | cut -d' ' -f1)
-	CSADP_CELLS=0 rocprofv3 --kernel-trace --output-format csv --pmc $C -d "$OUT" -o tiles_pmc_$TAG -- python3 $ROOT/tools/msa_probe.py Set3 > "$OUT/log_tiles_$TAG.txt" 2>&1
-done
-echo tiles done
-CSADP_BITS=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o pk_stats -- $BENCH --steps 8 --warmup 2 > "$OUT/log_pk_stats.txt" 2>&1
-for C in "WRITE_SIZE" "FETCH_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
-	TAG=$(echo $C | cut -d' ' -f1)
-	CSADP_BITS=0 rocprofv3 --kernel-trace --output-format csv --pmc $C -d "$OUT" -o pk_pmc_$TAG -- $BENCH --steps 4 --warmup 0 > "$OUT/log_pk_$TAG.txt" 2>&1
-done
-echo pk done
 ls "$OUT" | head -80

@@ -2,7 +2,7 @@
 """Condense rocprofv3 outputs (gpurun_out/<dir>, written by tools/profile_round.sh) into the small files
 committed under profiles/.
 
-usage: python tools/summarize_profile.py gpurun_out/r02 profiles/r02
+usage: python tools/summarize_profile.py gpurun_out/r03 profiles/r03
 Writes <prefix>_<workload>_kernel_stats.csv (copies of the --stats summaries) and <prefix>_pmc_summary.json:
 per workload and kernel the sums of every collected counter, per-launch HBM traffic with the gfx950 corrections of
 MI355X_MICROARCH.md (FETCH_SIZE x2 for wide coalesced reads, both counters in KiB), VALU instructions per wave, and
@@ -17,8 +17,8 @@ import os
 import shutil
 import sys
 
-KERNELS = ["nw_fill_bits_wide", "nw_fill_bits", "nw_traceback_replay", "nw_traceback_bits", "nw_fill_cells", "nw_traceback_cells",
-           "nw_fill_tiles_pk", "nw_fill_strips_pk", "nw_fill_tiles", "nw_traceback_pk", "nw_traceback", "nw_pack_planes", "nw_expand_rows",
+KERNELS = ["nw_fill_bits", "nw_traceback_replay", "nw_fill_cells", "nw_traceback_cells", "nw_pack_planes", "nw_expand_rows",
+
            "sp_columns"]
 
 
@@ -38,7 +38,7 @@ def main():
     src, prefix = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(prefix), exist_ok=True)
     out = {}
-    for wl in ("bench", "msa", "tiles", "pk"):
+    for wl in ("bench", "msa"):
         for variant in ("stats", "solo"):
             st = find(src, "%s_%s" % (wl, variant), "kernel_stats.csv")
             if st:
