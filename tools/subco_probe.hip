@@ -5,8 +5,10 @@
 // per step.  Each lane keeps the history of its outgoing carries in three accumulators (acc = 2 acc + carry).
 //   part 1: what the DPP forms do in the first lane of a wave / row (zero fill, borrow, destination kept)
 //   part 2: the new step against the round-2 step on one wave, 256 steps, same inputs -> same planes
-//   part 3: cycles per wave-step per SIMD at 1 / 2 / 4 / 8 waves per SIMD, W = 1 and 2 words per lane
-// Build: hipcc --offload-arch=gfx950 -O3 tools/subco_probe.hip -o build/subco_probe ; run on the GPU box.
+//   part 3: cycles per wave-step per SIMD at 1 / 2 / 4 / 8 waves per SIMD, W = 1 and 2 words per lane -- the C++ form as
+//           shipped, and the same block as ONE generated inline-assembly statement (tools/gen_bits_block.py): 4-5 % faster here,
+//           not faster inside nw_fill_bits (profiles/r03_ab_asm_block.txt), so not shipped
+// Build: python tools/gen_bits_block.py build/csadp_bits_block.inc; hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/subco_probe.hip -o build/subco_probe ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -295,6 +297,105 @@ __global__ void k_time_old(uint32_t *out, const uint32_t *in, int nblocks)
 	out[blockIdx.x * blockDim.x + threadIdx.x] = S.nH0 ^ S.H1 ^ S.H2 ^ S.PP;
 }
 
+
+/* ---- the same block as ONE generated inline-assembly statement (tools/gen_bits_block.py) --------------- */
+#include "../build/csadp_bits_block.inc"       /* python tools/gen_bits_block.py build/csadp_bits_block.inc */
+
+template <int W, int VAR>      /* 0: as shipped (4-byte instructions paired, 8-byte ones at 4 mod 8), 1: unpaired, 2: early borrows, 3: at 0 mod 8 */
+__device__ __forceinline__ void asm_block(StN<W> &S, const uint32_t (&D)[2], const uint32_t (&E)[2], const uint32_t *ip)
+{
+	const uint32_t ipa = (uint32_t)(uintptr_t)ip;           /* LDS byte address = low half of the generic pointer */
+	if constexpr (W == 1) {
+#define OPS1 : [nh0_0] "+v"(S.nH0[0]), [h1_0] "+v"(S.H1[0]), [h2_0] "+v"(S.H2[0]), [x0] "+v"(S.x0), [x1] "+v"(S.x1), [no2] "+v"(S.nO2), \
+	[no1] "+v"(S.nO1), [no0] "+v"(S.nO0), [a2] "+v"(S.acc2), [a1] "+v"(S.acc1), [a0] "+v"(S.acc0) \
+	: [d0] "v"(D[0]), [d1] "v"(D[1]), [ip] "v"(ipa) : BITS_BLOCK_CLOBBERS_W1
+		if (VAR == 1) asm volatile(BITS_BLOCK_ASM_W1_PLAIN OPS1);
+		else if (VAR == 2) asm volatile(BITS_BLOCK_ASM_W1_EARLY OPS1);
+		else if (VAR == 3) asm volatile(BITS_BLOCK_ASM_W1_AT0 OPS1);
+		else asm volatile(BITS_BLOCK_ASM_W1 OPS1);
+#undef OPS1
+	} else {
+#define OPS2 : [nh0_0] "+v"(S.nH0[0]), [h1_0] "+v"(S.H1[0]), [h2_0] "+v"(S.H2[0]), [nh0_1] "+v"(S.nH0[1]), [h1_1] "+v"(S.H1[1]), [h2_1] "+v"(S.H2[1]), \
+	[x0] "+v"(S.x0), [x1] "+v"(S.x1), [no2] "+v"(S.nO2), [no1] "+v"(S.nO1), [no0] "+v"(S.nO0), [a2] "+v"(S.acc2), [a1] "+v"(S.acc1), [a0] "+v"(S.acc0) \
+	: [d0] "v"(D[0]), [d1] "v"(D[1]), [e0_1] "v"(E[0]), [e1_1] "v"(E[1]), [ip] "v"(ipa) : BITS_BLOCK_CLOBBERS_W2
+		if (VAR == 1) asm volatile(BITS_BLOCK_ASM_W2_PLAIN OPS2);
+		else if (VAR == 2) asm volatile(BITS_BLOCK_ASM_W2_EARLY OPS2);
+		else if (VAR == 3) asm volatile(BITS_BLOCK_ASM_W2_AT0 OPS2);
+		else asm volatile(BITS_BLOCK_ASM_W2 OPS2);
+#undef OPS2
+	}
+}
+
+/* part 2 with the generated block: the rows lane 0 reads are written to LDS per block, everybody else reads the constant rows */
+template <int W>
+__global__ void k_verify_asm(uint32_t *out, const uint32_t *in, int steps)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t inj[32 * 8];
+	__shared__ __attribute__((aligned(16))) uint32_t konst[32 * 8 + 4];
+	const int lane = threadIdx.x;
+	for (int i = lane; i < 32 * 8 + 4; i += 64) konst[i] = 0x80000000u;
+	uint32_t B0[W], B1[W];
+	for (int h = 0; h < W; ++h) { B0[h] = in[lane * W + h]; B1[h] = in[64 * W + lane * W + h]; }
+	uint32_t D[2], E[2] = {B0[0] ^ B0[W - 1], B1[0] ^ B1[W - 1]};
+	const int left = lane > 0 ? lane - 1 : 0;
+	D[0] = B0[0] ^ in[left * W];
+	D[1] = B1[0] ^ in[64 * W + left * W];
+	const uint32_t b00 = __builtin_amdgcn_readfirstlane(B0[0]), b10 = __builtin_amdgcn_readfirstlane(B1[0]);
+	StN<W> S;
+	for (int h = 0; h < W; ++h) { S.nH0[h] = ~0u; S.H1[h] = S.H2[h] = 0; }
+	S.x0 = S.x1 = 0;
+	S.nO2 = S.nO1 = S.nO0 = 0x80000000u;
+	S.acc2 = S.acc1 = S.acc0 = 0;
+	const uint32_t *ip = lane == 0 ? &inj[0] : &konst[4];
+	for (int b = 0; b < steps / 32; ++b) {
+		if (lane < 32) {
+			const uint32_t u = in[128 * W + b * 32 + lane];
+			inj[lane * 8 + 0] = b00 ^ ((u & 1) ? ~0u : 0u);
+			inj[lane * 8 + 1] = b10 ^ ((u & 2) ? ~0u : 0u);
+			inj[lane * 8 + 2] = (u >> 2) & 1;
+			inj[lane * 8 + 3] = (u >> 3) & 1;
+			inj[lane * 8 + 4] = (u >> 4) & 1;
+		}
+		asm_block<W, 0>(S, D, E, ip);
+		out[b * 64 * 3 + lane * 3 + 0] = S.acc2;
+		out[b * 64 * 3 + lane * 3 + 1] = S.acc1;
+		out[b * 64 * 3 + lane * 3 + 2] = S.acc0;
+	}
+	uint32_t *fin = out + 65536;
+	for (int h = 0; h < W; ++h) {
+		fin[(lane * W + h) * 3 + 0] = S.nH0[h];
+		fin[(lane * W + h) * 3 + 1] = S.H1[h];
+		fin[(lane * W + h) * 3 + 2] = S.H2[h];
+	}
+}
+
+template <int W, int VAR, int PHASE>
+__global__ void k_time_asm(uint32_t *out, const uint32_t *in, int nblocks)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t inj[16][32 * 8];
+	__shared__ __attribute__((aligned(16))) uint32_t konst[32 * 8 + 4];
+	const int lane = threadIdx.x & 63, wv = (threadIdx.x >> 6) & 15;
+	for (int i = threadIdx.x; i < 32 * 8 + 4; i += blockDim.x) konst[i] = 0x80000000u;
+	for (int i = lane; i < 32 * 8; i += 64) inj[wv][i] = in[(i * 7) & 1023] & 1u;
+	__syncthreads();
+	const uint32_t *ip = lane == 0 ? &inj[wv][0] : &konst[4];
+	StN<W> S;
+	for (int h = 0; h < W; ++h) { S.nH0[h] = in[lane + 64 * h]; S.H1[h] = in[128 + lane + 64 * h]; S.H2[h] = in[256 + lane + 64 * h]; }
+	S.x0 = in[384 + lane]; S.x1 = in[448 + lane];
+	S.nO2 = in[512 + lane]; S.nO1 = in[576 + lane]; S.nO0 = in[640 + lane];
+	S.acc2 = S.acc1 = S.acc0 = 0;
+	const uint32_t D[2] = {in[704 + lane], in[768 + lane]}, E[2] = {in[832 + lane], in[896 + lane]};
+	uint32_t sink = 0;
+	for (int b = 0; b < nblocks; ++b) {
+		if (PHASE == 1) asm volatile("s_nop 0");
+		asm_block<W, VAR>(S, D, E, ip);
+		sink ^= S.acc2 ^ S.acc1 ^ S.acc0;
+	}
+	uint32_t r = sink ^ S.x0 ^ S.x1 ^ S.nO2 ^ S.nO1 ^ S.nO0;
+	for (int h = 0; h < W; ++h) r ^= S.nH0[h] ^ S.H1[h] ^ S.H2[h];
+	out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 template <typename K>
 static void run(const char *name, K kernel, uint32_t *out, const uint32_t *in, int cells_per_step)
 {
@@ -444,6 +545,20 @@ int main()
 				for (int p = 0; p < 3; ++p)
 					if (dv[b * 64 * 3 + l * 3 + p] != accs[(b * 64 + l) * 3 + p]) { if (bad < 5) printf("  W=%d acc mismatch block %d lane %d plane %d: %08x vs %08x\n", W, b, l, p, dv[b * 64 * 3 + l * 3 + p], accs[(b * 64 + l) * 3 + p]); ++bad; }
 		printf("W=%d: new step vs plain word recurrence over %d steps: %s (%d mismatches)\n", W, steps, bad ? "DIFFERENT" : "identical", bad);
+		/* the generated block on the same inputs */
+		CHECK(hipMemset(out, 0, 1024 * 1024 * 4));
+		if (W == 1) hipLaunchKernelGGL(k_verify_asm<1>, dim3(1), dim3(64), 0, 0, out, in, steps);
+		else hipLaunchKernelGGL(k_verify_asm<2>, dim3(1), dim3(64), 0, 0, out, in, steps);
+		CHECK(hipDeviceSynchronize());
+		CHECK(hipMemcpy(dv, out, sizeof dv, hipMemcpyDeviceToHost));
+		bad = 0;
+		for (int j = 0; j < nwords * 3; ++j)
+			if (fin[j] != dv[65536 + j]) { if (bad < 5) printf("  W=%d asm plane mismatch word %d/%d: %08x vs %08x\n", W, j / 3, j % 3, dv[65536 + j], fin[j]); ++bad; }
+		for (int b = 0; b < steps / 32; ++b)
+			for (int l = 0; l < 64; ++l)
+				for (int p = 0; p < 3; ++p)
+					if (dv[b * 64 * 3 + l * 3 + p] != accs[(b * 64 + l) * 3 + p]) { if (bad < 5) printf("  W=%d asm acc mismatch block %d lane %d plane %d: %08x vs %08x\n", W, b, l, p, dv[b * 64 * 3 + l * 3 + p], accs[(b * 64 + l) * 3 + p]); ++bad; }
+		printf("W=%d: generated assembly block vs plain word recurrence: %s (%d mismatches)\n", W, bad ? "DIFFERENT" : "identical", bad);
 	}
 
 	/* part 3 */
@@ -456,5 +571,12 @@ int main()
 	run("borrow step W=1 + ds_read_b128 + b32", (k_time_new<1, 1>), out, in, 32);
 	run("borrow step W=2 (53 VALU), no LDS", (k_time_new<2, 0>), out, in, 64);
 	run("borrow step W=2 + ds_read_b128 + b32", (k_time_new<2, 1>), out, in, 64);
+	run("generated block W=1 as shipped", (k_time_asm<1, 0, 0>), out, in, 32);
+	run("generated block W=1, 4-byte ones unpaired", (k_time_asm<1, 1, 0>), out, in, 32);
+	run("generated block W=1, at 0 mod 8", (k_time_asm<1, 3, 0>), out, in, 32);
+	run("generated block W=2 as shipped", (k_time_asm<2, 0, 0>), out, in, 64);
+	run("generated block W=2, 4-byte ones unpaired", (k_time_asm<2, 1, 0>), out, in, 64);
+	run("generated block W=2, early borrows", (k_time_asm<2, 2, 0>), out, in, 64);
+	run("generated block W=2, at 0 mod 8", (k_time_asm<2, 3, 0>), out, in, 64);
 	return 0;
 }
