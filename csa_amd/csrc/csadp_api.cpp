@@ -239,7 +239,9 @@ static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntas
 
 namespace {
 
-/* csadp_align_batch on one engine: lock-step rounds over the engine's cached arena */
+constexpr int kRoundGroups = 2;   /* task groups whose rounds run side by side (measured: DESIGN.md section 4) */
+
+/* csadp_align_batch on one engine: lock-step rounds over the engine's cached arena(s) */
 int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result *results)
 {
 	/* a batch of 2-sequence tasks takes the device-I/O pair path: letters up, rows down */
@@ -258,18 +260,68 @@ int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result 
 		memset(&results[t], 0, sizeof(results[t]));
 		status[(size_t)t] = prog[(size_t)t].init(tasks[t]);
 	});
+	/* Lock-step rounds: round i = step i of every task that has one.  A round is [tables -> device -> trace application,
+	 * refinement], and the device idles through the host's part.  Tasks are independent, so the list is dealt (longest
+	 * first) over up to kRoundGroups groups, each driven through its own rounds by its own host thread on its own arena
+	 * and stream: one group's host part runs under the others' device part (the pool serves one parallel region at a
+	 * time; the groups' kernels are small enough to share the chip).  One task, or CSADP_ROUND_GROUPS=1: the plain loop. */
+	auto drive = [&](const std::vector<int> &mine, FillBatch &fb) -> int {
+		for (;;) {
+			std::vector<int> active;
+			for (int t : mine)
+				if (status[(size_t)t] == CSADP_OK && advance(prog[(size_t)t])) active.push_back(t);
+			if (active.empty()) return CSADP_OK;
+			const int rc = run_round(prog, active, fb, status);
+			if (rc != CSADP_OK) return rc;
+		}
+	};
+	std::vector<int> live;
+	for (int t = 0; t < ntasks; ++t)
+		if (status[(size_t)t] == CSADP_OK) live.push_back(t);
+	int groups = 1;
 	{
+		const char *e = getenv("CSADP_ROUND_GROUPS");
+		const int want = e && *e ? atoi(e) : kRoundGroups;
+		groups = std::max(1, std::min(std::min(want, E->main_streams()), (int)live.size()));
+	}
+	if (groups <= 1) {
 		std::lock_guard<std::mutex> lock(E->batch_mutex);
 		if (!E->cached_batch) E->cached_batch = new (std::nothrow) FillBatch(E);
 		if (!E->cached_batch) return CSADP_ERR_NOMEM;
-		for (;;) {
-			std::vector<int> active;
-			for (int t = 0; t < ntasks; ++t)
-				if (status[t] == CSADP_OK && advance(prog[t])) active.push_back(t);
-			if (active.empty()) break;
-			const int rc = run_round(prog, active, *E->cached_batch, status);
-			if (rc != CSADP_OK) return rc;
+		E->cached_batch->set_stream_base(0);
+		const int rc = drive(live, *E->cached_batch);
+		if (rc != CSADP_OK) return rc;
+	} else {
+		std::vector<long long> cost(live.size());
+		for (size_t i = 0; i < live.size(); ++i) cost[i] = std::max(1LL, csadp_task_cost(&tasks[live[i]]));
+		std::vector<int> part(live.size());
+		long long maxload = 0;
+		int prc = csadp_partition_lpt(cost.data(), (int)live.size(), groups, part.data(), &maxload);
+		if (prc != CSADP_OK) return prc;
+		std::vector<std::vector<int>> mine((size_t)groups);
+		for (size_t i = 0; i < live.size(); ++i) mine[(size_t)part[i]].push_back(live[i]);
+		for (auto &m : mine) std::sort(m.begin(), m.end());
+		std::lock_guard<std::mutex> lock(E->batch_mutex);
+		if (!E->cached_batch) E->cached_batch = new (std::nothrow) FillBatch(E);
+		if (!E->cached_batch) return CSADP_ERR_NOMEM;
+		if ((int)E->extra_batches.size() < groups - 1) E->extra_batches.resize((size_t)groups - 1, nullptr);
+		for (int g = 1; g < groups; ++g) {
+			if (!E->extra_batches[(size_t)g - 1]) E->extra_batches[(size_t)g - 1] = new (std::nothrow) FillBatch(E);
+			if (!E->extra_batches[(size_t)g - 1]) return CSADP_ERR_NOMEM;
 		}
+		std::vector<int> grc((size_t)groups, CSADP_OK);
+		std::vector<std::thread> threads;
+		for (int g = 1; g < groups; ++g)
+			threads.emplace_back([&, g] {
+				FillBatch &fb = *E->extra_batches[(size_t)g - 1];
+				fb.set_stream_base(g);
+				grc[(size_t)g] = E->bind() == CSADP_OK ? drive(mine[(size_t)g], fb) : CSADP_ERR_HIP;
+			});
+		E->cached_batch->set_stream_base(0);
+		grc[0] = drive(mine[0], *E->cached_batch);
+		for (std::thread &th : threads) th.join();
+		for (int g = 0; g < groups; ++g)
+			if (grc[(size_t)g] != CSADP_OK) return grc[(size_t)g];
 	}
 	parallel_for(ntasks, [&](int t) {
 		if (status[(size_t)t] == CSADP_OK) status[(size_t)t] = prog[(size_t)t].finish(&results[t]);

@@ -223,6 +223,8 @@ void Engine::shutdown()
 		std::lock_guard<std::mutex> lock(batch_mutex);
 		delete cached_batch;
 		cached_batch = nullptr;
+		for (FillBatch *b : extra_batches) delete b;
+		extra_batches.clear();
 	}
 	drop_arena_cache();
 	{
@@ -814,11 +816,11 @@ int FillBatch::upload()
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	if (!laid_out_) return CSADP_ERR_STATE;
 	if ((cells_mode_ || (bits_ && bits_wide_)) && hand_bytes_ > 0)
-		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, E_->stream(0)));
-	/* every slot's stream must see the inputs: copy on slot 0 and wait (upload is not on the
+		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, home_stream(0)));
+	/* every slot's stream must see the inputs: copy on the batch's first stream and wait (upload is not on the
 	 * timed path; run() calls may follow on any stream) */
-	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, E_->stream(0)));
-	HIP_TRY(hipStreamSynchronize(E_->stream(0)));
+	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, home_stream(0)));
+	HIP_TRY(hipStreamSynchronize(home_stream(0)));
 	return CSADP_OK;
 }
 
@@ -947,7 +949,7 @@ int FillBatch::check_abort()
 {
 	if ((!bits_ && !cells_mode_) || !h_abort_) return CSADP_OK;
 	if (cells_mode_) {
-		hipStream_t st = E_->stream(last_slot_);
+		hipStream_t st = home_stream(last_slot_);
 		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
 		if (*h_abort_ == 0) return CSADP_OK;
@@ -992,7 +994,7 @@ int FillBatch::check_abort()
  * wait-free path), traceback */
 int FillBatch::run_slot_cells(int sl, bool serial)
 {
-	hipStream_t st = E_->stream(sl);
+	hipStream_t st = home_stream(sl);
 	hipEvent_t *ev = ev_[sl];
 	const CellJob *cj = reinterpret_cast<const CellJob *>(arena_ + jobs_off_[sl]);
 	int *abort_word = reinterpret_cast<int *>(arena_ + abort_off_);
@@ -1054,7 +1056,7 @@ int FillBatch::download()
 		 * device, ~20 us each, 15 times per alignment) */
 		const int frc = flush();
 		if (frc != CSADP_OK) return frc;
-		hipStream_t st = E_->stream(last_slot_);
+		hipStream_t st = home_stream(last_slot_);
 		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], res_bytes_, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
@@ -1069,7 +1071,7 @@ int FillBatch::download()
 		const int rc = sync();            /* flush pending passes; results of the LAST pass are wanted */
 		if (rc != CSADP_OK) return rc;
 	}
-	hipStream_t st = E_->stream(bits_ ? last_stream_ : last_slot_);
+	hipStream_t st = bits_ ? E_->stream(last_stream_) : home_stream(last_slot_);
 	const size_t want = (io_ && !want_strings_) ? sum_bytes_ : res_bytes_;
 	if (bits_) st = E_->copy_stream();            /* sync() has waited for the batch: nothing to order the copy behind */
 	HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], want, hipMemcpyDeviceToHost, st));

@@ -65,6 +65,7 @@ public:
 	 * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per input set) */
 	std::mutex batch_mutex;
 	FillBatch *cached_batch = nullptr;
+	std::vector<FillBatch *> extra_batches;       /* ... and the arenas of the further round groups (guarded by batch_mutex too) */
 
 private:
 	int init(int device, const csadp_config *cfg);
@@ -105,6 +106,9 @@ public:
 
 	/* pipelined = rotate run() calls over Engine::slots() result/scratch sets; otherwise one */
 	void set_pipelined(bool on) { pipelined_ = on; }
+	/* Batches that run side by side from different host threads (the round groups of csadp_align_batch) take different
+	 * streams of the engine: slot s of this batch uses stream (base + s) modulo the engine's main streams. */
+	void set_stream_base(int base) { stream_base_ = base; }
 	void clear();
 	/* register a fill; returns its job index */
 	int add(int nrows, int ncols, int nprev, int left_i);
@@ -159,6 +163,8 @@ public:
 
 private:
 	Engine *E_;
+	int stream_base_ = 0;
+	hipStream_t home_stream(int slot) const { return E_->stream((stream_base_ + slot) % E_->main_streams()); }
 	struct Extra { int ncols_pad; size_t in_coltab, in_leftc, in_rowshift, in_top, res_summary, res_ops; };
 	struct BitExtra { size_t in_cols, in_rows; size_t res_out[2]; };
 	struct TextRef { const char *ptr; int size; size_t off; };
