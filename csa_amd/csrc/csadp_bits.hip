@@ -265,6 +265,28 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K
 	}
 }
 
+/*
+ * The same 32 steps as ONE inline-assembly statement (tools/gen_bits_block.py -> csadp_bits_block.inc), for the launches that run
+ * ONE wave per SIMD with one word per lane -- a single matrix, the first fills of a whole-genome profile alignment.  A lone wave
+ * pays ~4.2 cycles for every instruction it issues, whatever it is: here no `s_nop` follows the chains (the compiler puts one
+ * behind every asm statement whose output the next instruction reads: three per step), there is one counted wait per step, and the
+ * block is 8-byte aligned with its 8-byte instructions at 0 mod 8, the placement a lone wave runs fastest: a 16 kbp pair fills in 1.43
+ * instead of 1.59 ms, a 200 kbp pair in 17.3 instead of 18.6 ms.  With several waves per SIMD the block gains nothing over the C++ form
+ * and the other placement is the fast one (measured both: tools/subco_probe.hip, profiles/r03_ab_asm_block.txt), so those kernels keep
+ * the C++ form.  tools/subco_probe.hip holds the generated block to the plain word recurrence on the device; the DPP hazard check of the
+ * build covers it.
+ */
+#include "csadp_bits_block.inc"
+__device__ __forceinline__ void bits_block_lone(BitState<1> &S, const LaneConst<1> &K, const uint32_t *ip)
+{
+	const uint32_t ipa = (uint32_t)(uintptr_t)ip;             /* LDS byte address = low half of the generic pointer */
+	asm volatile(BITS_BLOCK_ASM_W1_LONE
+	             : [nh0_0] "+v"(S.nH0[0]), [h1_0] "+v"(S.H1[0]), [h2_0] "+v"(S.H2[0]), [x0] "+v"(S.x0), [x1] "+v"(S.x1), [no2] "+v"(S.nO2),
+	               [no1] "+v"(S.nO1), [no0] "+v"(S.nO0), [a2] "+v"(S.acc2), [a1] "+v"(S.acc1), [a0] "+v"(S.acc0)
+	             : [d0] "v"(K.D0), [d1] "v"(K.D1), [ip] "v"(ipa)
+	             : BITS_BLOCK_CLOBBERS_W1);
+}
+
 /* checkpoint of a lane after block b of strip s: planes per word h at ck[((s nb + b) W + h) 64 + lane] (.w of word 0: acc2),
  * the other two accumulators at hand[(s nb + b) 64 + lane] */
 template <int W>
@@ -480,6 +502,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 			inject[wv][t * kInjWords + INJ_Z0] = z0;
 		}
 		if (b < 2) bits_block<W, true, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
+		else if constexpr (LONE && W == 1) bits_block_lone(S, K, ip);
 		else bits_block<W, false, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
 		save_state<W>(ck, hand, (size_t)s * nb + b, lane, S);
 		if (feeds) {

@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
-"""EXPERIMENT (round 3, measured, not shipped): the steady-state block of 32 steps of nw_fill_bits (csadp_bits.hip) as ONE
-inline-assembly statement per words-per-lane W, for tools/subco_probe.hip.  In the probe the block runs 4-5 % faster than the C++
-form (181 / 167 / 160 against 190 / 175 / 166 cycles per step of two words at 2 / 4 / 8 waves per SIMD); built into nw_fill_bits it
-was no faster (profiles/r03_ab_asm_block.txt: 2.15-2.24 against 2.07-2.12 ms for a launch alone, equal pipelined), so the kernel keeps
-the C++ form.  What the probe did settle: the same block placed at 0 instead of 4 modulo 8 bytes runs 14 % slower.
+"""The steady-state block of 32 steps of nw_fill_bits (csadp_bits.hip) as ONE inline-assembly statement.
+
+    python tools/gen_bits_block.py csa_amd/csrc/csadp_bits_block.inc          what ships: W = 1, for the one-wave-per-SIMD launches
+    python tools/gen_bits_block.py build/csadp_bits_block.inc --probe         every variant, W = 1 and 2, for tools/subco_probe.hip
+
+Measured (round 3).  Many waves per SIMD: in the probe the block runs 4-5 % faster than the C++ form (181 / 167 / 160 against
+190 / 175 / 166 cycles per step of two words at 2 / 4 / 8 waves per SIMD), built into nw_fill_bits it was no faster
+(profiles/r03_ab_asm_block.txt), and the same block at 0 instead of 4 modulo 8 bytes runs 14 % slower: the many-wave kernels keep the
+C++ form.  ONE wave per SIMD (a single matrix): the preference flips -- at 0 mod 8 the block takes 150 cycles per step against the
+C++ form's 161 -- and in the kernel a 16 kbp pair fills in 1.43 instead of 1.59 ms, a 200 kbp pair in 17.3 instead of 18.6 ms
+(profiles/r03_single_probe.txt): shipped for those launches.
 
 Why.  The C++ form of the step (bits_block) keeps its DPP / carry instructions in small `asm volatile` statements (the carry
 must stay in VCC between them).  The compiler treats every such statement as an instruction of unknown kind: it puts an
@@ -19,7 +25,6 @@ of this lane's input rows (v).  Temporaries are fixed VGPRs v[T0 .. T0+NT), decl
 Register use per step t (W = 2):   load set L[t % 2] = {P0, P1, Z2, Z1 | Z0}: x0 / x1 of the step live in P0 / P1 of that set
 until the next step has chained from them; the other set is re-loaded for step t + 1 right after this step's two v_xor_b32_dpp.
 
-    python tools/gen_bits_block.py build/csadp_bits_block.inc
 """
 import sys
 
@@ -214,17 +219,30 @@ def cstring(lines):
 
 
 def main():
+    probe = "--probe" in sys.argv
+    path = [x for x in sys.argv[1:] if not x.startswith("--")][0]
     out = ["/* GENERATED by tools/gen_bits_block.py -- do not edit.  See that file for the register map. */"]
+    if not probe:
+        # what ships: one word per lane, for the launches that run ONE wave per SIMD (a single matrix, the first fills of a
+        # whole-genome profile alignment): 4-byte instructions paired, the block 8-byte aligned with its 8-byte instructions
+        # at 0 mod 8 -- the placement a lone wave runs fastest (the many-wave kernels prefer 4 mod 8, and gain nothing from
+        # the block: DESIGN.md section 3)
+        lines, R = block(1, phase=0)
+        out.append("#define BITS_BLOCK_ASM_W1_LONE \\\n%s" % cstring(lines))
+        out.append("#define BITS_BLOCK_CLOBBERS_W1 " + ", ".join('"v%d"' % r for r in range(T0, R.end)) + ', "vcc", "memory"')
+        steps = [l for l in lines if l.startswith("v_")]
+        out.append("/* %d vector instructions per block = %.2f per step, temporaries v%d .. v%d */" % (len(steps), (len(steps) - 2) / 32.0, T0, R.end - 1))
+        open(path, "w").write("\n".join(out) + "\n")
+        return
     for W in (1, 2):
-        # the shipped form: 4-byte instructions paired, every 8-byte instruction at 4 mod 8 (tools/subco_probe.hip: the same block
-        # at 0 mod 8 runs 14 % slower); the others are the probe's comparisons
+        # the probe's comparisons: 4-byte instructions paired and every 8-byte instruction at 4 mod 8, unpaired, early borrows, at 0 mod 8
         for name, kw in (("", dict(phase=4)), ("_PLAIN", dict(paired=False)), ("_EARLY", dict(phase=4, early=True)), ("_AT0", dict(phase=0))):
             lines, R = block(W, **kw)
             out.append("#define BITS_BLOCK_ASM_W%d%s \\\n%s" % (W, name, cstring(lines)))
         out.append("#define BITS_BLOCK_CLOBBERS_W%d " % W + ", ".join('"v%d"' % r for r in range(T0, R.end)) + ', "vcc", "memory"')
         steps = [l for l in lines if l.startswith("v_")]
         out.append("/* W = %d: %d vector instructions per block = %.2f per step, temporaries v%d .. v%d */" % (W, len(steps), (len(steps) - 2) / 32.0, T0, R.end - 1))
-    open(sys.argv[1], "w").write("\n".join(out) + "\n")
+    open(path, "w").write("\n".join(out) + "\n")
 
 
 if __name__ == "__main__":

@@ -6,9 +6,10 @@
 //   part 1: what the DPP forms do in the first lane of a wave / row (zero fill, borrow, destination kept)
 //   part 2: the new step against the round-2 step on one wave, 256 steps, same inputs -> same planes
 //   part 3: cycles per wave-step per SIMD at 1 / 2 / 4 / 8 waves per SIMD, W = 1 and 2 words per lane -- the C++ form as
-//           shipped, and the same block as ONE generated inline-assembly statement (tools/gen_bits_block.py): 4-5 % faster here,
-//           not faster inside nw_fill_bits (profiles/r03_ab_asm_block.txt), so not shipped
-// Build: python tools/gen_bits_block.py build/csadp_bits_block.inc; hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/subco_probe.hip -o build/subco_probe ; run on the GPU box.
+//           shipped, and the same block as ONE generated inline-assembly statement (tools/gen_bits_block.py): with several waves per
+//           SIMD 4-5 % faster here and not faster inside nw_fill_bits (profiles/r03_ab_asm_block.txt); alone on its SIMD 7 % faster at
+//           0 mod 8 ("at 0 mod 8", w1 column) and 10 % in the kernel: shipped for the one-wave-per-SIMD launches
+// Build: python tools/gen_bits_block.py build/csadp_bits_block.inc --probe; hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/subco_probe.hip -o build/subco_probe ; run on the GPU box.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -299,7 +300,7 @@ __global__ void k_time_old(uint32_t *out, const uint32_t *in, int nblocks)
 
 
 /* ---- the same block as ONE generated inline-assembly statement (tools/gen_bits_block.py) --------------- */
-#include "../build/csadp_bits_block.inc"       /* python tools/gen_bits_block.py build/csadp_bits_block.inc */
+#include "../build/csadp_bits_block.inc"       /* python tools/gen_bits_block.py build/csadp_bits_block.inc --probe */
 
 template <int W, int VAR>      /* 0: as shipped (4-byte instructions paired, 8-byte ones at 4 mod 8), 1: unpaired, 2: early borrows, 3: at 0 mod 8 */
 __device__ __forceinline__ void asm_block(StN<W> &S, const uint32_t (&D)[2], const uint32_t (&E)[2], const uint32_t *ip)
