@@ -40,6 +40,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "csadp_device.h"
 #include "csadp_kernels.h"
 
@@ -47,7 +49,7 @@ namespace csadp {
 
 namespace {
 
-constexpr int kRing = 8;                       /* blocks of hand-off words buffered per strip boundary */
+constexpr int kRing = 8;                       /* blocks of hand-off words buffered per strip boundary (a power of two) */
 constexpr unsigned long long kSpinTicks = 50000000ull;   /* bound of every wait: 0.5 s of the 100 MHz s_memrealtime clock */
 
 /* v_bitop3_b32: any boolean function of three words in one instruction; the table is the function
@@ -471,17 +473,21 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 		if (!fetch_granules(1, v1, gA) || !fetch_granules(2, v2, gB)) { if (lane == 0) atomicExch(abort_word, 1); return; }
 	}
 
-	for (int b = 0; b < nb; ++b) {
+	/* one block of 32 steps; the two ramp blocks of a strip and the steady ones are separate loops: inside ONE loop the two
+	 * forms of the step met at a join, and the compiler paid for it with 32 register moves per block (the per-block work is
+	 * 8-12 % of a block of two words, 15-20 % of a block of one) */
+	auto block_of = [&](int b, auto ramp_tag) -> bool {
+		constexpr bool RAMP = decltype(ramp_tag)::value;
 		/* what enters lane 0 during this block: lane t prepares step t.  Carries: the producer's steps 32 b + t + 63 (its lane
 		 * 63 works on row 32 b + t then), i.e. the last step of its block b + 1 and the first 31 of block b + 2 */
 		const int t = lane & 31;
 		uint32_t z2 = 0, z1 = 0, z0 = 0;
 		if (wv > 0) {
 			const int need = (b + 3 < nb) ? b + 3 : nb;
-			if (!wait_at_least<TIGHT>(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!wait_at_least<TIGHT>(&made[wv - 1], need)) { if (lane == 0) atomicExch(abort_word, 1); return false; }
 			uint4 A = make_uint4(0, 0, 0, 0), Bv = make_uint4(0, 0, 0, 0);
-			if (b + 1 < nb) A = *reinterpret_cast<const uint4 *>(ring[wv - 1][(b + 1) % kRing]);
-			if (b + 2 < nb) Bv = *reinterpret_cast<const uint4 *>(ring[wv - 1][(b + 2) % kRing]);
+			if (b + 1 < nb) A = *reinterpret_cast<const uint4 *>(ring[wv - 1][(b + 1) & (kRing - 1)]);
+			if (b + 2 < nb) Bv = *reinterpret_cast<const uint4 *>(ring[wv - 1][(b + 2) & (kRing - 1)]);
 			z2 = carry_bit(A.x, Bv.x, t);
 			z1 = carry_bit(A.y, Bv.y, t);
 			z0 = carry_bit(A.z, Bv.z, t);
@@ -501,16 +507,16 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 			*reinterpret_cast<uint4 *>(&inject[wv][t * kInjWords]) = make_uint4(b00 ^ r0, b10 ^ r1, z2, z1);
 			inject[wv][t * kInjWords + INJ_Z0] = z0;
 		}
-		if (b < 2) bits_block<W, true, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
+		if constexpr (RAMP) bits_block<W, true, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
 		else if constexpr (LONE && W == 1) bits_block_lone(S, K, ip);
 		else bits_block<W, false, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
 		save_state<W>(ck, hand, (size_t)s * nb + b, lane, S);
 		if (feeds) {
 			/* the ring slot of this block last held block b - kRing, which the consumer fetches while preparing its blocks
 			 * b - kRing - 2 and b - kRing - 1 */
-			if (!wait_at_least<TIGHT>(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!wait_at_least<TIGHT>(&taken[wv + 1], b - kRing)) { if (lane == 0) atomicExch(abort_word, 1); return false; }
 			if (lane == kLanes - 1) {
-				*reinterpret_cast<uint4 *>(ring[wv][b % kRing]) = make_uint4(S.acc2, S.acc1, S.acc0, 0u);
+				*reinterpret_cast<uint4 *>(ring[wv][b & (kRing - 1)]) = make_uint4(S.acc2, S.acc1, S.acc0, 0u);
 				__hip_atomic_store(&made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 			}
 		}
@@ -523,10 +529,16 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 			gA[0] = gB[0];
 			gA[1] = gB[1];
 			gA[2] = gB[2];
-			if (!fetch_granules(b + 3, pre, gB)) { if (lane == 0) atomicExch(abort_word, 1); return; }
+			if (!fetch_granules(b + 3, pre, gB)) { if (lane == 0) atomicExch(abort_word, 1); return false; }
 			pre = request(b + 4);
 		}
-	}
+		return true;
+	};
+	const int nramp = nb < 2 ? nb : 2;
+	for (int b = 0; b < nramp; ++b)
+		if (!block_of(b, std::true_type{})) return;
+	for (int b = nramp; b < nb; ++b)
+		if (!block_of(b, std::false_type{})) return;
 }
 
 /*
