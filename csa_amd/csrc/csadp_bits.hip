@@ -605,6 +605,13 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 		return 0u - ((rp[(size_t)plane * J.rowwords + (row >> 5)] >> (row & 31)) & 1u);
 	};
 
+#ifdef CSADP_TB_TIMERS
+	unsigned long long tm_load = 0, tm_replay = 0, tm_walk = 0, tm_sync = 0, tm_mark = __builtin_amdgcn_s_memtime();
+	int tm_rounds = 0;
+#define TB_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_mark; tm_mark = now_; } while (0)
+#else
+#define TB_LAP(acc) do { } while (0)
+#endif
 	while (r > 0 && k > 0) {
 		const int wq = (k - 1) >> cs;                          /* lane column of the current cell */
 		const int s = wq >> 6;
@@ -680,53 +687,53 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 			uint2 *out = &tile[d][j];                          /* a step's row of a tile: [word][lane], so the 16 lanes of a store are contiguous */
 			uint32_t *outm = &mtile[SCORE ? d : 0][SCORE ? j : 0];
 			const bool ramp = btop - 4 * wv - 3 < 2;           /* wave-uniform: some piece of this wave is in block 0 or 1 */
+#ifdef CSADP_TB_TIMERS
+			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+			TB_LAP(tm_load);
 			if (ramp) bits_block<W, true, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
 			else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
+			TB_LAP(tm_replay);
 		}
 		__syncthreads();
+		TB_LAP(tm_sync);
 		if (wv == 0) {
 			const int k0 = k;
+			const uint2 *tiles = &tile[0][0];                  /* the NP tiles are one array: ONE look-up per iteration, no nested regions */
+			[[maybe_unused]] const uint32_t *mtiles = &mtile[0][0];
 			for (;;) {
+				/* lane i looks at cell (r - i, k - i); straight-line: the validity tests are one mask, the address of an invalid
+				 * lane is 0, both masks of the cell come from one 8-byte read (the nested form read them one after the other:
+				 * two LDS round trips per iteration on a wave that has its SIMD to itself) */
 				const int ri = r - lane, ki = k - lane;
-				uint32_t code = 3;                             /* 3 = stop: border or outside the replayed pieces */
+				const int kc = ki - 1;
+				const int wi = kc >> cs;                       /* arithmetic: cells left of the matrix fail the strip test */
+				const int sl = wi & 63;
+				const int l = (ri - 1) + sl;
+				const int d = btop - (l >> 5);
+				const int rel = sl - piece_first_lane<W>(k0, l0, s, d);
+				const bool ok = (ri > 0) & (ki > 0) & ((wi >> 6) == s) & ((unsigned)d < (unsigned)NP) & ((unsigned)rel < 16u);
+				const int at = ok ? d * (kBitBlock * pitch) + (l & 31) * pitch + ((kc >> 5) & (W - 1)) * 16 + rel : 0;
+				const uint2 dd = tiles[at];
+				const uint32_t sh = (uint32_t)kc & 31u;
+				const uint32_t nd = (dd.x >> sh) & 1u, lf = (dd.y >> sh) & 1u;
+				const uint32_t code = ok ? (nd ? lf : (uint32_t)DIR_D) : 3u;      /* U = 0, L = 1, D = 2; 3 = stop: border or outside the pieces */
 				bool match = false;
-				if (ri > 0 && ki > 0) {
-					const int kc = ki - 1;
-					const int wi = kc >> cs;
-					const int sl = wi & 63;
-					const int l = (ri - 1) + sl;
-					const int d = btop - l / kBitBlock;        /* <= btop: l >= 0 */
-					if ((wi >> 6) == s && d >= 0 && d < NP) {
-						const int rel = sl - piece_first_lane<W>(k0, l0, s, d);
-						if (rel >= 0 && rel < 16) {
-							const int at = (l % kBitBlock) * pitch + ((kc >> 5) & (W - 1)) * 16 + rel;
-							const uint2 dd = tile[d][at];
-							const uint32_t bit = 1u << (kc & 31);
-							code = (dd.x & bit) ? ((dd.y & bit) ? (uint32_t)DIR_L : (uint32_t)DIR_U) : (uint32_t)DIR_D;
-							if (SCORE) match = (mtile[SCORE ? d : 0][SCORE ? at : 0] & bit) != 0;
-						}
-					}
-				}
-				/* a run of 'D' and the gap move that ends it are taken in ONE iteration */
+				if (SCORE) match = ok && ((mtiles[SCORE ? at : 0] >> sh) & 1u) != 0;
+				/* a run of 'D' and the gap move that ends it are taken in ONE iteration, written by ONE store */
 				const unsigned long long stop = __ballot(code != DIR_D);
 				const int run = stop ? __builtin_ctzll(stop) : kLanes;
 				const uint32_t c0 = run < kLanes ? (uint32_t)__builtin_amdgcn_readlane((int)code, run) : 3u;
-				if (lane < run) ops[n + lane] = (uint8_t)DIR_D;
+				const int gap = c0 != 3u;
+				if (lane < run + gap) ops[n + lane] = (uint8_t)(lane < run ? (uint32_t)DIR_D : c0);
 				if (SCORE) {
 					const unsigned long long hits = __ballot(match) & (run == kLanes ? ~0ull : ((1ull << run) - 1));
-					score += 2 * __builtin_popcountll(hits) - run;          /* +1 per match, -1 per mismatch */
+					score += 2 * __builtin_popcountll(hits) - run - gap;      /* +1 per match, -1 per mismatch, -1 for the gap */
 				}
-				n += run;
-				r -= run;
-				k -= run;
-				if (c0 == 3) {
-					if (run == 0) break;                            /* border, or outside the replayed pieces */
-					continue;
-				}
-				if (lane == 0) ops[n] = (uint8_t)c0;
-				++n;
-				--score;                                        /* a gap in either sequence */
-				if (c0 == DIR_L) --k; else --r;
+				n += run + gap;
+				r -= run + (gap & (c0 != DIR_L));
+				k -= run + (c0 == DIR_L);
+				if (run + gap == 0) break;                          /* border, or outside the replayed pieces */
 			}
 			if (lane == 0) {
 				pos[0] = r;
@@ -735,13 +742,23 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 				pos[3] = score;
 			}
 		}
+		TB_LAP(tm_walk);
 		__syncthreads();
 		r = pos[0];
 		k = pos[1];
 		n = pos[2];
 		score = pos[3];
 		__syncthreads();
+		TB_LAP(tm_sync);
+#ifdef CSADP_TB_TIMERS
+		++tm_rounds;
+#endif
 	}
+#ifdef CSADP_TB_TIMERS
+	if (threadIdx.x == 0 && blockIdx.x == 0)
+		printf("traceback timers (wave 0, cycles): rounds %d  loads+inputs %llu  replay %llu  walk %llu  barriers %llu  per round %llu\n", tm_rounds, tm_load,
+		       tm_replay, tm_walk, tm_sync, (tm_load + tm_replay + tm_walk + tm_sync) / (tm_rounds ? tm_rounds : 1));
+#endif
 	if (threadIdx.x == 0) {
 		summary[0] = n;
 		summary[1] = r;
