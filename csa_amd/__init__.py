@@ -84,7 +84,7 @@ EXPORTS = [
     "csadp_partition_lpt", "csadp_fnv1a", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
     "csadp_build_anchor_map", "csadp_free_anchor_map", "csadp_msa", "csadp_free_rows", "csadp_write_aligned_fasta",
-    "csadp_debug_align_with_filler", "csadp_debug_pool_selftest",
+    "csadp_debug_align_with_filler", "csadp_debug_pool_selftest", "csadp_debug_set_epoch",
 ]
 
 DEBUG_FILL_FN = ctypes.CFUNCTYPE(
@@ -430,6 +430,14 @@ def read_rotations(path, nmax=64):
     n = ctypes.c_int()
     _check(lib().csadp_read_rotations(path.encode(), rots, nmax, ctypes.byref(n)), "csadp_read_rotations")
     return list(rots[:n.value])
+
+
+def debug_set_epoch(value):
+    """Test seam: set the process-wide epoch counter of the chunked fills' hand-off granules; returns the old value."""
+    L = lib()
+    L.csadp_debug_set_epoch.argtypes = [ctypes.c_uint]
+    L.csadp_debug_set_epoch.restype = ctypes.c_uint
+    return L.csadp_debug_set_epoch(value)
 
 
 def debug_align_with_filler(task, filler):

@@ -777,6 +777,8 @@ int csadp_sp_score(const char *const *aligned, int nseq, csadp_sp_stats *out)
 	return rc;
 }
 
+unsigned csadp_debug_set_epoch(unsigned next) { return Engine::set_epoch_counter(next); }
+
 int csadp_debug_pool_selftest(int items, long long *sum)
 {
 	if (items < 0 || !sum) return CSADP_ERR_ARG;

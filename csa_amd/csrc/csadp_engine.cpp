@@ -111,13 +111,18 @@ void Engine::shutdown_all()
 	g_primary = nullptr;
 }
 
+namespace {
+std::atomic<uint32_t> g_epoch_counter{0};
+}
+
 uint32_t Engine::next_epoch()
 {
-	static std::atomic<uint32_t> counter{0};
 	uint32_t e;
-	do e = (counter.fetch_add(1) + 1) & 0xffffffu; while (e == 0);
+	do e = (g_epoch_counter.fetch_add(1) + 1) & 0xffffffu; while (e == 0);
 	return e;
 }
+
+uint32_t Engine::set_epoch_counter(uint32_t v) { return g_epoch_counter.exchange(v); }
 
 int Engine::bind() const
 {

@@ -39,6 +39,7 @@ public:
 	int rotate_stream() { return stream_rr_.fetch_add(1); }
 	/* 1, 2, ... (never 0 modulo 2^24 within 16 M passes): tags of the hand-off granules of nw_fill_cells */
 	static uint32_t next_epoch();
+	static uint32_t set_epoch_counter(uint32_t v);   /* test seam (csadp_debug_set_epoch) */
 	bool ready() const { return ready_; }
 	static constexpr int kMaxSlots = 32;
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }

@@ -38,6 +38,11 @@ CSADP_API int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_
  * several threads at once. */
 CSADP_API int csadp_debug_pool_selftest(int items, long long *sum);
 
+/* The hand-off granules between the workgroups of a chunked fill are valid when they carry their launch's epoch, a
+ * process-wide counter of 24 bits that never takes the value 0 (freshly zeroed granules must never look valid).
+ * Sets the counter, so that a test can put launches either side of its wrap; returns the previous value. */
+CSADP_API unsigned csadp_debug_set_epoch(unsigned next);
+
 #ifdef __cplusplus
 }
 #endif

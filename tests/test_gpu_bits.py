@@ -262,6 +262,28 @@ def test_device_path_scores_cross_checked(monkeypatch):
     assert all(g["status"] == 0 for g in got)
 
 
+def test_chunked_fills_either_side_of_the_epoch_wrap():
+    """The granules between the workgroups of a chunked fill (bit-parallel and cell-per-lane) are valid when they carry their
+    launch's epoch, 24 bits of a process-wide counter that skips 0 -- zeroed granules must never look valid (round-2 ADVICE: a
+    21-bit tag that could be 0 let a consumer take unwritten words).  Six chunked passes with the counter set just below its
+    wrap: epochs 0xfffffe, 0xffffff, 1, 2, ... -- every result the oracle's."""
+    r = rng(707)
+    a, b = related(r, 9000, None)                      # one pair, 5 strips: two chunks of four (one wave per SIMD)
+    fam = [related(r, 900, None)[1] for _ in range(3)]   # profile steps of 8 strips: two chunks of the cell-per-lane kernel
+    want_pair = oracle_progressive([a, b], [5, 3])
+    want_fam = oracle_progressive(fam, None)
+    old = csa_amd.debug_set_epoch(0xfffffd)
+    try:
+        for _ in range(3):
+            g = csa_amd.align_batch([([a, b], [5, 3], None, None)])[0]
+            assert g["status"] == 0 and g["aligned"] == want_pair[1] and g["score"] == want_pair[2].last_score
+            g = csa_amd.align_batch([(fam, None, None, None)])[0]
+            assert g["status"] == 0 and g["aligned"] == want_fam[1]
+        assert csa_amd.debug_set_epoch(0) > 0xffffff       # the raw counter went past 24 bits: the epochs wrapped, skipping 0
+    finally:
+        csa_amd.debug_set_epoch(max(old, 16))
+
+
 def test_abort_word_triggers_the_chunk_by_chunk_repeat(monkeypatch, capfd):
     """The chunked fills (nw_fill_bits_wide, nw_fill_cells) wait across workgroups with bounded spins; when
     one runs out the batch's abort word is raised and the host repeats the pass chunk by chunk -- one launch
