@@ -147,6 +147,7 @@ int Engine::init(int dev, const csadp_config *cfg)
 	nstreams_ = 2 * main_streams();
 	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+	HIP_TRY(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
 	HIP_TRY(configure_kernels());                     /* per-device function attributes (csadp_bits.hip) */
 	verbose_ = cfg && cfg->verbose;
 	ready_ = true;
@@ -246,6 +247,11 @@ void Engine::shutdown()
 		(void)hipStreamSynchronize(copy_stream_);
 		(void)hipStreamDestroy(copy_stream_);
 		copy_stream_ = nullptr;
+	}
+	if (upload_stream_) {
+		(void)hipStreamSynchronize(upload_stream_);
+		(void)hipStreamDestroy(upload_stream_);
+		upload_stream_ = nullptr;
 	}
 	ready_ = false;
 }
@@ -829,15 +835,21 @@ int FillBatch::upload()
 	return CSADP_OK;
 }
 
-/* inputs -> HBM without waiting.  The copy runs on the engine's stream 0 and an event makes every other
- * stream of the engine wait for it, so passes may be enqueued right away (device-I/O pair batches: the
+/* inputs -> HBM without waiting.  The copy runs on the engine's upload stream (profile batches: stream 0) and an
+ * event makes every compute stream of the engine wait for it, so passes may be enqueued right away (device-I/O pair batches: the
  * host never blocks between create and fetch). */
 int FillBatch::upload_async()
 {
 	if (!laid_out_) return CSADP_ERR_STATE;
 	{ const int brc = E_->bind(); if (brc != CSADP_OK) return brc; }
 	const int nst = E_->nstreams();
-	hipStream_t s0 = E_->stream(bits_ ? base_stream_ : 0);
+	/* pair batches upload on a stream of their own: on the fill stream the copy of batch n+2 queued behind the fill
+	 * of batch n+1 (streams are FIFO) and the device idled through it; a batch that is uploaded AGAIN first lets
+	 * its own earlier passes drain */
+	hipStream_t s0 = bits_ ? E_->upload_stream() : E_->stream(0);
+	if (bits_)
+		for (int first = 0; first < Engine::kMaxSlots && first < 64; ++first)
+			if ((issued_ >> first) & 1ull) HIP_TRY(hipStreamWaitEvent(s0, ev_[first][2], 0));
 	if (bits_ && bits_wide_ && hand_bytes_ > 0)
 		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, s0));
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, s0));

@@ -51,6 +51,7 @@ public:
 	/* result downloads and abort-word reads of batches that have finished: a stream of its own, so that they never
 	 * queue behind what LATER batches have put on the compute streams */
 	hipStream_t copy_stream() const { return copy_stream_; }
+	hipStream_t upload_stream() const { return upload_stream_; }
 	int device() const { return device_; }
 	const char *name() const { return name_; }
 	int compute_units() const { return cus_; }
@@ -79,6 +80,7 @@ private:
 	int slots_ = 2, nstreams_ = 0;
 	hipStream_t streams_[2 * kMaxSlots] = {};
 	hipStream_t copy_stream_ = nullptr;
+	hipStream_t upload_stream_ = nullptr;
 	std::atomic<int> stream_rr_{0};
 	std::mutex pool_mutex_;
 	std::vector<std::pair<uint8_t *, size_t>> arena_pool_, pinned_pool_;
