@@ -4,7 +4,7 @@
  * (dynamicprogramming.c:1037-1047).  gfx950, wave64.
  *
  *   nw_fill_cells<WIDE>    K1c: a lane owns two adjacent columns, a wave 128, a workgroup kCellWaves strips
- *   nw_traceback_cells     K2d: the run-batched walk over K1c's direction words
+ *   (the direction walk over K1c's tags: csadp_cells_tb.hip)
  *
  * Why this shape.  The reference's own use of the DP (mode N) is a handful of wide gaps, each a chain
  * of up to 63 strictly sequential profile fills: what counts is the LATENCY of one fill, and a fill's
@@ -432,137 +432,6 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }
 
-/*
- * K2d.  Cell (j, k), 1-based: column c = k - 1 lives in strip S = c / 128, lane (c % 128) / 2, half h = c % 2
- * (column A or B of the lane), at local step l = (j - 1) + lane.  Word l / 16 of "virtual strip" 2S + h holds its
- * tag at bits 2 * (l % 16).  Along a diagonal move the row falls by one and the lane by one every second column, so
- * while the path crosses one strip (128 columns) l falls by ~192 = 12 words: the LDS window holds, for each of the
- * kTbStrips strips left of the current cell and both halves, the kTbWords words around the expected crossing --
- * 8 x 2 x 16 x 64 words = 64 KiB, loaded as whole 256-byte rows by the four waves.  Wave 0 then walks run-batched
- * (lane i looks at cell (j-i, k-i), a ballot finds the end of the run of 'D'); leaving the window just reloads it
- * around the current cell.
- */
-static_assert(kCellStripCols == 128, "the walk's shifts assume 128 columns per strip");
-constexpr int kTbStrips = 4;
-constexpr int kTbWords = 32;
-constexpr int kTbSlack = 8;          /* words above the expected entry point of a strip */
-constexpr int kTbExtra = 2;          /* rounds taken from the fetched words after a look-up's own */
-
-__global__ __launch_bounds__(256) void nw_traceback_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs)
-{
-	__shared__ __attribute__((aligned(16))) uint32_t win[kTbStrips * kCellCols * kTbWords * kLanes];
-	__shared__ int wlo[kTbStrips];
-	__shared__ int pos[3];
-
-	const CellJob &J = jobs[blockIdx.x];
-	uint8_t *ops = arena + J.ops;
-	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
-	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const int wpitch = J.steps_pad / 16;                      /* words per (virtual strip, lane) */
-	int j = J.nrows, k = J.ncols;
-	int n = 0;
-
-	while (j > 0 && k > 0) {
-		const int s0 = (k - 1) >> 7;                              /* kCellStripCols = 128 */
-		if (tid < kTbStrips) {
-			/* strip s0 - tid: the path is expected at its right edge (column 128*s + 127, lane 63) in row
-			 * j - (k - 1 - that column); for the current strip that point is extrapolated to the right */
-			const int sB = s0 - tid;
-			const int jedge = j - ((k - 1) - (kCellStripCols * sB + kCellStripCols - 1));
-			wlo[tid] = ((jedge - 1 + (kLanes - 1)) >> 4) + kTbSlack - (kTbWords - 1);
-		}
-		__syncthreads();
-		/* kTbStrips * 2 * kTbWords rows of 256 bytes = 16 uint4 per row; slot = strip block * 2 + half */
-		for (int e = tid; e < kTbStrips * kCellCols * kTbWords * 16; e += 256) {
-			const int slot = e / (kTbWords * 16), u = (e / 16) % kTbWords, q = e % 16;
-			const int sB = s0 - slot / kCellCols, w = wlo[slot / kCellCols] + u;
-			uint4 v = make_uint4(0, 0, 0, 0);
-			if (sB >= 0 && w >= 0 && w < wpitch)
-				v = *reinterpret_cast<const uint4 *>(dirs + ((size_t)(sB * kCellCols + slot % kCellCols) * wpitch + w) * kLanes + 4 * q);
-			reinterpret_cast<uint4 *>(win)[e] = v;
-		}
-		__syncthreads();
-		if (wave == 0) {
-			/* lane b < kTbStrips keeps wlo[b] in a register: the 64 cells of an iteration touch at most two
-			 * strips, whose window origins are fetched with v_readlane instead of a second LDS round trip */
-			const int wreg = lane < kTbStrips ? wlo[lane] : 0;
-			for (;;) {
-				/* one iteration = one LDS look-up per lane, straight-line: lane i looks at cell (j - i, k - i) */
-				const int kc = k - 1;                           /* 0-based column of lane 0's cell */
-				const int Bk = s0 - (kc >> 7);                  /* its strip block (wave-uniform) */
-				if (Bk >= kTbStrips) break;
-				const int wloA = __builtin_amdgcn_readlane(wreg, Bk);
-				const int wloB = __builtin_amdgcn_readlane(wreg, Bk + 1 < kTbStrips ? Bk + 1 : Bk);
-				const int ri = j - lane, kz = kc - lane;        /* row (1-based), column (0-based): outside the matrix when <= 0 / < 0 */
-				const int sc = kz >> 7;                         /* arithmetic: negative columns give a strip that fails the tests below */
-				const int B = s0 - sc;
-				const int ln = (kz & (kCellStripCols - 1)) >> 1;   /* the lane that owns the column */
-				const int l = ri - 1 + ln;                      /* local step of the cell in its strip */
-				const int u = (l >> 4) - (sc == (kc >> 7) ? wloA : wloB);
-				const bool ok = (ri > 0) & (kz >= 0) & (B < kTbStrips) & ((unsigned)u < (unsigned)kTbWords);
-				const uint32_t w = win[ok ? ((B * kCellCols + (kz & 1)) * kTbWords + u) * kLanes + ln : 0];
-				const uint32_t code = ok ? (w >> (2 * (l & 15))) & 3u : 3u;     /* 3 = stop: border or outside the window */
-				/* a run of 'D' and the gap move that ends it are taken in ONE iteration, written by ONE store */
-				const unsigned long long stop = __ballot(code != DIR_D);
-				const int run = stop ? __builtin_ctzll(stop) : kLanes;
-				const uint32_t c0 = run < kLanes ? (uint32_t)__builtin_amdgcn_readlane((int)code, run) : 3u;
-				const int gap = c0 != 3u;
-				if (lane < run + gap) ops[n + lane] = (uint8_t)(lane < run ? (uint32_t)DIR_D : c0);
-				n += run + gap;
-				j -= run + (gap & (c0 != DIR_L));
-				k -= run + (c0 == DIR_L);
-				if (run + gap == 0) break;                      /* border reached or window left: the outer loop decides */
-				/* More rounds out of the SAME words: after a gap move the cells of the new diagonal are the fetched
-				 * columns one row up (after U) or down (after L) -- in the same word 15 times out of 16, since a word
-				 * holds 16 consecutive rows of its column.  Lane q >= p looks at its column again, p = columns consumed,
-				 * delta = rows the diagonal has drifted.  No look-up, ~1/3 of an iteration's cost; kTbExtra rounds at
-				 * most (every further one finds fewer of its tags in the fetched words). */
-				int p = run + (c0 == DIR_L), delta = 0;
-				uint32_t last = c0;
-				bool more = gap != 0;
-#pragma unroll
-				for (int extra = 0; extra < kTbExtra; ++extra) {
-					if (!more || p >= kLanes) break;
-					delta += last == DIR_L ? 1 : -1;
-					const int l2 = l + delta;
-					const bool ok2 = ok & (lane >= p) & (ri + delta > 0) & ((l2 >> 4) == (l >> 4));
-					const uint32_t code2 = ok2 ? (w >> (2 * (l2 & 15))) & 3u : 3u;
-					const unsigned long long stop2 = __ballot(code2 != DIR_D) >> p;
-					const int left = kLanes - p;
-					const int run2 = stop2 ? __builtin_ctzll(stop2) : left;
-					const uint32_t c2 = run2 < left ? (uint32_t)__builtin_amdgcn_readlane((int)code2, p + run2) : 3u;
-					const int gap2 = c2 != 3u;
-					const int i2 = lane - p;
-					if (i2 >= 0 && i2 < run2 + gap2) ops[n + i2] = (uint8_t)(i2 < run2 ? (uint32_t)DIR_D : c2);
-					n += run2 + gap2;
-					j -= run2 + (gap2 & (c2 != DIR_L));
-					k -= run2 + (c2 == DIR_L);
-					p += run2 + (c2 == DIR_L);
-					last = c2;
-					more = gap2 != 0;
-				}
-			}
-			if (lane == 0) {
-				pos[0] = j;
-				pos[1] = k;
-				pos[2] = n;
-			}
-		}
-		__syncthreads();
-		j = pos[0];
-		k = pos[1];
-		n = pos[2];
-		__syncthreads();
-	}
-	if (tid == 0) {
-		summary[0] = n;
-		summary[1] = j;
-		summary[2] = k;
-		summary[3] = 0;
-	}
-}
-
 hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,
                              hipStream_t st)
 {
@@ -570,13 +439,6 @@ hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, con
 	epoch &= 0xffffffu;                                /* 24 bits travel in a granule */
 	if (wide) hipLaunchKernelGGL(nw_fill_cells<true>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, epoch, abort_word);
 	else hipLaunchKernelGGL(nw_fill_cells<false>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, epoch, abort_word);
-	return hipGetLastError();
-}
-
-hipError_t launch_traceback_cells(uint8_t *arena, const CellJob *jobs, int njobs, hipStream_t st)
-{
-	if (njobs <= 0) return hipSuccess;
-	hipLaunchKernelGGL(nw_traceback_cells, dim3(njobs), dim3(256), 0, st, arena, jobs);
 	return hipGetLastError();
 }
 

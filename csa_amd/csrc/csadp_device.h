@@ -128,8 +128,28 @@ struct CellJob {
 	int32_t steps_pad;        /* local steps per strip, multiple of kCellBlock, >= nrows + 64                              */
 	int32_t nprev;            /* i                                                                                          */
 	int32_t leftmul;          /* X of border column 0 is leftmul * r                                                       */
+	int32_t banded;           /* 1: the band-parallel traceback (csadp_cells_tb.hip); 0: one serial walk                   */
+	/* band-parallel traceback: bands of kBandRows rows, band b = rows (b*R, min((b+1)*R, nrows)], entered in its bottom row */
+	uint64_t tb_tab;          /* u16 [nbands][tb_pitch]: the walk from the x-th scouted start column of band b leaves the   */
+	                          /*     band `value` columns further left; kBandUnknown: not finished inside the band        */
+	uint64_t tb_ent;          /* i32 [nbands + 2]: column in which the path enters band b (-1: never); then end row, end column */
+	uint64_t tb_cnt;          /* i32 [nbands]: ops of band b                                                               */
+	uint64_t tb_scratch;      /* u8 [nrows + ncols + 64]: the ops of band b from (nrows - entry row) + (ncols - entry column) on */
+	int32_t nbands;           /* ceil(nrows / kBandRows)                                                                   */
+	int32_t tb_pitch;         /* entries per band in tb_tab: the scouted starts, tb_groups * kScoutStarts                  */
+	int32_t tb_groups;        /* groups of kScoutStarts start columns scouted per band, around the corner-to-corner line    */
 	int32_t pad_;
 };
+
+/* band-parallel traceback of the profile steps */
+constexpr int kBandRows = 128;       /* rows per band (multiple of 16: a band starts on a direction-word boundary)          */
+constexpr int kBandStride = 16;      /* columns between the scouts' start columns                                           */
+constexpr int kBandWords = kBandRows / 16 + 4;   /* direction words of one column that hold a band's rows, lane skew included */
+constexpr int kScoutStarts = 64;     /* start columns per scout workgroup (a lane each): 1024 columns = 8 strips            */
+constexpr int kScoutStrips = kScoutStarts * kBandStride / 128 + 3;     /* strips staged in LDS by a scout workgroup: 66 KiB */
+constexpr int kScoutCap = 2 * kBandRows + 64;                          /* steps after which a scout gives up                */
+constexpr int kEmitStrips = 4;       /* strips staged by an emitting workgroup                                              */
+constexpr unsigned kBandUnknown = 0xffffu;
 
 }  // namespace csadp
 

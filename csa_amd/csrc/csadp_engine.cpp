@@ -149,6 +149,7 @@ int Engine::init(int dev, const csadp_config *cfg)
 	HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
 	HIP_TRY(configure_kernels());                     /* per-device function attributes (csadp_bits.hip) */
+	HIP_TRY(configure_traceback_cells());
 	verbose_ = cfg && cfg->verbose;
 	ready_ = true;
 	return CSADP_OK;
@@ -360,6 +361,9 @@ int FillBatch::layout_cells()
 	Engine &E = *E_;
 	const int nj = (int)jobs_.size();
 	cells_mode_ = true;
+	const int band_min = env_int("CSADP_TB_BAND_MIN", 512);       /* rows; 0x7fffffff: never */
+	const int tb_corridor = env_int("CSADP_TB_CORRIDOR", 3);      /* groups of 1024 start columns scouted per band */
+	tb_max_bands_ = tb_max_groups_ = 0;
 	cjobs_.assign((size_t)nj, CellJob());
 	tiles_.clear();
 	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
@@ -381,6 +385,16 @@ int FillBatch::layout_cells()
 		C.steps_pad = (int)align_up((size_t)J.nrows + 64, kCellBlock);
 		J.nstrips = C.nstrips;
 		J.steps_pad = C.steps_pad;
+		/* the walk band-parallel from band_min rows on (csadp_cells_tb.hip); smaller matrices by one serial walk */
+		C.nbands = (J.nrows + kBandRows - 1) / kBandRows;
+		C.banded = J.nrows >= band_min ? 1 : 0;
+		if (C.banded) {
+			const int ngroups = (J.ncols / kBandStride + 1 + kScoutStarts - 1) / kScoutStarts;
+			C.tb_groups = std::min(ngroups, std::max(1, tb_corridor));
+			C.tb_pitch = C.tb_groups * kScoutStarts;
+			tb_max_bands_ = std::max(tb_max_bands_, C.nbands);
+			tb_max_groups_ = std::max(tb_max_groups_, C.tb_groups);
+		}
 		extra_[(size_t)j].ncols_pad = C.nstrips * kCellStripCols;
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)C.nstrips * kCellCols * (C.steps_pad / 16) * kLanes * 4;
@@ -456,6 +470,18 @@ int FillBatch::layout_cells()
 			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
 			C.dirs = off;
 			off = align_up(off + (size_t)C.nstrips * kCellCols * (C.steps_pad / 16) * kLanes * 4, 256);
+		}
+		for (int j = 0; j < nj; ++j) {
+			CellJob &C = slot_jobs[(size_t)sl][(size_t)j];
+			if (!C.banded) continue;
+			C.tb_tab = off;
+			off = align_up(off + (size_t)C.nbands * C.tb_pitch * 2, 256);
+			C.tb_ent = off;
+			off = align_up(off + ((size_t)C.nbands + 2) * 4, 256);
+			C.tb_cnt = off;
+			off = align_up(off + (size_t)C.nbands * 4, 256);
+			C.tb_scratch = off;
+			off = align_up(off + (size_t)C.nrows + C.ncols + 64, 256);
 		}
 		hand_off_[sl] = off;                          /* the hand-off granules of all jobs, contiguous: zeroed by upload() */
 		for (int j = 0; j < nj; ++j) {
@@ -538,8 +564,6 @@ int FillBatch::layout_bits()
 	bits_group_ = 1;
 	nslots_ = 1;
 	if (pipelined_) {
-		long long strips = 0;
-		for (const BitJob &B : bjobs_) strips += B.nstrips;
 		const int dflt_streams = 2;
 		/* passes per launch: one workgroup per compute unit (tools/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
 		 * per lane 2 streams x 2 passes = two waves per SIMD runs 44 TCUPS, 4 x 2 39-43, 2 x 4 37-40: more workgroups than compute
@@ -1031,7 +1055,7 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	if (!serial && test_abort_)                           /* testing: pretend a bounded wait ran out, so that the repeat path runs */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
-	HIP_TRY(launch_traceback_cells(arena_, cj, (int)cjobs_.size(), st));
+	HIP_TRY(launch_traceback_cells(arena_, cj, (int)cjobs_.size(), tb_max_bands_, tb_max_groups_, st));
 	HIP_TRY(hipEventRecord(ev[2], st));
 	slot_used_[sl] = true;
 	return CSADP_OK;

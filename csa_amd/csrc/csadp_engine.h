@@ -191,6 +191,7 @@ private:
 	bool test_abort_ = false;                     /* CSADP_TEST_FORCE_ABORT, read when the batch is laid out */
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	unsigned used_streams_ = 0;
+	int tb_max_bands_ = 0, tb_max_groups_ = 0;     /* band-parallel traceback: most bands / scout groups of a banded job */
 	unsigned long long issued_ = 0;             /* bit-parallel path: slot ranges (by first slot) with a launch on record */
 	int wait_batch();                           /* ... and the wait for exactly those launches (events, not streams) */
 	size_t abort_off_ = 0, serial_off_ = 0;

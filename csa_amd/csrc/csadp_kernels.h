@@ -25,7 +25,10 @@ hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, 
 /* epoch: a value no earlier launch on this memory has used (24 bits): it tags the hand-off granules between chunks */
 hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,
                              hipStream_t st);
-hipError_t launch_traceback_cells(uint8_t *arena, const CellJob *jobs, int njobs, hipStream_t st);
+/* csadp_cells_tb.hip: the direction walk.  max_bands = 0: every matrix by one serial walk (CellJob::banded all 0);
+ * else the most bands / scout groups of any banded job of the batch (scout, resolve, emit, gather) */
+hipError_t configure_traceback_cells();
+hipError_t launch_traceback_cells(uint8_t *arena, const CellJob *jobs, int njobs, int max_bands, int max_groups, hipStream_t st);
 /* csadp_pairio.hip: 2-sequence tasks whose letters live in the arena (BitJob::text): bit planes from
  * the raw circular texts, and the two aligned rows + the DP score from the traceback's op list */
 hipError_t launch_pack_planes(uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st);

@@ -26,18 +26,24 @@ def device():
 # families.  Batches of 2-sequence tasks in bit-parallel mode also pack their inputs and build their rows
 # on the device (csadp_pairio.hip); "bits-hostio" switches that off: tables written and traces applied by
 # the host, as for N sequences.  (The tiled 32-bit and packed-16 families of rounds 1-2 are gone.)
-@pytest.fixture(params=["bits", "bits-hostio", "cells"])
+# The direction walk of the 32-bit kernel is one serial walk for matrices of fewer than 512 rows and band-parallel
+# from there on (csadp_cells_tb.hip; CSADP_TB_BAND_MIN, read at every batch layout): "cells-banded" makes every
+# matrix, a one-row one included, take the scout / resolve / emit / gather kernels, "cells" none.
+@pytest.fixture(params=["bits", "bits-hostio", "cells", "cells-banded"])
 def fill_mode(request, monkeypatch):
     if request.param == "bits-hostio":
         monkeypatch.setenv("CSADP_DEVICE_IO", "0")
     elif request.param != "bits":
         monkeypatch.setenv("CSADP_BITS", "0")
+        monkeypatch.setenv("CSADP_TB_BAND_MIN", "1" if request.param == "cells-banded" else "2000000000")
     return request.param
 
 
 # Profile steps (i >= 2, stale borders) run the persistent cell-per-lane kernel (csadp_cells.hip).
-@pytest.fixture(params=["cells"])
-def profile_mode(request):
+@pytest.fixture(params=["cells", "cells-banded", "cells-default"])
+def profile_mode(request, monkeypatch):
+    if request.param != "cells-default":
+        monkeypatch.setenv("CSADP_TB_BAND_MIN", "1" if request.param == "cells-banded" else "2000000000")
     return request.param
 
 
@@ -123,8 +129,8 @@ def test_families_vs_oracle_medium(profile_mode):
         assert g["cells"] == st.cells and g["fills"] == st.fills
 
 
-@pytest.mark.parametrize("length", [1, 2, 31, 63, 64, 65, 191, 255, 256, 257, 513, 1030, 4100])
-def test_cells_kernel_strip_chunk_and_block_boundaries(length):
+@pytest.mark.parametrize("length", [1, 2, 31, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 513, 1030, 4100])
+def test_cells_kernel_strip_chunk_and_block_boundaries(length, profile_mode):
     """nw_fill_cells / nw_traceback_cells at the boundaries of their geometry: a lane per column, 64 per
     strip, 4 strips per workgroup (wider jobs chain workgroups through HBM), 32 steps per hand-off block,
     16 steps per direction word, a 16-strip traceback window.  Families of 3..6 sequences (profile steps,
@@ -147,9 +153,10 @@ def test_cells_kernel_strip_chunk_and_block_boundaries(length):
         assert g["score"] == st.last_score and g["fills"] == st.fills
 
 
-def test_cells_kernel_paths_that_leave_the_traceback_window():
+def test_cells_kernel_paths_that_leave_the_traceback_window(profile_mode):
     """Profiles whose optimal path drifts far from the diagonal (a 700-letter insertion in the middle of the
-    row sequence): the walk leaves its LDS window and must reload it around the current cell."""
+    row sequence): the walk leaves its LDS window and must reload it around the current cell; the band-parallel
+    walk meets bands that are crossed by hundreds of L moves (scouts give up: the band is walked exactly)."""
     r = rng(4711)
     base = bytes(r.choice(b"ACGT") for _ in range(2500))
     ins = bytes(r.choice(b"ACGT") for _ in range(700))
@@ -160,6 +167,34 @@ def test_cells_kernel_paths_that_leave_the_traceback_window():
     for (f, rot), g in zip([(fam, [0, 0, 0, 0]), (fam[::-1], [3, 2, 1, 0])], got):
         cons, strs, st = oracle_progressive(f, rot)
         assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score
+
+
+def test_banded_traceback_unmerged_bands_early_ends_and_borders(monkeypatch):
+    """The band-parallel walk where its shortcuts do not apply: unrelated sequences (flanking scouts rarely merge inside a
+    band), a path that reaches column 0 or row 0 far from the corner (few rows under many columns and the reverse), entry
+    columns right of the last start column, row counts either side of the band height, and a low-complexity profile whose
+    ties send the scouts along long runs of L.  Every fill against the oracle, with the serial walk beside it."""
+    r = rng(8128)
+    def rand(n):
+        return bytes(r.choice(b"ACGT") for _ in range(n))
+    base = rand(3000)
+    tasks = [
+        ([rand(1500), rand(1400), rand(1600)], [0, 0, 0], None, None),                     # unrelated
+        ([base[:90], base, base[100:2900]], [0, 0, 0], None, None),                         # 90 rows under 3000 columns
+        ([base, base[2000:2100], base[5:]], [0, 0, 0], None, None),
+        ([base[:1000] + base[1900:], base, base[:128 * 7]], [0, 0, 0], None, None),         # a 900-column run of L; 896 rows
+        ([b"A" * 700 + rand(300) + b"AC" * 300, b"A" * 650 + rand(280) + b"AC" * 330, b"A" * 900 + b"AC" * 200], [0, 0, 0], None, None),
+        ([base[:128 * 3 + 1], base[:128 * 3 - 1], base[:128 * 3]], [0, 0, 0], None, None),
+    ]
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    # CSADP_TB_CORRIDOR: groups of 1024 start columns scouted per band around the corner-to-corner line (default 3)
+    for band_min, corridor in (("1", "3"), ("1", "1"), ("1", "1000"), ("2000000000", "3")):
+        monkeypatch.setenv("CSADP_TB_BAND_MIN", band_min)
+        monkeypatch.setenv("CSADP_TB_CORRIDOR", corridor)
+        got = csa_amd.align_batch(tasks)
+        for (cons, strs, st), g in zip(want, got):
+            assert g["status"] == 0 and g["consensus"] == cons
+            assert g["aligned"] == strs and g["score"] == st.last_score and g["fills"] == st.fills
 
 
 def test_device_io_alphabet_regions_and_rotations():
