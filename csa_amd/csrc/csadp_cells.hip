@@ -244,7 +244,10 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	 * the round trip through memory (~1.3 us) is longer than a block (~0.8 us); the loop below is unrolled by two
 	 * so that each of the two requests in flight has its own register and no copy waits for it early. */
 	unsigned long long preA = 0, preB = 0;
-	const int last_granule = J.steps_pad - 1;                   /* requests past the end repeat this one; nobody looks at them */
+	/* the job's fields the loop needs, in registers: the block is an asm statement with a "memory" clobber, after which
+	 * the compiler read them from the job record again -- a scalar load and its wait in front of every block */
+	const int steps_pad = J.steps_pad, leftmul = ROLE == ROLE_FIRST ? J.leftmul : 0;
+	const int last_granule = steps_pad - 1;                     /* requests past the end repeat this one; nobody looks at them */
 	if (ROLE == ROLE_CHUNK) {
 		granule_request(preA, hand_in + min(63 + t, last_granule));
 		granule_request(preB, hand_in + min(kCellBlock + 63 + t, last_granule));
@@ -277,7 +280,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			int spins = 0;
 			unsigned long long t0 = 0;
 			for (;;) {
-				const bool ok = ps >= J.steps_pad || (uint32_t)(v >> 40) == epoch;
+				const bool ok = ps >= steps_pad || (uint32_t)(v >> 40) == epoch;
 				if (__all(ok)) break;
 				__builtin_amdgcn_s_sleep(2);
 				if (spins == 0) t0 = __builtin_amdgcn_s_memrealtime();
@@ -309,15 +312,15 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
 			known_taken = __hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		const int32_t xfirst = J.leftmul * (b * kCellBlock + 1);   /* border column: X[r][0] = leftmul * r (:967) */
+		const int32_t xfirst = leftmul * (b * kCellBlock + 1);     /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
 		if (b < 2) {
-			cell_block_ramp<WIDE, ROLE>(S, window + 3, xfirst, J.leftmul, lw, lanebuf, words, b * kCellBlock, lane);
+			cell_block_ramp<WIDE, ROLE>(S, window + 3, xfirst, leftmul, lw, lanebuf, words, b * kCellBlock, lane);
 			if (b == 1) {                                       /* the hand-scheduled blocks keep D = diag + leftc */
 				S.A.diag += S.A.leftc;
 				S.B.diag += S.B.leftc;
 			}
 		} else {
-			cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, J.leftmul, lw, lanebuf, words);
+			cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words);
 		}
 		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers */
 			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

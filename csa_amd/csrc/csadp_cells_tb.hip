@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 	const int jtop = b * kBandRows;
 	int j = jtop + kBandRows, k = i < nstarts ? i * kBandStride : 0;
 	bool lost = false;
+	int nleft = 0;                                                     /* L moves so far */
 	/* branch-free step: lanes that are done, or whose walk has left the staged strips (a run of L nobody near the path
 	 * takes), idle; 25 instructions and one LDS read per step */
 	for (int steps = 0; steps < kScoutCap; ++steps) {
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 		const bool in = live & (ds < (unsigned)kScoutStrips) & (dw < (unsigned)kBandWords);
 		const uint32_t word = lds[in ? ((ds * kCellCols + (c & 1)) * kBandWords + dw) * kLanes + ln : 0];
 		const uint32_t tag = (word >> (2 * (l & 15))) & 3u;
-		lost |= live & !in;
+		nleft += tag == DIR_L;
+		lost |= live & (!in | (nleft > kScoutMaxLeft));                  /* many L moves: a start right of the path on its (slow) way to it */
 		j -= in & (tag != DIR_L);
 		k -= in & (tag != DIR_U);
 #ifdef CSADP_TB_STATS

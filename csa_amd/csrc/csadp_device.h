@@ -147,7 +147,8 @@ constexpr int kBandStride = 16;      /* columns between the scouts' start column
 constexpr int kBandWords = kBandRows / 16 + 4;   /* direction words of one column that hold a band's rows, lane skew included */
 constexpr int kScoutStarts = 64;     /* start columns per scout workgroup (a lane each): 1024 columns = 8 strips            */
 constexpr int kScoutStrips = kScoutStarts * kBandStride / 128 + 3;     /* strips staged in LDS by a scout workgroup: 66 KiB */
-constexpr int kScoutCap = 2 * kBandRows + 64;                          /* steps after which a scout gives up                */
+constexpr int kScoutMaxLeft = 128;   /* L moves after which a scout gives up (a band the path crosses so is walked exactly) */
+constexpr int kScoutCap = kBandRows + kScoutMaxLeft + 1;               /* steps a scout can take                            */
 constexpr int kEmitStrips = 4;       /* strips staged by an emitting workgroup                                              */
 constexpr unsigned kBandUnknown = 0xffffu;
 
