@@ -131,7 +131,7 @@ def test_families_vs_oracle_medium(profile_mode):
 
 @pytest.mark.parametrize("length", [1, 2, 31, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 513, 1030, 4100])
 def test_cells_kernel_strip_chunk_and_block_boundaries(length, profile_mode):
-    """nw_fill_cells / nw_traceback_cells at the boundaries of their geometry: a lane per column, 64 per
+    """nw_fill_cells and the direction walk (csadp_cells_tb.hip) at the boundaries of their geometry: a lane per column, 64 per
     strip, 4 strips per workgroup (wider jobs chain workgroups through HBM), 32 steps per hand-off block,
     16 steps per direction word, a 16-strip traceback window.  Families of 3..6 sequences (profile steps,
     stale borders, DeleteGappedColumns between them) against the oracle, string for string."""

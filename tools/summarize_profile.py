@@ -17,9 +17,7 @@ import os
 import shutil
 import sys
 
-KERNELS = ["nw_fill_bits", "nw_traceback_replay", "nw_fill_cells", "nw_traceback_cells", "nw_pack_planes", "nw_expand_rows",
-
-           "sp_columns"]
+KERNELS = ["nw_fill_bits", "nw_traceback_replay", "nw_fill_cells", "nw_tb_scout", "nw_tb_resolve", "nw_tb_emit", "nw_tb_gather", "nw_pack_planes", "nw_expand_rows", "sp_columns"]
 
 
 def kernel_key(name):
