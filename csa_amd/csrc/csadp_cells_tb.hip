@@ -288,7 +288,36 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 #ifdef CSADP_TB_STATS
 	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-	stage_band(lds, dirs, wpitch, J.nstrips, W.sLo, W.nS, W.wLo, threadIdx.x, 256);
+	/* The scouts' window interleaves the two halves of a strip: word w of column c of strip ds sits at
+	 * [(ds * kBandWords + w) * 128 + c % 128], so a step's address is a multiply-add and an OR instead of the
+	 * half / lane arithmetic of the direction words' own layout (a third of the step's instructions). */
+	{
+		constexpr int kDepth = 8;
+		const int total = kScoutStrips * kCellCols * kBandWords * 16;     /* uint4 units of 4 lanes of one half */
+		for (int e0 = threadIdx.x; e0 < total; e0 += 256 * kDepth) {
+			uint4 v[kDepth];
+#pragma unroll
+			for (int x = 0; x < kDepth; ++x) {
+				const int e = e0 + x * 256;
+				const int slot = e / (kBandWords * 16), u = (e / 16) % kBandWords, q = e % 16;
+				const int sB = W.sLo + slot / kCellCols, w = W.wLo + u;
+				v[x] = make_uint4(0, 0, 0, 0);
+				if (e < total && sB >= 0 && sB < J.nstrips && w < wpitch)
+					v[x] = *reinterpret_cast<const uint4 *>(dirs + ((size_t)(sB * kCellCols + slot % kCellCols) * wpitch + w) * kLanes + 4 * q);
+			}
+#pragma unroll
+			for (int x = 0; x < kDepth; ++x) {
+				const int e = e0 + x * 256;
+				if (e >= total) continue;
+				const int slot = e / (kBandWords * 16), u = (e / 16) % kBandWords, q = e % 16;
+				uint32_t *dst = lds + ((slot / kCellCols) * kBandWords + u) * kCellStripCols + 8 * q + (slot % kCellCols);
+				dst[0] = v[x].x;
+				dst[2] = v[x].y;
+				dst[4] = v[x].z;
+				dst[6] = v[x].w;
+			}
+		}
+	}
 	__syncthreads();
 #ifdef CSADP_TB_STATS
 	const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -298,24 +327,24 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 	if (t >= kScoutStarts) return;                                     /* one wave walks, a start per lane */
 	const int i = i0 + t;
 	const int jtop = b * kBandRows;
-	int j = jtop + kBandRows, k = i < nstarts ? i * kBandStride : 0;
-	bool lost = false;
-	int nleft = 0;                                                     /* L moves so far */
-	/* branch-free step: lanes that are done, or whose walk has left the staged strips (a run of L nobody near the path
-	 * takes), idle; 25 instructions and one LDS read per step */
+	/* j = row, c = column - 1; a lane whose walk is lost (it left the staged strips, or took more than kScoutMaxLeft L moves:
+	 * a start right of the path on its slow way to it) parks in row jtop - 1: not live, and not a valid result */
+	int j = jtop + kBandRows, c = (i < nstarts ? i * kBandStride : 0) - 1;
+	int nleft = 0;
+	const int jbase = -1 - 16 * W.wLo;                                 /* l - 16 wLo = j + jbase + lane of the column */
 	for (int steps = 0; steps < kScoutCap; ++steps) {
-		const bool live = (j > jtop) & (k > 0) & !lost;
+		const bool live = (j > jtop) & (c >= 0);
 		if (!__any(live)) break;
-		const int c = k - 1, sc = c >> 7, ln = (c & (kCellStripCols - 1)) >> 1;
-		const int l = j - 1 + ln;
-		const unsigned ds = (unsigned)(sc - W.sLo), dw = (unsigned)((l >> 4) - W.wLo);
-		const bool in = live & (ds < (unsigned)kScoutStrips) & (dw < (unsigned)kBandWords);
-		const uint32_t word = lds[in ? ((ds * kCellCols + (c & 1)) * kBandWords + dw) * kLanes + ln : 0];
+		const int l = j + jbase + ((c >> 1) & 63);                       /* local step relative to the window's first word */
+		const unsigned idx = (unsigned)(((c >> 7) - W.sLo) * kBandWords + (l >> 4));
+		const bool in = live & (idx < (unsigned)(kScoutStrips * kBandWords));   /* rows of the band: 0 <= l >> 4 < kBandWords */
+		const uint32_t word = lds[in ? (idx << 7) | (unsigned)(c & 127) : 0u];
 		const uint32_t tag = (word >> (2 * (l & 15))) & 3u;
 		nleft += tag == DIR_L;
-		lost |= live & (!in | (nleft > kScoutMaxLeft));                  /* many L moves: a start right of the path on its (slow) way to it */
+		const bool lost = live & (!in | (nleft > kScoutMaxLeft));
 		j -= in & (tag != DIR_L);
-		k -= in & (tag != DIR_U);
+		c -= in & (tag != DIR_U);
+		j = lost ? jtop - 1 : j;
 #ifdef CSADP_TB_STATS
 		++nsteps;
 #endif
@@ -324,9 +353,10 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 	if (t == 0 && blockIdx.x == 1 && b == J.nbands / 2 && J.nbands > 100)
 		printf("scout: staged in %.1f us, %d steps in %.1f us\n", (double)(t1 - t0) / 100.0, nsteps, (double)(__builtin_amdgcn_s_memrealtime() - t1) / 100.0);
 #endif
+	const int k = c + 1;
 	const unsigned moved = (unsigned)(i * kBandStride - k);
 	uint16_t *tab = reinterpret_cast<uint16_t *>(arena + J.tb_tab) + (size_t)b * J.tb_pitch + blockIdx.x * kScoutStarts;
-	tab[t] = (uint16_t)((j == jtop && k > 0 && !lost && moved < kBandUnknown) ? moved : kBandUnknown);
+	tab[t] = (uint16_t)((j == jtop && k > 0 && moved < kBandMoved) ? moved : kBandUnknown);
 }
 
 /* ---- K2f ---------------------------------------------------------------------------------------------------------- */
@@ -392,25 +422,24 @@ __global__ __launch_bounds__(256) void nw_tb_resolve(uint8_t *__restrict__ arena
 			if (tid == 0) {
 				int jj = j, kk = k, bb = b;
 				int f = first[bb - cLo];
+				const uint16_t *row = tab + (bb - cLo) * pitch;
 				for (;;) {
-					const uint16_t *row = tab + (bb - cLo) * pitch;
-					const int fnext = first[max(bb - 1 - cLo, 0)];         /* read beside the row's entries, not after them */
-					const int lo = kk / kBandStride, rem = kk % kBandStride;
-					const int hi = lo + (rem != 0);
-					if (hi * kBandStride > J.ncols) break;                 /* no start right of the entry column */
-					const int xlo = lo - f, xhi = hi - f;
-					f = fnext;
-					if (xlo < 0 || xhi >= pitch) break;                    /* outside the scouted corridor */
-					const unsigned a = row[xlo], c = row[xhi];
-					if (a == kBandUnknown || c == kBandUnknown) break;
-					const int ea = lo * kBandStride - (int)a, ec = hi * kBandStride - (int)c;
-					if (ea != ec) break;                                   /* the flanks have not merged inside the band */
+					const int fnext = first[max(bb - 1 - cLo, 0)];         /* read beside the row's entry, not after it */
+					const int lo = kk / kBandStride, hi = lo + ((kk % kBandStride) != 0);
+					const unsigned xlo = (unsigned)(lo - f), xhi = (unsigned)(hi - f);
+					if (xlo >= (unsigned)pitch || xhi >= (unsigned)pitch) break;   /* outside the scouted corridor (negative: huge) */
+					const unsigned a = row[xlo], c = row[xhi];             /* both reads in flight together: one LDS latency per band */
+					if (a == kBandUnknown || c == kBandUnknown) break;     /* (start columns beyond ncols are written as unknown) */
+					const int ea = lo * kBandStride - (int)a;
+					if (ea != hi * kBandStride - (int)c) break;            /* the flanks have not merged inside the band */
 					kk = ea;
 					jj = bb * kBandRows;
 					--bb;
 					if (jj == 0) break;
 					ent[bb] = kk;
 					if (bb < cLo) break;
+					f = fnext;
+					row -= pitch;
 				}
 				pos[0] = jj;
 				pos[1] = kk;

@@ -151,6 +151,7 @@ constexpr int kScoutMaxLeft = 128;   /* L moves after which a scout gives up (a 
 constexpr int kScoutCap = kBandRows + kScoutMaxLeft + 1;               /* steps a scout can take                            */
 constexpr int kEmitStrips = 4;       /* strips staged by an emitting workgroup                                              */
 constexpr unsigned kBandUnknown = 0xffffu;
+constexpr unsigned kBandMoved = 0x8000u;      /* a scout's `moved` is below this */
 
 }  // namespace csadp
 
