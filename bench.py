@@ -536,6 +536,7 @@ def main():
                                  "as well as the time: `value` is the figure to compare across rounds" % (
                                      round(valu_per_cell * 32 * wpl), 32 * wpl, wpl, tm_pipe["streams"], valu_per_cell),
                          "valu_per_cell": round(valu_per_cell, 4), "words_per_lane": wpl,
+                         "frac_at_round2_instructions_per_cell": round(sustained_tops / valu_per_cell * (31.0 / 32.0) / VALU_PEAK_TOPS, 4),
                          "one_launch_alone": {"cells": launch_cells, "avg_launch_us": round(tm["fill_ms"] * 1e3, 1),
                                               "achieved": round(alone_tops, 2), "frac": round(alone_tops / VALU_PEAK_TOPS, 4),
                                               "what": "HIP events around ONE launch with nothing else in flight (one workgroup "

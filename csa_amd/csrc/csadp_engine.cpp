@@ -390,7 +390,8 @@ int FillBatch::layout_cells()
 		C.banded = J.nrows >= band_min ? 1 : 0;
 		if (C.banded) {
 			const int ngroups = (J.ncols / kBandStride + 1 + kScoutStarts - 1) / kScoutStarts;
-			C.tb_groups = std::min(ngroups, std::max(1, tb_corridor));
+			/* at most as many groups as let one band's table row fit the resolve kernel's LDS table (64 KiB of u16) */
+			C.tb_groups = std::min(std::min(ngroups, std::max(1, tb_corridor)), 64 * 1024 / 2 / kScoutStarts);
 			C.tb_pitch = C.tb_groups * kScoutStarts;
 			tb_max_bands_ = std::max(tb_max_bands_, C.nbands);
 			tb_max_groups_ = std::max(tb_max_groups_, C.tb_groups);
