@@ -554,6 +554,9 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
  * (r - i, k - i), one step-row apart; with the round-2 pitch of 16 cells = 128 bytes they hit two bank pairs (6.5 - 17
  * conflict cycles per LDS instruction, profiles/r02_pmc_summary.json), with an odd pitch 32 different ones.
  */
+constexpr int kOverlapPieces = 16;         /* a 16 kbp pair: 0.29 ms; 12 pieces (three replaying waves + the walking one, a SIMD each) 0.305;
+                                            * 16 pieces on eight replaying waves of two pieces each (two waves per SIMD) 0.34 */
+
 template <int W>
 __device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d)
 {
@@ -563,12 +566,20 @@ __device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d)
 	return min(max(le - 8, 0), kLanes - 16);
 }
 
-template <int W, int NP, bool SCORE>       /* SCORE: also sum the move scores of the path (score-only callers skip the host walk) */
-__global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
+/* SCORE: also sum the move scores of the path (score-only callers skip the host walk).
+ * OVERLAP (a few large matrices, the LDS of a compute unit to one workgroup): a fifth wave does nothing but walk, and while it
+ * walks the NP pieces of one tile set the other four replay the NEXT NP pieces up the same predicted diagonal into a second
+ * set; a round is then max(walk, loads + replay) instead of their sum.  When the path leaves the prediction (it changes
+ * strip, or drifts more than 8 lanes) the walk stops as ever, the pieces are planned afresh from the current cell and their
+ * replay is waited for -- what every round costs without the overlap. */
+template <int W, int NP, bool SCORE, bool OVERLAP>
+__global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
 {
+	static_assert(!(OVERLAP && SCORE), "no room for two sets of match masks");
 	constexpr int pitch = 16 * W + 1;
 	constexpr int cs = W == 1 ? 5 : W == 2 ? 6 : 7;
-	__shared__ __attribute__((aligned(16))) uint2 tile[NP][kBitBlock * pitch];
+	constexpr int kSets = OVERLAP ? 2 : 1;
+	__shared__ __attribute__((aligned(16))) uint2 tile[kSets * NP][kBitBlock * pitch];
 	__shared__ uint32_t mtile[SCORE ? NP : 1][SCORE ? kBitBlock * pitch : 1];    /* match masks of the same cells */
 	__shared__ __attribute__((aligned(16))) uint32_t inject[NP][kBitBlock * kInjWords];
 	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];   /* 4 words off the banks of the inject rows */
@@ -612,94 +623,153 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 #else
 #define TB_LAP(acc) do { } while (0)
 #endif
-	while (r > 0 && k > 0) {
-		const int wq = (k - 1) >> cs;                          /* lane column of the current cell */
-		const int s = wq >> 6;
-		const int lane0 = wq & 63;
-		const int l0 = (r - 1) + lane0;
-		const int btop = l0 / kBitBlock;
-		{
-			/* this lane's piece */
-			const int d = 4 * wv + (lane >> 4);
-			const int f = piece_first_lane<W>(k, l0, s, d);
-			const int b = btop - d < 0 ? 0 : btop - d;         /* pieces above block 0 replay block 0 and are never read */
-			const int j = lane & 15;
-			const int sl = f + j;                              /* lane index in the strip */
-			const size_t w0 = ((size_t)s * kLanes + sl) * W;
-			BitState<W> S;
-			fresh_state<W>(S);
-			uint32_t B0[W], B1[W];
+	/* OVERLAP: the plan (reference cell and its block) outlives a round; dbase = first piece of tile set `cur` */
+	int kref = 0, s = 0, l0 = 0, btop = 0, dbase = 0, cur = 0;
+	bool plan = true;
+	/* one piece: d = its number up the planned diagonal, into tile `slot` */
+	/* One piece in two halves: what it reads from HBM (checkpoint of its lanes, the accumulators that enter its first lane, letters
+	 * and row bits), and the 32 replay steps into a tile.  OVERLAP requests the inputs of the NEXT round's piece before it replays
+	 * this round's: the loads' trip (about 4 k of a round's 10 k cycles on the replaying waves) runs under the 32 steps. */
+	struct PieceIn {
+		int f, b;
+		uint32_t B0[W], B1[W], L0, L1;                       /* column letters of the lane's words; word 0 of the lane to the left */
+		uint4 ckv[W];
+		uint2 hv;
+		uint32_t older[3], newer[3];
+		uint32_t bf0, bf1;
+		uint32_t rmx[2], rmi[2][2];                          /* row bits: the step before the block; the first lane's rows at steps j, j + 16 */
+	};
+	auto fetch_piece = [&](const int d, PieceIn &P) {
+		const int f = piece_first_lane<W>(kref, l0, s, d);     /* pieces stay in the plan's strip: one that followed the diagonal into the
+		                                                        * strip to the left would share its block number with one in this strip (the
+		                                                        * crossing falls inside a block), and two strips are 63 steps apart in time */
+		const int b = btop - d < 0 ? 0 : btop - d;             /* pieces above block 0 replay block 0 and are never read */
+		const int j = lane & 15;
+		const int sl = f + j;                                  /* lane index in the strip */
+		const size_t w0 = ((size_t)s * kLanes + sl) * W;
+		P.f = f;
+		P.b = b;
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			P.B0[h] = cp[w0 + h];
+			P.B1[h] = cp[J.nwords_pad + w0 + h];
+		}
+		const size_t wl = sl > 0 ? w0 - W : w0;
+		P.L0 = cp[wl];
+		P.L1 = cp[J.nwords_pad + wl];
+		P.hv = make_uint2(0, 0);
+		P.rmx[0] = P.rmx[1] = 0;
+#pragma unroll
+		for (int h = 0; h < W; ++h) P.ckv[h] = make_uint4(0, 0, 0, 0);
+		if (b > 0) {
+			const size_t at = (size_t)s * nb + (b - 1);
+#pragma unroll
+			for (int h = 0; h < W; ++h) P.ckv[h] = ck[(at * W + h) * kLanes + sl];
+			P.hv = hand[at * kLanes + sl];
+			/* x of the step before the block: the lane worked on row 32 b - 1 - sl then (not yet live: any value) */
+			const int row = b * kBitBlock - 1 - sl;
+			P.rmx[0] = row_mask(0, row);
+			P.rmx[1] = row_mask(1, row);
+		}
+		/* what enters the piece's first lane: lane j of the row prepares steps j and j + 16 */
+		if (f > 0) {                                           /* the lane to the left, one step earlier */
+			acc_of(s, b - 1, f - 1, P.older);
+			acc_of(s, b, f - 1, P.newer);
+		} else if (s > 0) {                                    /* lane 63 of the strip to the left is 63 steps ahead */
+			acc_of(s - 1, b + 1, kLanes - 1, P.older);
+			acc_of(s - 1, b + 2, kLanes - 1, P.newer);
+		} else {
+			P.older[0] = P.older[1] = P.older[2] = P.newer[0] = P.newer[1] = P.newer[2] = 0;
+		}
+		P.bf0 = cp[((size_t)s * kLanes + f) * W];
+		P.bf1 = cp[J.nwords_pad + ((size_t)s * kLanes + f) * W];
+#pragma unroll
+		for (int hh = 0; hh < 2; ++hh) {
+			const int row = b * kBitBlock + (j + 16 * hh) - f;     /* the first lane's row at step t */
+			P.rmi[hh][0] = row_mask(0, row);
+			P.rmi[hh][1] = row_mask(1, row);
+		}
+	};
+	auto compute_piece = [&](const PieceIn &P, const int slot) {
+		const int j = lane & 15;
+		const int sl = P.f + j;
+		BitState<W> S;
+		fresh_state<W>(S);
+		LaneConst<W> K;
+		K.D0 = P.B0[0] ^ P.L0;
+		K.D1 = P.B1[0] ^ P.L1;
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			K.E0[h] = P.B0[0] ^ P.B0[h];
+			K.E1[h] = P.B1[0] ^ P.B1[h];
+		}
+		if (P.b > 0) {
 #pragma unroll
 			for (int h = 0; h < W; ++h) {
-				B0[h] = cp[w0 + h];
-				B1[h] = cp[J.nwords_pad + w0 + h];
+				S.nH0[h] = P.ckv[h].x;
+				S.H1[h] = P.ckv[h].y;
+				S.H2[h] = P.ckv[h].z;
 			}
-			LaneConst<W> K;
-			{
-				const size_t wl = sl > 0 ? w0 - W : w0;
-				K.D0 = B0[0] ^ cp[wl];
-				K.D1 = B1[0] ^ cp[J.nwords_pad + wl];
-#pragma unroll
-				for (int h = 0; h < W; ++h) {
-					K.E0[h] = B0[0] ^ B0[h];
-					K.E1[h] = B1[0] ^ B1[h];
-				}
-			}
-			if (b > 0) {
-				const size_t at = (size_t)s * nb + (b - 1);
-#pragma unroll
-				for (int h = 0; h < W; ++h) {
-					const uint4 v = ck[(at * W + h) * kLanes + sl];
-					S.nH0[h] = v.x;
-					S.H1[h] = v.y;
-					S.H2[h] = v.z;
-					if (h == 0) S.nO2 = (v.w & 1u) ? 0u : kNoCarry;          /* what the lane put out in the last step of block b - 1 */
-				}
-				const uint2 hv = hand[at * kLanes + sl];
-				S.nO1 = (hv.x & 1u) ? 0u : kNoCarry;
-				S.nO0 = (hv.y & 1u) ? 0u : kNoCarry;
-				/* x of the step before the block: the lane worked on row 32 b - 1 - sl then (not yet live: any value) */
-				const int row = b * kBitBlock - 1 - sl;
-				S.x0 = B0[0] ^ row_mask(0, row);
-				S.x1 = B1[0] ^ row_mask(1, row);
-			}
-			/* what enters the piece's first lane: lane j of the row prepares steps j and j + 16 */
-			uint32_t older[3], newer[3];
-			if (f > 0) {                                       /* the lane to the left, one step earlier */
-				acc_of(s, b - 1, f - 1, older);
-				acc_of(s, b, f - 1, newer);
-			} else if (s > 0) {                                /* lane 63 of the strip to the left is 63 steps ahead */
-				acc_of(s - 1, b + 1, kLanes - 1, older);
-				acc_of(s - 1, b + 2, kLanes - 1, newer);
-			} else {
-				older[0] = older[1] = older[2] = newer[0] = newer[1] = newer[2] = 0;
-			}
-			const uint32_t bf0 = cp[((size_t)s * kLanes + f) * W], bf1 = cp[J.nwords_pad + ((size_t)s * kLanes + f) * W];
-#pragma unroll
-			for (int hh = 0; hh < 2; ++hh) {
-				const int t = j + 16 * hh;
-				const int row = b * kBitBlock + t - f;         /* the first lane's row at step t */
-				*reinterpret_cast<uint4 *>(&inject[d][t * kInjWords]) =
-				    make_uint4(bf0 ^ row_mask(0, row), bf1 ^ row_mask(1, row), carry_bit(older[0], newer[0], t), carry_bit(older[1], newer[1], t));
-				inject[d][t * kInjWords + INJ_Z0] = carry_bit(older[2], newer[2], t);
-			}
-			const uint32_t *ip = j == 0 ? &inject[d][0] : &konst[4];
-			uint2 *out = &tile[d][j];                          /* a step's row of a tile: [word][lane], so the 16 lanes of a store are contiguous */
-			uint32_t *outm = &mtile[SCORE ? d : 0][SCORE ? j : 0];
-			const bool ramp = btop - 4 * wv - 3 < 2;           /* wave-uniform: some piece of this wave is in block 0 or 1 */
-#ifdef CSADP_TB_TIMERS
-			asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-			TB_LAP(tm_load);
-			if (ramp) bits_block<W, true, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
-			else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, b * kBitBlock, sl);
-			TB_LAP(tm_replay);
+			S.nO2 = (P.ckv[0].w & 1u) ? 0u : kNoCarry;          /* what the lane put out in the last step of block b - 1 */
+			S.nO1 = (P.hv.x & 1u) ? 0u : kNoCarry;
+			S.nO0 = (P.hv.y & 1u) ? 0u : kNoCarry;
+			S.x0 = P.B0[0] ^ P.rmx[0];
+			S.x1 = P.B1[0] ^ P.rmx[1];
 		}
-		__syncthreads();
-		TB_LAP(tm_sync);
+#pragma unroll
+		for (int hh = 0; hh < 2; ++hh) {
+			const int t = j + 16 * hh;
+			*reinterpret_cast<uint4 *>(&inject[slot % NP][t * kInjWords]) = make_uint4(
+			    P.bf0 ^ P.rmi[hh][0], P.bf1 ^ P.rmi[hh][1], carry_bit(P.older[0], P.newer[0], t), carry_bit(P.older[1], P.newer[1], t));
+			inject[slot % NP][t * kInjWords + INJ_Z0] = carry_bit(P.older[2], P.newer[2], t);
+		}
+		const uint32_t *ip = j == 0 ? &inject[slot % NP][0] : &konst[4];
+		uint2 *out = &tile[slot][j];                           /* a step's row of a tile: [word][lane], so the 16 lanes of a store are contiguous */
+		uint32_t *outm = &mtile[SCORE ? slot : 0][SCORE ? j : 0];
+		const bool ramp = __any(P.b < 2);                      /* wave-uniform: some piece of this wave is in block 0 or 1 */
+#ifdef CSADP_TB_TIMERS
+		if (!OVERLAP) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      /* (OVERLAP: the next piece's requests stay in flight) */
+#endif
+		TB_LAP(tm_load);
+		if (ramp) bits_block<W, true, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, P.b * kBitBlock, sl);
+		else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, P.b * kBitBlock, sl);
+		TB_LAP(tm_replay);
+	};
+	PieceIn ahead;                                             /* OVERLAP: the inputs of the piece this lane replays next */
+	bool have_ahead = false;
+	while (r > 0 && k > 0) {
+		if (!OVERLAP || plan) {                                  /* plan the pieces from the current cell */
+			const int wq = (k - 1) >> cs;                          /* lane column of the current cell */
+			s = wq >> 6;
+			l0 = (r - 1) + (wq & 63);
+			btop = l0 / kBitBlock;
+			kref = k;
+			dbase = 0;
+			if (!OVERLAP || wv > 0) {
+				const int x = 4 * (OVERLAP ? wv - 1 : wv) + (lane >> 4);
+				PieceIn P;
+				fetch_piece(x, P);
+				compute_piece(P, (OVERLAP ? cur * NP : 0) + x);
+			}
+			have_ahead = false;
+			plan = false;
+			__syncthreads();
+			TB_LAP(tm_sync);
+		}
+		if (OVERLAP && wv > 0) {
+			/* the next NP pieces up the same diagonal, into the other set, while wave 0 walks this one; their inputs were requested
+			 * a round ago when the plan has held since, and those of the round after are requested before the 32 steps */
+			const int x = 4 * (wv - 1) + (lane >> 4);
+			PieceIn P;
+			if (have_ahead) P = ahead;
+			else fetch_piece(dbase + NP + x, P);
+			fetch_piece(dbase + 2 * NP + x, ahead);
+			have_ahead = true;
+			compute_piece(P, (1 - cur) * NP + x);
+		}
 		if (wv == 0) {
-			const int k0 = k;
-			const uint2 *tiles = &tile[0][0];                  /* the NP tiles are one array: ONE look-up per iteration, no nested regions */
+			const int k0 = kref;
+			const uint2 *tiles = &tile[OVERLAP ? cur * NP : 0][0];   /* the NP tiles are one array: ONE look-up per iteration, no nested regions */
 			[[maybe_unused]] const uint32_t *mtiles = &mtile[0][0];
 			for (;;) {
 				/* lane i looks at cell (r - i, k - i); straight-line: the validity tests are one mask, the address of an invalid
@@ -710,8 +780,9 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 				const int wi = kc >> cs;                       /* arithmetic: cells left of the matrix fail the strip test */
 				const int sl = wi & 63;
 				const int l = (ri - 1) + sl;
-				const int d = btop - (l >> 5);
-				const int rel = sl - piece_first_lane<W>(k0, l0, s, d);
+				const int dabs = btop - (l >> 5);                     /* piece number up the planned diagonal */
+				const int d = dabs - dbase;                            /* its tile in this set */
+				const int rel = sl - piece_first_lane<W>(k0, l0, s, dabs);
 				const bool ok = (ri > 0) & (ki > 0) & ((wi >> 6) == s) & ((unsigned)d < (unsigned)NP) & ((unsigned)rel < 16u);
 				const int at = ok ? d * (kBitBlock * pitch) + (l & 31) * pitch + ((kc >> 5) & (W - 1)) * 16 + rel : 0;
 				const uint2 dd = tiles[at];
@@ -750,11 +821,27 @@ __global__ __launch_bounds__(NP * 16) void nw_traceback_replay(uint8_t *__restri
 		score = pos[3];
 		__syncthreads();
 		TB_LAP(tm_sync);
+		if (OVERLAP && r > 0 && k > 0) {
+			/* did the walk end where the plan continues?  The current cell must lie in a piece of the set just replayed */
+			const int wq = (k - 1) >> cs, sl = wq & 63;
+			const int dabs = btop - (((r - 1) + sl) >> 5);
+			const unsigned rel = (unsigned)(sl - piece_first_lane<W>(kref, l0, s, dabs));
+			if ((wq >> 6) == s && dabs >= dbase + NP && dabs < dbase + 2 * NP && rel < 16u) {
+				cur ^= 1;
+				dbase += NP;
+			} else {
+				plan = true;
+			}
+		}
+		(void)have_ahead;
 #ifdef CSADP_TB_TIMERS
 		++tm_rounds;
 #endif
 	}
 #ifdef CSADP_TB_TIMERS
+	if (OVERLAP && threadIdx.x == 64 && blockIdx.x == 0)
+		printf("traceback timers (wave 1, cycles): rounds %d  loads+inputs %llu  replay %llu  walk %llu  barriers %llu  per round %llu\n", tm_rounds, tm_load,
+		       tm_replay, tm_walk, tm_sync, (tm_load + tm_replay + tm_walk + tm_sync) / (tm_rounds ? tm_rounds : 1));
 	if (threadIdx.x == 0 && blockIdx.x == 0)
 		printf("traceback timers (wave 0, cycles): rounds %d  loads+inputs %llu  replay %llu  walk %llu  barriers %llu  per round %llu\n", tm_rounds, tm_load,
 		       tm_replay, tm_walk, tm_sync, (tm_load + tm_replay + tm_walk + tm_sync) / (tm_rounds ? tm_rounds : 1));
@@ -828,14 +915,18 @@ hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const Bit
 	return launch_fill_any(words, waves, true, arena, jobs, njobs, passes, waves * kLanes, work, nwork, epoch, abort_word, st);
 }
 
-hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, hipStream_t st)
+hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, bool overlap, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
+	if (overlap && words == 1 && !scores) {                    /* the caller leaves the compute units' LDS to these workgroups */
+		hipLaunchKernelGGL((nw_traceback_replay<1, kOverlapPieces, false, true>), dim3(njobs), dim3(kOverlapPieces * 16 + 64), 0, st, arena, jobs);
+		return hipGetLastError();
+	}
 	/* with match masks next to the direction tiles, half as many pieces of two words fit the LDS */
 #define CSADP_TB(W_, NP_, NPS_)                                                                                                        \
 	do {                                                                                                                               \
-		if (scores) hipLaunchKernelGGL((nw_traceback_replay<W_, NPS_, true>), dim3(njobs), dim3(NPS_ * 16), 0, st, arena, jobs);        \
-		else hipLaunchKernelGGL((nw_traceback_replay<W_, NP_, false>), dim3(njobs), dim3(NP_ * 16), 0, st, arena, jobs);                \
+		if (scores) hipLaunchKernelGGL((nw_traceback_replay<W_, NPS_, true, false>), dim3(njobs), dim3(NPS_ * 16), 0, st, arena, jobs);        \
+		else hipLaunchKernelGGL((nw_traceback_replay<W_, NP_, false, false>), dim3(njobs), dim3(NP_ * 16), 0, st, arena, jobs);                \
 	} while (0)
 	if (words == 1) CSADP_TB(1, kReplayPieces1, kReplayPieces1);
 	else if (words == 2) CSADP_TB(2, kReplayPieces2, 8);

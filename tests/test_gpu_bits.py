@@ -18,9 +18,13 @@ def device():
 
 # words of 32 columns per lane: the engine picks 1 or 2 by the shape of the batch (layout_bits); every test below runs with
 # each of the three kernels
-@pytest.fixture(params=["1 word", "2 words", "4 words"])
+# Batches of at most 32 one-word jobs take the traceback that walks one tile set while the next is replayed
+# (CSADP_TB_OVERLAP, default on); "1 word, replay then walk" runs the same cases through the plain one.
+@pytest.fixture(params=["1 word", "1 word, replay then walk", "2 words", "4 words"])
 def bits_mode(request, monkeypatch):
     monkeypatch.setenv("CSADP_BITS_WORDS", request.param.split()[0])
+    if "then walk" in request.param:
+        monkeypatch.setenv("CSADP_TB_OVERLAP", "0")
     return request.param
 
 
