@@ -628,8 +628,9 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 	bool plan = true;
 	/* one piece: d = its number up the planned diagonal, into tile `slot` */
 	/* One piece in two halves: what it reads from HBM (checkpoint of its lanes, the accumulators that enter its first lane, letters
-	 * and row bits), and the 32 replay steps into a tile.  OVERLAP requests the inputs of the NEXT round's piece before it replays
-	 * this round's: the loads' trip (about 4 k of a round's 10 k cycles on the replaying waves) runs under the 32 steps. */
+	 * and row bits), and the 32 replay steps into a tile.  (OVERLAP requested the inputs of the NEXT round's piece before replaying
+	 * this round's at first: the 5 k cycles in front of the steps are address arithmetic on a lone wave, not the loads' trip, and the
+	 * extra registers and copies cost 4 %: dropped.) */
 	struct PieceIn {
 		int f, b;
 		uint32_t B0[W], B1[W], L0, L1;                       /* column letters of the lane's words; word 0 of the lane to the left */
@@ -735,8 +736,6 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 		else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, P.b * kBitBlock, sl);
 		TB_LAP(tm_replay);
 	};
-	PieceIn ahead;                                             /* OVERLAP: the inputs of the piece this lane replays next */
-	bool have_ahead = false;
 	while (r > 0 && k > 0) {
 		if (!OVERLAP || plan) {                                  /* plan the pieces from the current cell */
 			const int wq = (k - 1) >> cs;                          /* lane column of the current cell */
@@ -751,20 +750,15 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 				fetch_piece(x, P);
 				compute_piece(P, (OVERLAP ? cur * NP : 0) + x);
 			}
-			have_ahead = false;
 			plan = false;
 			__syncthreads();
 			TB_LAP(tm_sync);
 		}
 		if (OVERLAP && wv > 0) {
-			/* the next NP pieces up the same diagonal, into the other set, while wave 0 walks this one; their inputs were requested
-			 * a round ago when the plan has held since, and those of the round after are requested before the 32 steps */
+			/* the next NP pieces up the same diagonal, into the other set, while wave 0 walks this one */
 			const int x = 4 * (wv - 1) + (lane >> 4);
 			PieceIn P;
-			if (have_ahead) P = ahead;
-			else fetch_piece(dbase + NP + x, P);
-			fetch_piece(dbase + 2 * NP + x, ahead);
-			have_ahead = true;
+			fetch_piece(dbase + NP + x, P);
 			compute_piece(P, (1 - cur) * NP + x);
 		}
 		if (wv == 0) {
@@ -833,7 +827,6 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 				plan = true;
 			}
 		}
-		(void)have_ahead;
 #ifdef CSADP_TB_TIMERS
 		++tm_rounds;
 #endif
