@@ -976,8 +976,9 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 	HIP_TRY(hipEventRecord(ev[1], st));
 	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
 	/* a few large matrices: the traceback that walks one tile set while the next is replayed (a workgroup then takes nearly all
-	 * the LDS of its compute unit: not beside chip-filling fills) */
-	const bool overlap = tb_overlap_ && bits_words_ == 1 && !want_scores_ && g * nj <= 32;
+	 * the LDS of its compute unit: not beside chip-filling fills; a batch that is not pipelined -- mode N's first fills -- has
+	 * the chip to itself while it walks) */
+	const bool overlap = tb_overlap_ && bits_words_ == 1 && !want_scores_ && g * nj <= (pipelined_ ? 32 : E_->compute_units());
 	HIP_TRY(launch_traceback_bits(bits_words_, arena_, bj, g * nj, want_scores_, overlap, side));
 	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
 	HIP_TRY(hipEventRecord(ev[2], side));
