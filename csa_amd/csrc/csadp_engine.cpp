@@ -362,6 +362,7 @@ int FillBatch::layout_cells()
 	const int nj = (int)jobs_.size();
 	cells_mode_ = true;
 	const int band_min = env_int("CSADP_TB_BAND_MIN", 512);       /* rows; 0x7fffffff: never */
+	const bool band_forced = getenv("CSADP_TB_BAND_MIN") != nullptr;
 	const int tb_corridor = env_int("CSADP_TB_CORRIDOR", 3);      /* groups of 1024 start columns scouted per band */
 	tb_max_bands_ = tb_max_groups_ = 0;
 	cjobs_.assign((size_t)nj, CellJob());
@@ -387,7 +388,9 @@ int FillBatch::layout_cells()
 		J.steps_pad = C.steps_pad;
 		/* the walk band-parallel from band_min rows on (csadp_cells_tb.hip); smaller matrices by one serial walk */
 		C.nbands = (J.nrows + kBandRows - 1) / kBandRows;
-		C.banded = J.nrows >= band_min ? 1 : 0;
+		/* (a profile more than twice as long as the row sequence: every band is crossed by more L moves than a scout takes, all of
+		 * them would be walked twice -- one serial walk then, unless the tests ask for bands) */
+		C.banded = (J.nrows >= band_min && (band_forced || J.ncols <= 2 * J.nrows)) ? 1 : 0;
 		if (C.banded) {
 			const int ngroups = (J.ncols / kBandStride + 1 + kScoutStarts - 1) / kScoutStarts;
 			/* at most as many groups as let one band's table row fit the resolve kernel's LDS table (64 KiB of u16) */
