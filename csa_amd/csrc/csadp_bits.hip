@@ -557,12 +557,15 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 constexpr int kOverlapPieces = 16;         /* a 16 kbp pair: 0.29 ms; 12 pieces (three replaying waves + the walking one, a SIMD each) 0.305;
                                             * 16 pieces on eight replaying waves of two pieces each (two waves per SIMD) 0.34 */
 
+/* slope: columns the planned path moves left per local step, in 1/1024 (1024: the diagonal, what the plain kernel plans with;
+ * the overlapped one plans along the line to the matrix' corner: a pair of 12.5 k x 16.3 k letters -- the first fill of Set3's
+ * wide gap -- leaves every diagonal plan within a round) */
 template <int W>
-__device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d)
+__device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d, int slope = 1024)
 {
 	constexpr int cs = W == 1 ? 5 : W == 2 ? 6 : 7;            /* log2 of the columns per lane */
-	const int m = max(0, 32 * d - 31 + (l0 & 31));             /* cells up the diagonal to the piece's block (upper bound) */
-	const int le = ((k0 - 1 - m) >> cs) - 64 * s;              /* lane of the diagonal there; negative: left of this strip */
+	const int m = max(0, 32 * d - 31 + (l0 & 31));             /* steps up the planned path to the piece's block (upper bound) */
+	const int le = ((k0 - 1 - ((m * slope) >> 10)) >> cs) - 64 * s;   /* lane of the path there; negative: left of this strip */
 	return min(max(le - 8, 0), kLanes - 16);
 }
 
@@ -625,6 +628,7 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 #endif
 	/* OVERLAP: the plan (reference cell and its block) outlives a round; dbase = first piece of tile set `cur` */
 	int kref = 0, s = 0, l0 = 0, btop = 0, dbase = 0, cur = 0;
+	int slope = 1024;
 	bool plan = true;
 	/* one piece: d = its number up the planned diagonal, into tile `slot` */
 	/* One piece in two halves: what it reads from HBM (checkpoint of its lanes, the accumulators that enter its first lane, letters
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 		uint32_t rmx[2], rmi[2][2];                          /* row bits: the step before the block; the first lane's rows at steps j, j + 16 */
 	};
 	auto fetch_piece = [&](const int d, PieceIn &P) {
-		const int f = piece_first_lane<W>(kref, l0, s, d);     /* pieces stay in the plan's strip: one that followed the diagonal into the
+		const int f = piece_first_lane<W>(kref, l0, s, d, slope);     /* pieces stay in the plan's strip: one that followed the diagonal into the
 		                                                        * strip to the left would share its block number with one in this strip (the
 		                                                        * crossing falls inside a block), and two strips are 63 steps apart in time */
 		const int b = btop - d < 0 ? 0 : btop - d;             /* pieces above block 0 replay block 0 and are never read */
@@ -744,6 +748,11 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 			btop = l0 / kBitBlock;
 			kref = k;
 			dbase = 0;
+			if (OVERLAP) {
+				/* columns per row towards the corner, per local step: a row up is 1 + (columns per row) / (columns per lane) steps */
+				const float cr = (float)k / (float)r;
+				slope = min(max((int)(1024.0f * cr / (1.0f + cr / (float)(32 * W))), 256), 4096);
+			}
 			if (!OVERLAP || wv > 0) {
 				const int x = 4 * (OVERLAP ? wv - 1 : wv) + (lane >> 4);
 				PieceIn P;
@@ -776,7 +785,7 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 				const int l = (ri - 1) + sl;
 				const int dabs = btop - (l >> 5);                     /* piece number up the planned diagonal */
 				const int d = dabs - dbase;                            /* its tile in this set */
-				const int rel = sl - piece_first_lane<W>(k0, l0, s, dabs);
+				const int rel = sl - piece_first_lane<W>(k0, l0, s, dabs, slope);
 				const bool ok = (ri > 0) & (ki > 0) & ((wi >> 6) == s) & ((unsigned)d < (unsigned)NP) & ((unsigned)rel < 16u);
 				const int at = ok ? d * (kBitBlock * pitch) + (l & 31) * pitch + ((kc >> 5) & (W - 1)) * 16 + rel : 0;
 				const uint2 dd = tiles[at];
@@ -819,7 +828,7 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 			/* did the walk end where the plan continues?  The current cell must lie in a piece of the set just replayed */
 			const int wq = (k - 1) >> cs, sl = wq & 63;
 			const int dabs = btop - (((r - 1) + sl) >> 5);
-			const unsigned rel = (unsigned)(sl - piece_first_lane<W>(kref, l0, s, dabs));
+			const unsigned rel = (unsigned)(sl - piece_first_lane<W>(kref, l0, s, dabs, slope));
 			if ((wq >> 6) == s && dabs >= dbase + NP && dabs < dbase + 2 * NP && rel < 16u) {
 				cur ^= 1;
 				dbase += NP;
