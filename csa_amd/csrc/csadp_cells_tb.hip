@@ -147,13 +147,8 @@ __device__ void walk_window(uint32_t *win, int *wlo, int *pos, const uint32_t *_
 	}
 }
 
-/* ---- the direction words of one band, staged in LDS ---------------------------------------------------------------- */
-
-struct BandWindow {
-	const uint32_t *lds;      /* [nS][2][kBandWords][64] */
-	int sLo, nS;              /* strips sLo .. sLo + nS - 1 (sLo may be negative: those strips hold zeros nobody reads) */
-	int wLo;                  /* first word: band row 0 of lane 0 */
-};
+/* ---- the direction words of one band, staged in LDS: [nS strips][2 halves][kBandWords][64 lanes], strips sLo .. sLo + nS - 1
+ * (sLo may be negative: those strips hold zeros nobody reads), words from wLo on ------------------------------------------------ */
 
 __device__ __forceinline__ void stage_band(uint32_t *lds, const uint32_t *__restrict__ dirs, int wpitch, int nstrips, int sLo, int nS, int wLo,
                                            int tid, int nthreads)
@@ -280,11 +275,8 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 	const uint32_t *dirs = reinterpret_cast<const uint32_t *>(arena + J.dirs);
 	const int wpitch = J.steps_pad / 16;
 	const int ilast = min(i0 + kScoutStarts, nstarts) - 1;
-	BandWindow W;
-	W.lds = lds;
-	W.nS = kScoutStrips;
-	W.sLo = ((ilast * kBandStride - 1) >> 7) - (kScoutStrips - 1);     /* the strip of the last start's cell and those left of it */
-	W.wLo = (b * kBandRows) >> 4;
+	const int sLo = ((ilast * kBandStride - 1) >> 7) - (kScoutStrips - 1);   /* the strip of the last start's cell and those left of it */
+	const int wLo = (b * kBandRows) >> 4;                                     /* first direction word of the band's rows */
 #ifdef CSADP_TB_STATS
 	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -300,7 +292,7 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 			for (int x = 0; x < kDepth; ++x) {
 				const int e = e0 + x * 256;
 				const int slot = e / (kBandWords * 16), u = (e / 16) % kBandWords, q = e % 16;
-				const int sB = W.sLo + slot / kCellCols, w = W.wLo + u;
+				const int sB = sLo + slot / kCellCols, w = wLo + u;
 				v[x] = make_uint4(0, 0, 0, 0);
 				if (e < total && sB >= 0 && sB < J.nstrips && w < wpitch)
 					v[x] = *reinterpret_cast<const uint4 *>(dirs + ((size_t)(sB * kCellCols + slot % kCellCols) * wpitch + w) * kLanes + 4 * q);
@@ -331,12 +323,12 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 	 * a start right of the path on its slow way to it) parks in row jtop - 1: not live, and not a valid result */
 	int j = jtop + kBandRows, c = (i < nstarts ? i * kBandStride : 0) - 1;
 	int nleft = 0;
-	const int jbase = -1 - 16 * W.wLo;                                 /* l - 16 wLo = j + jbase + lane of the column */
+	const int jbase = -1 - 16 * wLo;                                 /* l - 16 wLo = j + jbase + lane of the column */
 	for (int steps = 0; steps < kScoutCap; ++steps) {
 		const bool live = (j > jtop) & (c >= 0);
 		if (!__any(live)) break;
 		const int l = j + jbase + ((c >> 1) & 63);                       /* local step relative to the window's first word */
-		const unsigned idx = (unsigned)(((c >> 7) - W.sLo) * kBandWords + (l >> 4));
+		const unsigned idx = (unsigned)(((c >> 7) - sLo) * kBandWords + (l >> 4));
 		const bool in = live & (idx < (unsigned)(kScoutStrips * kBandWords));   /* rows of the band: 0 <= l >> 4 < kBandWords */
 		const uint32_t word = lds[in ? (idx << 7) | (unsigned)(c & 127) : 0u];
 		const uint32_t tag = (word >> (2 * (l & 15))) & 3u;
