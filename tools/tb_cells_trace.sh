@@ -13,7 +13,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 out = []
 for r in rows:
-    n = r["Kernel_Name"]
+    n = r["Kernel_Name"].replace("(anonymous namespace)::", "")
     if "cells" in n or "nw_tb" in n:
         out.append("%s %.1f us grid %s" % (n.split("(")[0][-28:], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, r.get("Grid_Size_X", r.get("Grid_Size", "?"))))
 open(sys.argv[1] + "/launches.txt", "w").write("\n".join(out) + "\n")
