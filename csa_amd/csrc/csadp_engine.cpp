@@ -362,6 +362,7 @@ int FillBatch::layout_cells()
 	const int nj = (int)jobs_.size();
 	cells_mode_ = true;
 	const int band_min = env_int("CSADP_TB_BAND_MIN", 512);       /* rows; 0x7fffffff: never */
+	pull_uploads_ = env_int("CSADP_PULL_UPLOADS", 1) != 0;
 	const bool band_forced = getenv("CSADP_TB_BAND_MIN") != nullptr;
 	const int tb_corridor = env_int("CSADP_TB_CORRIDOR", 3);      /* groups of 1024 start columns scouted per band */
 	tb_max_bands_ = tb_max_groups_ = 0;
@@ -859,6 +860,11 @@ int FillBatch::upload()
 		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, home_stream(0)));
 	/* every slot's stream must see the inputs: copy on the batch's first stream and wait (upload is not on the
 	 * timed path; run() calls may follow on any stream) */
+	if (cells_mode_ && nslots_ == 1 && pull_uploads_ && in_bytes_ <= (size_t)4 << 20) {
+		/* a lock-step round's tables: pulled by a kernel, and NOT waited for here -- the fill follows on the same stream */
+		HIP_TRY(launch_pull_pinned(arena_, h_in_, in_bytes_, home_stream(0)));
+		return CSADP_OK;
+	}
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, home_stream(0)));
 	HIP_TRY(hipStreamSynchronize(home_stream(0)));
 	return CSADP_OK;

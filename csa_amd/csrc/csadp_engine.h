@@ -189,6 +189,7 @@ private:
 	int bits_words_ = 1;                          /* words of 32 columns per lane of this batch's bit-parallel kernels */
 	int bits_lds_pad_ = 0;                        /* dynamic LDS a one-workgroup-per-job fill launch reserves on top (bounds the workgroups per compute unit) */
 	bool test_abort_ = false;                     /* CSADP_TEST_FORCE_ABORT, read when the batch is laid out */
+	bool pull_uploads_ = true;                    /* CSADP_PULL_UPLOADS: profile steps' tables are read from pinned memory by a kernel */
 	bool tb_overlap_ = true;                      /* CSADP_TB_OVERLAP: few-job batches walk and replay side by side */
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	unsigned used_streams_ = 0;

@@ -39,6 +39,8 @@ hipError_t configure_kernels();
 /* Column statistics (tools.c:259-281): out[0] gaps, out[1] conserved columns, out[2] SP score;
  * chars = nseq x length bytes, sequence-major; out must be zeroed. */
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st);
+/* bytes from pinned host memory to the device, read by a kernel (small latency-bound uploads) */
+hipError_t launch_pull_pinned(void *dst, const void *pinned_src, size_t bytes, hipStream_t st);
 
 }  // namespace csadp
 

@@ -5,6 +5,8 @@
  * families of rounds 1-2 were reachable only through environment switches and were retired in round 3.
  */
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "csadp_device.h"
@@ -45,6 +47,22 @@ __global__ __launch_bounds__(256) void sp_columns(const uint8_t *__restrict__ ch
 	atomicAdd((unsigned long long *)&part[2], (unsigned long long)score);
 	__syncthreads();
 	if (threadIdx.x < 3) atomicAdd((unsigned long long *)&out[threadIdx.x], (unsigned long long)part[threadIdx.x]);
+}
+
+/* host -> device copy by the compute units: the inputs of a profile step are a few hundred KB in pinned host memory, which a
+ * kernel reads over PCIe directly; the copy engine's path costs ~25 us before the first byte (hipMemcpyAsync), this one ~10 */
+__global__ __launch_bounds__(256) void pull_pinned(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t units)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < units; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+hipError_t launch_pull_pinned(void *dst, const void *pinned_src, size_t bytes, hipStream_t st)
+{
+	const size_t units = (bytes + 15) / 16;                  /* both buffers are allocated in multiples of 256 bytes */
+	if (units == 0) return hipSuccess;
+	const int blocks = (int)std::min<size_t>((units + 255) / 256, 512);
+	hipLaunchKernelGGL(pull_pinned, dim3(blocks), dim3(256), 0, st, reinterpret_cast<uint4 *>(dst), reinterpret_cast<const uint4 *>(pinned_src), units);
+	return hipGetLastError();
 }
 
 hipError_t launch_sp_columns(const uint8_t *chars, int nseq, int length, long long *out, hipStream_t st)
