@@ -329,7 +329,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU (config 4: 1024 / 8)")
     ap.add_argument("--len", type=int, default=16384, dest="length")
     ap.add_argument("--mode", default="weak", choices=["weak", "strong"])
-    ap.add_argument("--workload", default="config4", choices=["config4", "config5", "mammals"],
+    ap.add_argument("--workload", default="config4", choices=["config4", "config5", "mammals", "primates"],
                     help="--mode strong: which list rank 0 owns; mammals = config 3, all 66 whole-sequence pairs of "
                          "tests/golden/data/Mammals.txt with the reference's rotations: rank 0 reads the FASTA and broadcasts the pool")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -383,13 +383,15 @@ def main():
     else:
         # rank 0 owns the list; cost = DP cells from the nominal lengths; LPT + broadcast
         pair_of = None
-        if args.workload == "mammals":
-            # config 3: rank 0 owns the FASTA batch; every other rank receives the letters and rotations as one packed pool
+        if args.workload in ("mammals", "primates"):
+            # config 3 (and its second point, the 120 Primates pairs): rank 0 owns the FASTA batch; every other rank receives
+            # the letters and rotations as one packed pool
+            setname = args.workload.capitalize()
             seqs = rots = None
             if rank == 0:
                 from helpers import GOLDEN, load_golden, read_fasta
-                _, seqs = read_fasta(os.path.join(GOLDEN, "data", "Mammals.txt"))
-                rots = load_golden("pipeline.json")["Mammals"]["rotations"]
+                _, seqs = read_fasta(os.path.join(GOLDEN, "data", setname + ".txt"))
+                rots = load_golden("pipeline.json")[setname]["rotations"]
             pool, prot = group.broadcast_pool(seqs, rots)
             pair_of = [(a, b) for a in range(len(pool)) for b in range(a + 1, len(pool))]
             lens = [(len(pool[a]), len(pool[b])) for a, b in pair_of]
@@ -467,8 +469,9 @@ def main():
         rows_ok = len(rows_by_id) == expect and all(csa_amd.fnv1a(rows_by_id[t]) == by_id[t][2] for t in by_id)
         ok = ok and rows_ok
         checked = 0
-        if args.mode == "strong" and args.workload == "mammals":
-            gold = {(c["a"], c["b"]): c for c in load_golden("real_pairs.json") if c["set"] == "Mammals"}
+        if args.mode == "strong" and args.workload in ("mammals", "primates"):
+            gold = {(c["a"], c["b"]): c for c in load_golden("real_pairs.json")
+                    if c["set"] == args.workload.capitalize() and list(c["rots"]) == [prot[c["a"]], prot[c["b"]]]}
             for t, (a, b) in enumerate(pair_of):
                 g = gold[(a, b)]
                 ok = ok and by_id[t] == (g["sp"], g["consensus"], int(g["fnv1a"], 16))
@@ -495,7 +498,9 @@ def main():
         line = {
             "metric": "DP cells/sec (GCUPS) on %s, letters in HBM -> aligned rows in HBM, whole job" % (
                 "1-200 kbp mixed-length pairs (config 5)" if args.workload == "config5" and args.mode == "strong" else
-                "the 66 whole-sequence Mammals pairs (config 3)" if args.workload == "mammals" and args.mode == "strong" else "16 kbp x 16 kbp pairs"),
+                "the 66 whole-sequence Mammals pairs (config 3)" if args.workload == "mammals" and args.mode == "strong" else
+                "the 120 whole-sequence Primates pairs (config 3, second point)" if args.workload == "primates" and args.mode == "strong" else
+                "16 kbp x 16 kbp pairs"),
             "value": round(value, 3), "unit": "GCUPS", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": args.mode, "vs_baseline": None,

@@ -529,12 +529,21 @@ int FillBatch::layout_bits()
 		/* two words per lane when that still puts two waves on every SIMD: strips of 64 lanes x 2 words, times the passes a
 		 * pipelined batch keeps in flight (2 launches of up to 4 passes, chosen below by the same rule).  Batches smaller than
 		 * that -- down to one matrix -- are bound by the latency of a step: one word per lane, twice the strips. */
-		long long strips2 = 0;
-		for (const FillJob &J : jobs_) strips2 += ((J.ncols + 31) / 32 + 127) / 128;
+		long long strips2 = 0, cost1 = 0, cost2 = 0;
+		for (const FillJob &J : jobs_) {
+			const long long s1 = ((J.ncols + 31) / 32 + 63) / 64, s2 = ((J.ncols + 31) / 32 + 127) / 128;
+			strips2 += s2;
+			/* a workgroup's waves go round the four SIMDs: a fifth strip -- 17 000 columns at two words per lane -- doubles
+			 * up on the first strip's SIMD and the whole chain of strips runs at that pair's pace; so strips count in fours,
+			 * times the step's instructions (31 / 52 for one / two words per lane) */
+			cost1 += (s1 + 3) / 4 * 4 * 31;
+			cost2 += (s2 + 3) / 4 * 4 * 52;
+		}
 		const long long simds = 4LL * std::max(E.compute_units(), 1);
-		const int group2 = pipelined_ ? std::max(1, std::min((std::max(E.compute_units(), 1) + nj - 1) / nj, 4)) : 1;
+		const int group2 = pipelined_ ? std::max(1, std::min(std::max(E.compute_units(), 1) / std::max(nj, 1), 4)) : 1;
 		const long long in_flight = strips2 * (pipelined_ ? 2 * group2 : 1);
-		int w = in_flight >= 2 * simds ? 2 : 1;
+		/* (one word per lane only when it is clearly cheaper: at equal cost two words measure 14 % faster -- 64 jobs of 33 000 columns) */
+		int w = (2 * in_flight >= 3 * simds && 93 * cost2 <= 100 * cost1) ? 2 : 1;
 		w = env_int("CSADP_BITS_WORDS", w);
 		bits_words_ = (w == 2 || w == 4) ? w : 1;
 	}
@@ -574,8 +583,13 @@ int FillBatch::layout_bits()
 		/* passes per launch: one workgroup per compute unit (tools/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
 		 * per lane 2 streams x 2 passes = two waves per SIMD runs 44 TCUPS, 4 x 2 39-43, 2 x 4 37-40: more workgroups than compute
 		 * units per launch are not spread evenly over them) */
+		/* ... so a launch of workgroups of four strips holds as many passes as give every compute unit at most ONE of them
+		 * (120 jobs: 2 passes = 240 workgroups run 39 TCUPS, 3 passes = 360 run 29: the compute units that get two take twice
+		 * as long); workgroups of more strips than SIMDs are uneven anyway and do better queued deep (120 jobs of 9 strips: 4
+		 * passes 27.5 TCUPS, 2 passes 22.6) */
 		const int want = std::max(E.compute_units(), 1);
-		bits_group_ = std::max(1, std::min((want + nj - 1) / nj, 4));
+		if (bits_maxstrips_ <= 4) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
+		else bits_group_ = std::max(1, std::min((2 * want + nj - 1) / nj, 4));
 		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
 		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", dflt_streams), E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
