@@ -48,6 +48,7 @@ VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 BITS_STEP_MIX = {
     1: {"v_bitop3": (19, 2.6), "dpp_or_carry": (11, 4.3), "two_operand": (1, 2.1)},
     2: {"v_bitop3": (36, 2.6), "dpp_or_carry": (14, 4.3), "two_operand": (2, 2.1)},
+    3: {"v_bitop3": (53, 2.6), "dpp_or_carry": (17, 4.3), "two_operand": (3, 2.1)},
     4: {"v_bitop3": (70, 2.6), "dpp_or_carry": (20, 4.3), "two_operand": (4, 2.1)},
 }
 

@@ -138,6 +138,24 @@ __device__ __forceinline__ void chain_w2(uint32_t &s0, uint32_t &s1, uint32_t &a
 }
 
 template <bool ROWS, bool ACC>
+__device__ __forceinline__ void chain_w3(uint32_t (&s)[3], uint32_t &acc, uint32_t no, uint32_t z, const uint32_t (&a)[3], const uint32_t (&b)[3])
+{
+	uint32_t j;
+#define CSADP_W3                                                                                                        \
+	"v_addc_co_u32 %[s0], vcc, %[a0], %[b0], vcc\n\tv_addc_co_u32 %[s1], vcc, %[a1], %[b1], vcc\n\t"                    \
+	"v_addc_co_u32 %[s2], vcc, %[a2], %[b2], vcc"
+#define CSADP_W3_OUT [j] "=&v"(j), [s0] "=&v"(s[0]), [s1] "=&v"(s[1]), [s2] "=&v"(s[2])
+#define CSADP_W3_IN [no] "v"(no), [z] "v"(z), [a0] "v"(a[0]), [b0] "v"(b[0]), [a1] "v"(a[1]), [b1] "v"(b[1]), [a2] "v"(a[2]), [b2] "v"(b[2])
+	if (ROWS && ACC) asm volatile(CSADP_SUB(CSADP_DPP_ROW) CSADP_W3 "\n\t" CSADP_ACC : CSADP_W3_OUT, [acc] "+v"(acc) : CSADP_W3_IN : "vcc");
+	else if (ROWS) asm volatile(CSADP_SUB(CSADP_DPP_ROW) CSADP_W3 : CSADP_W3_OUT : CSADP_W3_IN : "vcc");
+	else if (ACC) asm volatile(CSADP_SUB(CSADP_DPP_WAVE) CSADP_W3 "\n\t" CSADP_ACC : CSADP_W3_OUT, [acc] "+v"(acc) : CSADP_W3_IN : "vcc");
+	else asm volatile(CSADP_SUB(CSADP_DPP_WAVE) CSADP_W3 : CSADP_W3_OUT : CSADP_W3_IN : "vcc");
+#undef CSADP_W3
+#undef CSADP_W3_OUT
+#undef CSADP_W3_IN
+}
+
+template <bool ROWS, bool ACC>
 __device__ __forceinline__ void chain_w4(uint32_t (&s)[4], uint32_t &acc, uint32_t no, uint32_t z, const uint32_t (&a)[4], const uint32_t (&b)[4])
 {
 	uint32_t j;
@@ -160,9 +178,10 @@ __device__ __forceinline__ void chain_w4(uint32_t (&s)[4], uint32_t &acc, uint32
 template <int W, bool ROWS, bool ACC>
 __device__ __forceinline__ void chain(uint32_t (&s)[W], uint32_t &acc, uint32_t no, uint32_t z, const uint32_t (&a)[W], const uint32_t (&b)[W])
 {
-	static_assert(W == 1 || W == 2 || W == 4, "words per lane");
+	static_assert(W >= 1 && W <= 4, "words per lane");
 	if constexpr (W == 1) chain_w1<ROWS, ACC>(s[0], acc, no, z, a[0], b[0]);
 	else if constexpr (W == 2) chain_w2<ROWS, ACC>(s[0], s[1], acc, no, z, a[0], b[0], a[1], b[1]);
+	else if constexpr (W == 3) chain_w3<ROWS, ACC>(s, acc, no, z, a, b);
 	else chain_w4<ROWS, ACC>(s, acc, no, z, a, b);
 }
 
@@ -557,15 +576,22 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 constexpr int kOverlapPieces = 16;         /* a 16 kbp pair: 0.29 ms; 12 pieces (three replaying waves + the walking one, a SIMD each) 0.305;
                                             * 16 pieces on eight replaying waves of two pieces each (two waves per SIMD) 0.34 */
 
+/* the lane column (64 per strip) of 0-based matrix column c: 32 W columns per lane; floor for negative c (left of the matrix) */
+template <int W>
+__device__ __forceinline__ int lane_column(int c)
+{
+	if constexpr (W == 3) return c >= 0 ? c / 96 : -((95 - c) / 96);
+	else return c >> (W == 1 ? 5 : W == 2 ? 6 : 7);
+}
+
 /* slope: columns the planned path moves left per local step, in 1/1024 (1024: the diagonal, what the plain kernel plans with;
  * the overlapped one plans along the line to the matrix' corner: a pair of 12.5 k x 16.3 k letters -- the first fill of Set3's
  * wide gap -- leaves every diagonal plan within a round) */
 template <int W>
 __device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d, int slope = 1024)
 {
-	constexpr int cs = W == 1 ? 5 : W == 2 ? 6 : 7;            /* log2 of the columns per lane */
 	const int m = max(0, 32 * d - 31 + (l0 & 31));             /* steps up the planned path to the piece's block (upper bound) */
-	const int le = ((k0 - 1 - ((m * slope) >> 10)) >> cs) - 64 * s;   /* lane of the path there; negative: left of this strip */
+	const int le = lane_column<W>(k0 - 1 - ((m * slope) >> 10)) - 64 * s;   /* lane of the path there; negative: left of this strip */
 	return min(max(le - 8, 0), kLanes - 16);
 }
 
@@ -580,7 +606,6 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 {
 	static_assert(!(OVERLAP && SCORE), "no room for two sets of match masks");
 	constexpr int pitch = 16 * W + 1;
-	constexpr int cs = W == 1 ? 5 : W == 2 ? 6 : 7;
 	constexpr int kSets = OVERLAP ? 2 : 1;
 	__shared__ __attribute__((aligned(16))) uint2 tile[kSets * NP][kBitBlock * pitch];
 	__shared__ uint32_t mtile[SCORE ? NP : 1][SCORE ? kBitBlock * pitch : 1];    /* match masks of the same cells */
@@ -742,7 +767,7 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 	};
 	while (r > 0 && k > 0) {
 		if (!OVERLAP || plan) {                                  /* plan the pieces from the current cell */
-			const int wq = (k - 1) >> cs;                          /* lane column of the current cell */
+			const int wq = lane_column<W>(k - 1);                  /* lane column of the current cell */
 			s = wq >> 6;
 			l0 = (r - 1) + (wq & 63);
 			btop = l0 / kBitBlock;
@@ -780,14 +805,14 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 				 * two LDS round trips per iteration on a wave that has its SIMD to itself) */
 				const int ri = r - lane, ki = k - lane;
 				const int kc = ki - 1;
-				const int wi = kc >> cs;                       /* arithmetic: cells left of the matrix fail the strip test */
+				const int wi = lane_column<W>(kc);             /* floor: cells left of the matrix fail the strip test */
 				const int sl = wi & 63;
 				const int l = (ri - 1) + sl;
 				const int dabs = btop - (l >> 5);                     /* piece number up the planned diagonal */
 				const int d = dabs - dbase;                            /* its tile in this set */
 				const int rel = sl - piece_first_lane<W>(k0, l0, s, dabs, slope);
 				const bool ok = (ri > 0) & (ki > 0) & ((wi >> 6) == s) & ((unsigned)d < (unsigned)NP) & ((unsigned)rel < 16u);
-				const int at = ok ? d * (kBitBlock * pitch) + (l & 31) * pitch + ((kc >> 5) & (W - 1)) * 16 + rel : 0;
+				const int at = ok ? d * (kBitBlock * pitch) + (l & 31) * pitch + (W == 3 ? (unsigned)(kc >> 5) % 3u : (unsigned)(kc >> 5) & (unsigned)(W - 1)) * 16 + rel : 0;
 				const uint2 dd = tiles[at];
 				const uint32_t sh = (uint32_t)kc & 31u;
 				const uint32_t nd = (dd.x >> sh) & 1u, lf = (dd.y >> sh) & 1u;
@@ -826,7 +851,7 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 		TB_LAP(tm_sync);
 		if (OVERLAP && r > 0 && k > 0) {
 			/* did the walk end where the plan continues?  The current cell must lie in a piece of the set just replayed */
-			const int wq = (k - 1) >> cs, sl = wq & 63;
+			const int wq = lane_column<W>(k - 1), sl = wq & 63;
 			const int dabs = btop - (((r - 1) + sl) >> 5);
 			const unsigned rel = (unsigned)(sl - piece_first_lane<W>(kref, l0, s, dabs, slope));
 			if ((wq >> 6) == s && dabs >= dbase + NP && dabs < dbase + 2 * NP && rel < 16u) {
@@ -864,7 +889,7 @@ hipError_t configure_kernels() { return hipSuccess; }
 int fill_bits_lds_bytes(int waves) { return waves * (kRing * 16 + kBitBlock * kInjWords * 4 + 8) + (kBitBlock * kInjWords + 4) * 4; }
 int traceback_bits_lds_bytes(int words)
 {
-	const int np = words == 1 ? kReplayPieces1 : words == 2 ? kReplayPieces2 : kReplayPieces4;
+	const int np = words == 1 ? kReplayPieces1 : words == 2 ? kReplayPieces2 : words == 3 ? kReplayPieces3 : kReplayPieces4;
 	return np * (kBitBlock * (16 * words + 1) * 8 + kBitBlock * kInjWords * 4) + (kBitBlock * kInjWords + 4) * 4 + 16;
 }
 
@@ -895,6 +920,7 @@ hipError_t launch_fill_any(int words, int waves, bool chunked, uint8_t *arena, c
 {
 	if (words == 1) return launch_fill_waves<1>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
 	if (words == 2) return launch_fill_waves<2>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
+	if (words == 3) return launch_fill_waves<3>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
 	if (words == 4) return launch_fill_waves<4>(waves, chunked, arena, jobs, njobs, passes, threads, work, nwork, epoch, abort_word, st);
 	return hipErrorInvalidValue;
 }
@@ -932,6 +958,7 @@ hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, 
 	} while (0)
 	if (words == 1) CSADP_TB(1, kReplayPieces1, kReplayPieces1);
 	else if (words == 2) CSADP_TB(2, kReplayPieces2, 8);
+	else if (words == 3) CSADP_TB(3, kReplayPieces3, 6);
 	else if (words == 4) CSADP_TB(4, kReplayPieces4, kReplayPieces4);
 	else return hipErrorInvalidValue;
 #undef CSADP_TB

@@ -62,7 +62,7 @@ constexpr int kBitMaxWords = 4;      /* words per lane: 1, 2 or 4, chosen per ba
 #ifndef CSADP_TB_NP1
 #define CSADP_TB_NP1 16
 #endif
-constexpr int kReplayPieces1 = CSADP_TB_NP1, kReplayPieces2 = CSADP_TB_NP2, kReplayPieces4 = 4;
+constexpr int kReplayPieces1 = CSADP_TB_NP1, kReplayPieces2 = CSADP_TB_NP2, kReplayPieces3 = 8, kReplayPieces4 = 4;
 
 struct BitJob {
 	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */

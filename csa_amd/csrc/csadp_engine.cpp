@@ -529,23 +529,32 @@ int FillBatch::layout_bits()
 		/* two words per lane when that still puts two waves on every SIMD: strips of 64 lanes x 2 words, times the passes a
 		 * pipelined batch keeps in flight (2 launches of up to 4 passes, chosen below by the same rule).  Batches smaller than
 		 * that -- down to one matrix -- are bound by the latency of a step: one word per lane, twice the strips. */
-		long long strips2 = 0, cost1 = 0, cost2 = 0;
+		long long strips[4] = {0, 0, 0, 0}, cost[4] = {0, 0, 0, 0};
+		static const int kStepValu[4] = {0, 31, 52, 73};              /* VALU instructions per step (tools/count_valu.py) */
 		for (const FillJob &J : jobs_) {
-			const long long s1 = ((J.ncols + 31) / 32 + 63) / 64, s2 = ((J.ncols + 31) / 32 + 127) / 128;
-			strips2 += s2;
-			/* a workgroup's waves go round the four SIMDs: a fifth strip -- 17 000 columns at two words per lane -- doubles
-			 * up on the first strip's SIMD and the whole chain of strips runs at that pair's pace; so strips count in fours,
-			 * times the step's instructions (31 / 52 for one / two words per lane) */
-			cost1 += (s1 + 3) / 4 * 4 * 31;
-			cost2 += (s2 + 3) / 4 * 4 * 52;
+			const long long words = (J.ncols + 31) / 32;
+			for (int w = 1; w <= 3; ++w) {
+				const long long sw = (words + 64 * w - 1) / (64 * w);
+				strips[w] += sw;
+				/* a workgroup's waves go round the four SIMDs: a fifth strip -- 17 000 columns at two words per lane -- doubles
+				 * up on the first strip's SIMD and the whole chain of strips runs at that pair's pace; so beyond four, strips
+				 * count in fours, times the step's instructions */
+				cost[w] += (sw <= 4 ? sw : (sw + 3) / 4 * 4) * kStepValu[w];
+			}
 		}
 		const long long simds = 4LL * std::max(E.compute_units(), 1);
 		const int group2 = pipelined_ ? std::max(1, std::min(std::max(E.compute_units(), 1) / std::max(nj, 1), 4)) : 1;
-		const long long in_flight = strips2 * (pipelined_ ? 2 * group2 : 1);
-		/* (one word per lane only when it is clearly cheaper: at equal cost two words measure 14 % faster -- 64 jobs of 33 000 columns) */
-		int w = (2 * in_flight >= 3 * simds && 93 * cost2 <= 100 * cost1) ? 2 : 1;
+		const int passes = pipelined_ ? 2 * group2 : 1;
+		/* two words per lane when that still keeps 1.5 waves per SIMD in flight; three -- real mitochondrial genomes: 16.4-17.0 k
+		 * letters are three strips of 6144 columns instead of five of 4096 -- when one wave per SIMD; one word per lane only
+		 * when it is clearly cheaper (at equal cost two words measure 14 % faster: 64 jobs of 33 000 columns) */
+		const bool ok2 = 2 * strips[2] * passes >= 3 * simds, ok3 = strips[3] * passes >= simds;
+		int w = 1;
+		long long best = cost[1] * 100 / 93;
+		if (ok2 && cost[2] <= best) { w = 2; best = cost[2]; }
+		if (ok3 && cost[3] < best) { w = 3; best = cost[3]; }
 		w = env_int("CSADP_BITS_WORDS", w);
-		bits_words_ = (w == 2 || w == 4) ? w : 1;
+		bits_words_ = (w >= 2 && w <= 4) ? w : 1;
 	}
 	const int wpl = bits_words_;
 	for (int j = 0; j < nj; ++j) {

@@ -20,7 +20,7 @@ def device():
 # each of the three kernels
 # Batches of at most 32 one-word jobs take the traceback that walks one tile set while the next is replayed
 # (CSADP_TB_OVERLAP, default on); "1 word, replay then walk" runs the same cases through the plain one.
-@pytest.fixture(params=["1 word", "1 word, replay then walk", "2 words", "4 words"])
+@pytest.fixture(params=["1 word", "1 word, replay then walk", "2 words", "3 words", "4 words"])
 def bits_mode(request, monkeypatch):
     monkeypatch.setenv("CSADP_BITS_WORDS", request.param.split()[0])
     if "then walk" in request.param:
