@@ -203,12 +203,15 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
                       "GPU strings %s" % (n, secs, "identical" if mismatches == 0 else "MISMATCH x%d" % mismatches)}
 
 
-def cpu_many_cores(tasks, per_proc=2):
+def cpu_many_cores(tasks, per_proc=2, o3=False):
     """The same CPU code in P independent processes (the reference keeps global state, so no
     threads), `per_proc` pairs each.  Runs BEFORE this process touches the GPU, so the forked
-    children never hold a device context."""
-    from helpers import have_ref, oracle_progressive, ref_progressive
-    run = ref_progressive if have_ref() else (lambda t, r: oracle_progressive(t, r))
+    children never hold a device context.  o3: the reference built with -O3 -march=znver3
+    -fomit-frame-pointer (oracle/Makefile: SURVEY 8(d)(ii)'s second compiler setting)."""
+    from helpers import have_ref, have_ref_o3, oracle_progressive, ref_progressive
+    if o3 and not have_ref_o3():
+        return None
+    run = (lambda t, r: ref_progressive(t, r, o3=o3)) if have_ref() else (lambda t, r: oracle_progressive(t, r))
     procs = max(1, min(32, (os.cpu_count() or 2) // 2, len(tasks) // per_proc))
     pids = []
     t0 = time.perf_counter()
@@ -229,6 +232,7 @@ def cpu_many_cores(tasks, per_proc=2):
     wall = time.perf_counter() - t0
     cells = sum(len(t[0][0]) * len(t[0][1]) for t in tasks[:procs * per_proc])
     return {"value": round(cells / wall / 1e9, 3) if ok else None, "unit": "GCUPS", "cores": procs,
+            "build": "-O3 -march=znver3 -fomit-frame-pointer" if o3 else "-O2",
             "sample": "%d processes x %d pairs, %.1f s wall" % (procs, per_proc, wall)}
 
 
@@ -273,6 +277,93 @@ def streaming_leg(csa_amd, tasks, batches, depth=3):
             "batches": batches, "in_flight": depth, "ok": ok,
             "what": "host letters -> H2D -> pack, fill, traceback, expand -> D2H -> malloc'd result strings, "
                     "several batches in flight through csadp_pairs_create/run/flush/fetch"}
+
+
+def timed_pair_batch(csa_amd, tasks, steps, warmup):
+    """`steps` passes of one device-resident pair batch, timed like the headline (letters in HBM -> aligned rows in HBM; every
+    pass enqueued, then one wait), after `warmup` untimed ones.  Returns (seconds, timing record of the last launch, results)."""
+    pb = csa_amd.PairBatch(tasks)
+    pb.sync()
+    for _ in range(warmup):
+        pb.run()
+    pb.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pb.run()
+    pb.sync()
+    dt = time.perf_counter() - t0
+    tm = pb.timing()
+    res = pb.fetch()
+    pb.close()
+    return dt, tm, res
+
+
+def real_sets_leg(csa_amd, steps=48, warmup=8):
+    """BASELINE config 3 and its second point: ALL whole-sequence pairs of the reference's example sets (Manual/Mammals.txt: 66,
+    Manual/Primates.txt: 120) with the reference's rotations, as one device-resident batch each; every record (SP score,
+    consensus, FNV-1a of the two rows) against the compiled reference's (tests/golden/real_pairs.json)."""
+    from helpers import GOLDEN, load_golden, read_fasta
+    out = {}
+    gold_all = load_golden("real_pairs.json")
+    pipe = load_golden("pipeline.json")
+    for setname in ("Mammals", "Primates"):
+        _, seqs = read_fasta(os.path.join(GOLDEN, "data", setname + ".txt"))
+        rots = pipe[setname]["rotations"]
+        pair_of = [(a, b) for a in range(len(seqs)) for b in range(a + 1, len(seqs))]
+        tasks = [([seqs[a], seqs[b]], [rots[a], rots[b]], None, None) for a, b in pair_of]
+        dt, tm, res = timed_pair_batch(csa_amd, tasks, steps, warmup)
+        gold = {(c["a"], c["b"]): c for c in gold_all if c["set"] == setname and list(c["rots"]) == [rots[c["a"]], rots[c["b"]]]}
+        same = 0
+        for (a, b), r in zip(pair_of, res):
+            g = gold.get((a, b))
+            if g and r["status"] == 0 and (r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])) == (g["sp"], g["consensus"], int(g["fnv1a"], 16)):
+                same += 1
+        out[setname] = {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
+                        "ms_per_step": round(dt * 1e3 / steps, 3), "steps": steps, "warmup": warmup,
+                        "equal_to_reference_digests": same, "words_per_lane": tm["words_per_lane"],
+                        "passes_per_launch": tm["merge_group"], "launches_in_flight": tm["streams"]}
+    out["what"] = ("config 3: the 66 Mammals and the 120 Primates whole-sequence pairs (16.3-17.7 k letters, gap-rich paths), letters in HBM -> "
+                   "aligned rows in HBM, timed like `value`")
+    return out
+
+
+def config5_leg(csa_amd, steps=3, warmup=1):
+    """BASELINE config 5: 256 pairs of 1-200 kbp (1.2e12 cells per pass) as ONE device-resident batch; every result re-spells its
+    inputs and scores what its rows score."""
+    from csa_amd.synth import config5_lengths, synth_pair
+    from helpers import degap, rotated, sp_score
+    la, _ = config5_lengths(256)
+    tasks = []
+    for i, length in enumerate(la):
+        a, b, ra, rb = synth_pair(20000 + i, length=int(length))
+        tasks.append(([a, b], [ra, rb], None, None))
+    dt, tm, res = timed_pair_batch(csa_amd, tasks, steps, warmup)
+    ok = True
+    for t, r in zip(tasks, res):
+        ok = ok and r["status"] == 0 and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
+        ok = ok and sp_score(r["aligned"]) == r["score"]
+    return {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
+            "ms_per_step": round(dt * 1e3 / steps, 2), "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"],
+            "properties_hold_for_all": bool(ok),
+            "what": "256 synthetic pairs of 1-200 kbp in one batch (jobs of up to 33 strips run as chains of workgroups)"}
+
+
+def unrelated_leg(csa_amd, steps=20, warmup=5):
+    """SURVEY 8(d), config 4's second variant: 64 UNRELATED 16 kbp pairs -- the gap-richest paths a 16 kbp pair has."""
+    from csa_amd.synth import synth_pair
+    from helpers import degap, rotated, sp_score
+    tasks = []
+    for p in range(64):
+        a, b, ra, rb = synth_pair(70000 + p, unrelated=True)
+        tasks.append(([a, b], [ra, rb], None, None))
+    dt, tm, res = timed_pair_batch(csa_amd, tasks, steps, warmup)
+    ok = True
+    for t, r in zip(tasks, res):
+        ok = ok and r["status"] == 0 and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
+        ok = ok and sp_score(r["aligned"]) == r["score"]
+    return {"pairs": len(tasks), "gcups": round(tm["cells"] * steps / dt / 1e9, 1), "ms_per_step": round(dt * 1e3 / steps, 3),
+            "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"], "properties_hold_for_all": bool(ok),
+            "what": "64 unrelated random 16384-letter pairs (tests/test_gpu_parity.py holds their scores to the oracle's optimum)"}
 
 
 def profile_path_leg(csa_amd):
@@ -351,10 +442,11 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    many_cores = None
+    many_cores = many_cores_o3 = None
     if args.gpus == 1 and not args.no_cpu_baseline:
         from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
         many_cores = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length))
+        many_cores_o3 = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length), o3=True)
 
     import csa_amd
     from csa_amd import dist as cdist
@@ -573,9 +665,22 @@ def main():
             line["one_shot"]["vs_value"] = round(line["one_shot"]["gcups_device"] / (value / args.gpus), 3)
             line["profile_path"] = profile_path_leg(csa_amd)
             line["single_matrix"] = single_matrix_leg(csa_amd)
+            # SURVEY 8(d)'s unit of work counts H2D of the sequences and D2H of the results inside the wall time: that rate,
+            # first class beside `value` (which starts and ends in HBM, as the bench contract asks)
+            line["gcups_8d_h2d_d2h_inclusive"] = {"value": line["streaming"]["gcups"], "unit": "GCUPS", "vs_value": line["streaming"]["vs_value"],
+                                                  "what": "SURVEY 8(d): host letters -> H2D -> kernels -> D2H -> host strings inside the wall "
+                                                          "time (the `streaming` leg: %d batches of %d pairs, %d in flight)" % (
+                                                              line["streaming"]["batches"], len(big), line["streaming"]["in_flight"])}
+            if args.mode == "weak" and args.workload == "config4":
+                line["real_sets"] = real_sets_leg(csa_amd)
+                line["config5"] = config5_leg(csa_amd)
+                line["unrelated_16k"] = unrelated_leg(csa_amd)
+                line["records"]["checked_against_reference_digests_in_all_legs"] = (
+                    checked + line["real_sets"]["Mammals"]["equal_to_reference_digests"] + line["real_sets"]["Primates"]["equal_to_reference_digests"])
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)
             line["cpu_baseline"]["many_cores"] = many_cores
+            line["cpu_baseline"]["many_cores_o3"] = many_cores_o3
             line["cpu_baseline"]["host"] = host_description()
             line["cpu_baseline"]["reference_faithful"] = reference_faithful_sample(csa_amd)
     batch.close()

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <chrono>
 #include <limits>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -124,45 +125,57 @@ int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Bor
 	 * One item per (text s, automaton t): N x N independent walks (round 2 ran one item per text: 12-19 items on a host
 	 * with 256 hardware threads), then one item per text takes the minimum over the automata. */
 	std::vector<std::vector<int>> common((size_t)N), ident((size_t)N);
-	std::vector<std::vector<int>> walk((size_t)N * N), st0((size_t)N);
+	std::vector<std::vector<int>> st0((size_t)N);
+	/* Every item walks its text through its automaton and min-reduces what it finds into common[s], a chunk of positions at a
+	 * time under the text's lock: the transient memory stays O(N n) (round 3 kept every walk whole until a second pass reduced
+	 * them: N x N vectors of text length, 280 MB for 64 genomes of 17 kbp, over 3 GB for 200 kbp inputs). */
+	std::vector<std::mutex> guard((size_t)N);
+	host_parallel_for(N, [&](int s) {
+		const int n = (int)rev[(size_t)s].size();
+		std::vector<int> &L = common[(size_t)s];
+		L.resize((size_t)n);
+		for (int p = 0; p < n; ++p) L[(size_t)p] = n - p;         /* own bound: the suffix itself */
+		st0[(size_t)s].assign((size_t)n, 0);
+	});
 	host_parallel_for(N * N, [&](int item) {
 		const int s = item / N, t = item % N;
 		if (t == s && t != 0) return;                              /* the text's own bound is the suffix itself */
 		const std::vector<unsigned char> &R = rev[(size_t)s];
 		const int n = (int)R.size();
-		std::vector<int> &L = walk[(size_t)item];
-		L.resize((size_t)n);
-		if (t == 0) st0[(size_t)s].assign((size_t)n, 0);
+		constexpr int kChunk = 4096;
+		int part[kChunk];                                          /* matching statistics of positions p0 .. p0 + len - 1, descending q */
+		std::vector<int> &L = common[(size_t)s];
+		int *S0 = t == 0 ? st0[(size_t)s].data() : nullptr;        /* the states in automaton 0: one writer per text */
 		const Automaton &A = sam[(size_t)t];
 		int v = 0, l = 0;
-		for (int q = 0; q < n; ++q) {
-			const int c = R[(size_t)q];
-			while (v != 0 && A.st[(size_t)v].next[c] == -1) {
-				v = A.st[(size_t)v].link;
-				l = A.st[(size_t)v].len;
+		for (int q0 = 0; q0 < n; q0 += kChunk) {
+			const int len = std::min(kChunk, n - q0);
+			for (int i = 0; i < len; ++i) {
+				const int q = q0 + i;
+				const int c = R[(size_t)q];
+				while (v != 0 && A.st[(size_t)v].next[c] == -1) {
+					v = A.st[(size_t)v].link;
+					l = A.st[(size_t)v].len;
+				}
+				if (A.st[(size_t)v].next[c] != -1) {
+					v = A.st[(size_t)v].next[c];
+					++l;
+				}
+				part[i] = l;
+				if (S0) S0[(size_t)(n - 1 - q)] = v;
 			}
-			if (A.st[(size_t)v].next[c] != -1) {
-				v = A.st[(size_t)v].next[c];
-				++l;
+			std::lock_guard<std::mutex> hold(guard[(size_t)s]);
+			for (int i = 0; i < len; ++i) {
+				int &dst = L[(size_t)(n - 1 - (q0 + i))];
+				if (part[i] < dst) dst = part[i];
 			}
-			const int p = n - 1 - q;
-			L[(size_t)p] = l;
-			if (t == 0) st0[(size_t)s][(size_t)p] = v;
 		}
 	});
 	host_parallel_for(N, [&](int s) {
 		const int n = (int)rev[(size_t)s].size();
-		std::vector<int> &L = common[(size_t)s];
+		const std::vector<int> &L = common[(size_t)s];
 		std::vector<int> &id = ident[(size_t)s];
-		L.resize((size_t)n);
 		id.assign((size_t)n, 0);
-		for (int p = 0; p < n; ++p) L[(size_t)p] = n - p;         /* own bound: the suffix itself */
-		for (int t = 0; t < N; ++t) {
-			if (t == s && t != 0) continue;
-			const std::vector<int> &W = walk[(size_t)s * N + t];
-			for (int p = 0; p < n; ++p)
-				if (W[(size_t)p] < L[(size_t)p]) L[(size_t)p] = W[(size_t)p];
-		}
 		const Automaton &A0 = sam[0];
 		for (int p = 0; p < n; ++p) {
 			int v = st0[(size_t)s][(size_t)p];

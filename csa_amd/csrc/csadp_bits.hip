@@ -35,7 +35,7 @@
  * (acc = 2 acc + carry: one v_addc_co_u32 per plane on the carry the chain has just left in VCC); the three
  * words are saved with the lane's checkpoint every 32 steps, so the traceback can restart a replay at ANY
  * lane, and lane 63's three words per block are all the next strip needs.
- * Work per lane and step: 31 VALU for W = 1, 53 for W = 2 (0.83 per cell), 97 for W = 4 (0.76).
+ * Work per lane and step (tools/count_valu.py): 31 VALU for W = 1, 52 for W = 2 (0.81 per cell), 73 for W = 3 (0.76), 94 for W = 4 (0.73).
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -53,7 +53,7 @@ struct TileRef {
  */
 constexpr int kBitMaxStrips = 16;    /* waves per workgroup */
 constexpr int kBitBlock = 32;        /* steps per hand-off block between strips */
-constexpr int kBitMaxWords = 4;      /* words per lane: 1, 2 or 4, chosen per batch (csadp_engine.cpp: layout_bits) */
+constexpr int kBitMaxWords = 4;      /* words per lane: 1, 2 or 3 chosen per batch, 4 on request (csadp_engine.cpp: layout_bits) */
 /* pieces (16 lanes x 32 steps) a traceback round replays, by words per lane (70 / 101 / 67 KB of LDS tiles).  Two words: 8 pieces
  * 44.6 TCUPS, 12 pieces 45.8-46.1, 16 pieces 23 (151 KB: no room for a fill workgroup next to it; profiles/r03_ab_*.txt) */
 #ifndef CSADP_TB_NP2

@@ -262,6 +262,7 @@ void Engine::shutdown()
 FillBatch::~FillBatch()
 {
 	(void)E_->bind();
+	settle_pull();
 	/* the arena and the pinned mirrors go back to the engine's pools: nothing may still be using them */
 	if (laid_out_ && bits_) {
 		(void)wait_batch();
@@ -277,8 +278,19 @@ FillBatch::~FillBatch()
 			if (e) (void)hipEventDestroy(e);
 }
 
+/* A pull upload (upload(): a kernel reads the pinned staging on the batch's stream) is not waited for where it is launched;
+ * download() waits for that stream on the way.  Every other road to the staging -- clear() and a new layout after an error
+ * between upload() and download(), the destructor -- settles it first. */
+void FillBatch::settle_pull()
+{
+	if (!pull_pending_) return;
+	if (E_->bind() == CSADP_OK) (void)hipStreamSynchronize(home_stream(0));
+	pull_pending_ = false;
+}
+
 void FillBatch::clear()
 {
+	settle_pull();
 	jobs_.clear();
 	extra_.clear();
 	tiles_.clear();
@@ -522,7 +534,7 @@ int FillBatch::layout_bits()
 	test_abort_ = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;        /* testing: read once per layout, not per launch */
 	tb_overlap_ = env_int("CSADP_TB_OVERLAP", 1) != 0;
 	bits_lds_pad_ = -1;                                             /* chosen below, once the launch shape is known */
-	/* Words of 32 columns per lane (1, 2 or 4).  More words per lane amortise what a step spends on its neighbours (the three
+	/* Words of 32 columns per lane (1, 2 or 3 by default; 4 on request: CSADP_BITS_WORDS).  More words per lane amortise what a step spends on its neighbours (the three
 	 * borrow instructions, the letter chain, the accumulators: 11 of W = 1's 31 instructions, 11 of W = 2's 53) and halve the
 	 * strips -- and with them the waves -- of a matrix.  DESIGN.md section 3 has the measurements behind the default. */
 	{
@@ -588,7 +600,12 @@ int FillBatch::layout_bits()
 	bits_group_ = 1;
 	nslots_ = 1;
 	if (pipelined_) {
-		const int dflt_streams = 2;
+		/* workgroups of at most three strips (real mitochondrial genomes at three words per lane: 16.3-17.7 k columns) leave a
+		 * SIMD of their compute unit idle and a pass is few waves (66 pairs: 198): four launches in flight, and no LDS
+		 * reservation below, so that a compute unit takes three or four of them (profiles/r04_sweep_real.txt, 48 steps:
+		 * 66 Mammals pairs 24.6 -> 29.6 TCUPS, 120 Primates pairs 31.2 -> 33.7) */
+		const bool small_wgs = bits_maxstrips_ <= 3;
+		const int dflt_streams = small_wgs ? 4 : 2;
 		/* passes per launch: one workgroup per compute unit (tools/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
 		 * per lane 2 streams x 2 passes = two waves per SIMD runs 44 TCUPS, 4 x 2 39-43, 2 x 4 37-40: more workgroups than compute
 		 * units per launch are not spread evenly over them) */
@@ -630,7 +647,7 @@ int FillBatch::layout_bits()
 	 * reserves dynamic LDS so that exactly two of them fit next to one traceback workgroup (tools/sweep_pad.sh,
 	 * profiles/r03_sweep_pad.txt: +2-4 %, and a collapse of 25 % as soon as two fills and a traceback no longer fit). */
 	bits_lds_pad_ = 0;
-	if (pipelined_ && !bits_wide_) {
+	if (pipelined_ && !bits_wide_ && bits_maxstrips_ > 3) {
 		const int waves = bits_maxstrips_ <= 4 ? 4 : bits_maxstrips_ <= 8 ? 8 : 16;
 		const int room = (160 * 1024 - traceback_bits_lds_bytes(bits_words_)) / 2 - fill_bits_lds_bytes(waves) - 2048;
 		bits_lds_pad_ = std::max(0, std::min(room, 60 * 1024)) & ~255;
@@ -790,7 +807,6 @@ int FillBatch::layout_bits()
 	 * all complete late and together, and the caller's pipeline runs dry in between: 4.9 vs 4.25 ms per 512-pair batch. */
 	const bool rotate = env_int("CSADP_STREAM_ROTATE", nj < E.compute_units() ? 1 : 0) != 0;
 	base_stream_ = rotate ? E.rotate_stream() % E.main_streams() : 0;
-	used_streams_ = 0;
 	issued_ = 0;
 	bjobs_ = slot_jobs[0];
 	return CSADP_OK;
@@ -800,6 +816,7 @@ int FillBatch::layout_bits()
 int FillBatch::alloc_buffers()
 {
 	Engine &E = *E_;
+	settle_pull();
 	if (total_bytes_ > arena_cap_) {
 		if (arena_) { E.give_arena(arena_, arena_cap_); arena_ = nullptr; arena_cap_ = 0; }
 		arena_ = E.take_arena(total_bytes_, &arena_cap_);
@@ -846,6 +863,7 @@ int FillBatch::alloc_buffers()
 /* buffers, zeroed inputs, events */
 int FillBatch::finish_layout()
 {
+	settle_pull();
 	{ const int arc = alloc_buffers(); if (arc != CSADP_OK) return arc; }
 	/* events: the bit-parallel path keeps a launch's three events at the first slot of its range only */
 	for (int sl = 0; sl < nslots_; ++sl) {
@@ -886,6 +904,7 @@ int FillBatch::upload()
 	if (cells_mode_ && nslots_ == 1 && pull_uploads_ && in_bytes_ <= (size_t)4 << 20) {
 		/* a lock-step round's tables: pulled by a kernel, and NOT waited for here -- the fill follows on the same stream */
 		HIP_TRY(launch_pull_pinned(arena_, h_in_, in_bytes_, home_stream(0)));
+		pull_pending_ = true;                          /* the kernel reads h_in_: settle_pull() before the staging is touched again */
 		return CSADP_OK;
 	}
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, home_stream(0)));
@@ -915,7 +934,6 @@ int FillBatch::upload_async()
 	HIP_TRY(hipEventRecord(ev_up_, s0));
 	for (int sl = 0; sl < nst; ++sl)
 		if (E_->stream(sl) != s0) HIP_TRY(hipStreamWaitEvent(E_->stream(sl), ev_up_, 0));
-	used_streams_ |= 1u << (bits_ ? base_stream_ : 0);
 	return CSADP_OK;
 }
 
@@ -962,7 +980,6 @@ int FillBatch::flush_bits(int k)
 		const int first = (qi * 2 + parity) * bits_group_;
 		const int g = std::min(k, bits_group_);
 		const int rc = launch_bits_pass(first, g, E.stream(q), E.stream(qs), false);
-		used_streams_ |= (1u << q) | (1u << qs);
 		last_stream_ = qs;
 		if (rc != CSADP_OK) return rc;
 		last_first_ = first;
@@ -1139,6 +1156,7 @@ int FillBatch::download()
 		HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipMemcpyAsync(h_res_, arena_ + res_off_[last_slot_], res_bytes_, hipMemcpyDeviceToHost, st));
 		HIP_TRY(hipStreamSynchronize(st));
+		pull_pending_ = false;                         /* one slot: st is the stream the pull ran on */
 		if (*h_abort_ == 0) return CSADP_OK;
 		const int arc = check_abort();                 /* repeats the pass chunk by chunk */
 		if (arc != CSADP_OK) return arc;

@@ -192,7 +192,8 @@ private:
 	bool pull_uploads_ = true;                    /* CSADP_PULL_UPLOADS: profile steps' tables are read from pinned memory by a kernel */
 	bool tb_overlap_ = true;                      /* CSADP_TB_OVERLAP: few-job batches walk and replay side by side */
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
-	unsigned used_streams_ = 0;
+	bool pull_pending_ = false;                   /* a pull upload of the staging may still be running on home_stream(0) */
+	void settle_pull();
 	int tb_max_bands_ = 0, tb_max_groups_ = 0;     /* band-parallel traceback: most bands / scout groups of a banded job */
 	unsigned long long issued_ = 0;             /* bit-parallel path: slot ranges (by first slot) with a launch on record */
 	int wait_batch();                           /* ... and the wait for exactly those launches (events, not streams) */

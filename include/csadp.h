@@ -198,7 +198,7 @@ typedef struct csadp_timing {
 	                        /* chunked fill ran out (0 in any healthy run)                        */
 	int device_io;          /* 1 = a pass starts from the raw letters in HBM and ends with the    */
 	                        /* aligned rows in HBM (nw_pack_planes / nw_expand_rows in the pass)  */
-	int words_per_lane;     /* bit-parallel path: 32-column words a lane owns (1, 2 or 4)         */
+	int words_per_lane;     /* bit-parallel path: 32-column words a lane owns (1 .. 4)           */
 	int streams;            /* bit-parallel path: fill launches kept in flight                    */
 } csadp_timing;
 

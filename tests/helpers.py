@@ -15,6 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_SO = os.path.join(ROOT, "oracle", "libcsa_oracle.so")
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libcsa_ref.so")
+REF_O3_SO = os.path.join(ROOT, "oracle", "_ref", "libcsa_ref_o3.so")     # the same reference sources at -O3 -march=znver3 (oracle/Makefile)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -25,7 +26,7 @@ class OdpStats(ctypes.Structure):
 
 
 _oracle = None
-_ref = None
+_ref = {}
 
 
 def build_oracle():
@@ -51,13 +52,17 @@ def have_ref():
     return os.path.exists(REF_SO)
 
 
-def ref_lib():
-    global _ref
-    if _ref is None:
-        lib = ctypes.CDLL(REF_SO)
+def have_ref_o3():
+    return os.path.exists(REF_O3_SO)
+
+
+def ref_lib(o3=False):
+    path = REF_O3_SO if o3 else REF_SO
+    if path not in _ref:
+        lib = ctypes.CDLL(path)
         lib.csa_ref_progressive_dp.restype = ctypes.c_int
-        _ref = lib
-    return _ref
+        _ref[path] = lib
+    return _ref[path]
 
 
 def _task_args(texts, rots, starts, ends):
@@ -97,9 +102,9 @@ def oracle_progressive(texts, rots=None, starts=None, ends=None):
     return rc, strs, stats
 
 
-def ref_progressive(texts, rots=None, starts=None, ends=None):
-    """Run the compiled reference (oracle/_ref).  Returns (consensus, strings, seconds)."""
-    lib = ref_lib()
+def ref_progressive(texts, rots=None, starts=None, ends=None, o3=False):
+    """Run the compiled reference (oracle/_ref; o3: its -O3 build).  Returns (consensus, strings, seconds)."""
+    lib = ref_lib(o3)
     n = len(texts)
     rots = rots or [0] * n
     starts = starts or [0] * n

@@ -16,7 +16,7 @@ def device():
     yield
 
 
-# words of 32 columns per lane: the engine picks 1 or 2 by the shape of the batch (layout_bits); every test below runs with
+# words of 32 columns per lane: the engine picks 1, 2 or 3 by the shape of the batch (layout_bits); every test below runs with
 # each of the three kernels
 # Batches of at most 32 one-word jobs take the traceback that walks one tile set while the next is replayed
 # (CSADP_TB_OVERLAP, default on); "1 word, replay then walk" runs the same cases through the plain one.

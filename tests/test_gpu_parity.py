@@ -476,6 +476,37 @@ def test_whole_config4_properties():
     assert total > 0
 
 
+def test_config4_unrelated_variant_64_pairs():
+    """SURVEY 8(d), config 4's second variant: 64 UNRELATED 16 kbp pairs (b an independent random sequence) -- the worst case
+    of the negative score range and of the traceback (a gap-rich path that wanders off the corner-to-corner line).  Strings
+    against the oracle for three pairs; for all 64: the size-independent properties and the score against the oracle's
+    linear-space optimum (dynamicprogramming.c:990-1029, walk :1037-1047)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = 64
+    pairs = [synth_pair(70000 + p, unrelated=True) for p in range(n)]
+    tasks = [([a, b], [ra, rb], None, None) for a, b, ra, rb in pairs]
+    pb = csa_amd.PairBatch(tasks)
+    pb.run()
+    pb.run()
+    pb.sync()
+    got = pb.fetch()
+    pb.close()
+    for (a, b, ra, rb), g in zip(pairs, got):
+        assert g["status"] == 0
+        assert len(g["aligned"][0]) == len(g["aligned"][1]) == g["consensus"]
+        assert degap(g["aligned"][0]) == rotated(a, ra) and degap(g["aligned"][1]) == rotated(b, rb)
+        assert sp_score(g["aligned"]) == g["score"]
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 2)) as ex:
+        want = list(ex.map(lambda t: oracle_pair_score_linear(t[0], t[1]), tasks))
+    assert [g["score"] for g in got] == want
+    for i in (0, 31, 63):
+        cons, strs, st = oracle_progressive(tasks[i][0], tasks[i][1])
+        assert got[i]["consensus"] == cons and got[i]["aligned"] == strs and got[i]["score"] == st.last_score
+    # the same pairs one by one through the other entry point (a one-job batch takes the latency-shaped path)
+    one = csa_amd.align_batch(tasks[:2])
+    assert [o["aligned"] for o in one] == [g["aligned"] for g in got[:2]]
+
+
 def test_whole_config5_in_one_batch():
     """Config 5: 256 pairs, lengths 1 k .. 200 k, 1.2e12 cells, as ONE device-resident
     batch -- possible because checkpoint mode keeps no direction planes (0.3 TB of them otherwise).
