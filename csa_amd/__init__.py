@@ -84,7 +84,7 @@ EXPORTS = [
     "csadp_partition_lpt", "csadp_fnv1a", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
     "csadp_build_anchor_map", "csadp_free_anchor_map", "csadp_msa", "csadp_free_rows", "csadp_write_aligned_fasta",
-    "csadp_debug_align_with_filler", "csadp_debug_pool_selftest", "csadp_debug_set_epoch",
+    "csadp_debug_align_with_filler", "csadp_debug_align_batch_with_filler", "csadp_debug_pool_selftest", "csadp_debug_set_epoch",
 ]
 
 DEBUG_FILL_FN = ctypes.CFUNCTYPE(

@@ -138,12 +138,19 @@ bool advance(Progressive &p)
 	return false;
 }
 
-/* one lock-step round: every task with a pending fill contributes one job */
-int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, FillBatch &fb, std::vector<int> &status)
+/* What the fills of one round leave for the host: per active task its walk (dynamicprogramming.c:1037-1047) */
+struct RoundTrace {
+	const uint8_t *ops = nullptr;
+	int nops = 0, remj = 0, remk = 0;
+	const int32_t *score = nullptr;          /* H[nrows][ncols] where the filler knows it */
+};
+/* the fills + walks of one round: the device (a FillBatch) in the product, the caller's filler in the CPU test seam */
+typedef std::function<int(std::vector<Progressive> &, const std::vector<int> &, std::vector<RoundTrace> &, double *ms)> RoundFills;
+
+/* the product's: tables -> one device batch -> op lists */
+int device_fills(FillBatch &fb, std::vector<Progressive> &tasks, const std::vector<int> &active, std::vector<RoundTrace> &out, double *ms)
 {
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
 	auto tick = std::chrono::steady_clock::now();
-	double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int phase = 0;
 	auto lap = [&]() {
 		const auto now = std::chrono::steady_clock::now();
@@ -170,10 +177,39 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, F
 	if ((rc = fb.run()) != CSADP_OK) return rc;
 	if ((rc = fb.download()) != CSADP_OK) return rc;
 	lap();
+	for (size_t j = 0; j < active.size(); ++j) {
+		const int32_t *sm = fb.summary((int)j);
+		out[j].ops = fb.ops((int)j);
+		out[j].nops = sm[0];
+		out[j].remj = sm[1];
+		out[j].remk = sm[2];
+		out[j].score = fb.device_scores() ? &sm[3] : nullptr;   /* where the device has scored its path, the host's own sum along the trace must agree */
+	}
+	return CSADP_OK;
+}
+
+/* one lock-step round: every task with a pending fill contributes one job */
+int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, const RoundFills &fills, std::vector<int> &status)
+{
+	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	auto tick = std::chrono::steady_clock::now();
+	double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	int phase = 0;
+	auto lap = [&]() {
+		const auto now = std::chrono::steady_clock::now();
+		ms[phase++] = std::chrono::duration<double, std::milli>(now - tick).count();
+		tick = now;
+	};
+	std::vector<RoundTrace> traces(active.size());
+	{
+		const int rc = fills(tasks, active, traces, ms);
+		if (rc != CSADP_OK) return rc;
+	}
+	phase = 3;
+	tick = std::chrono::steady_clock::now();
 	parallel_for((int)active.size(), [&](int j) {
-		const int32_t *sm = fb.summary(j);
-		/* where the device has scored its path, the host's own sum along the trace must agree */
-		const int a = tasks[active[(size_t)j]].apply_trace(fb.ops(j), sm[0], sm[1], sm[2], fb.device_scores() ? &sm[3] : nullptr, true);
+		const RoundTrace &T = traces[(size_t)j];
+		const int a = tasks[active[(size_t)j]].apply_trace(T.ops, T.nops, T.remj, T.remk, T.score, true);
 		if (a != CSADP_OK) status[active[(size_t)j]] = a;
 	});
 	/* DeleteGappedColumns of all tasks: the scoring of the candidate columns -- nearly all of its time -- as ONE flat
@@ -241,6 +277,76 @@ namespace {
 
 constexpr int kRoundGroups = 2;   /* task groups whose rounds run side by side (measured: DESIGN.md section 4) */
 
+/* N independent ProgressiveDP calls as lock-step rounds over round groups; `fills_of(g)` = group g's fills, `prepare(groups)` readies
+ * them, `enter()` runs first on every extra group's thread (the product binds its device there). */
+int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *results, int max_groups, const std::function<int(int)> &prepare,
+                       const std::function<RoundFills(int)> &fills_of, const std::function<int()> &enter)
+{
+	std::vector<Progressive> prog((size_t)ntasks);
+	std::vector<int> status((size_t)ntasks, CSADP_OK);
+	parallel_for(ntasks, [&](int t) {
+		memset(&results[t], 0, sizeof(results[t]));
+		status[(size_t)t] = prog[(size_t)t].init(tasks[t]);
+	});
+	/* Lock-step rounds: round i = step i of every task that has one.  A round is [tables -> device -> trace application,
+	 * refinement], and the device idles through the host's part.  Tasks are independent, so the list is dealt (longest
+	 * first) over up to kRoundGroups groups, each driven through its own rounds by its own host thread on its own arena
+	 * and stream: one group's host part runs under the others' device part (the pool serves one parallel region at a
+	 * time; the groups' kernels are small enough to share the chip).  One task, or CSADP_ROUND_GROUPS=1: the plain loop. */
+	auto drive = [&](const std::vector<int> &mine, const RoundFills &fills) -> int {
+		for (;;) {
+			std::vector<int> active;
+			for (int t : mine)
+				if (status[(size_t)t] == CSADP_OK && advance(prog[(size_t)t])) active.push_back(t);
+			if (active.empty()) return CSADP_OK;
+			const int rc = run_round(prog, active, fills, status);
+			if (rc != CSADP_OK) return rc;
+		}
+	};
+	std::vector<int> live;
+	for (int t = 0; t < ntasks; ++t)
+		if (status[(size_t)t] == CSADP_OK) live.push_back(t);
+	int groups = 1;
+	{
+		const char *e = getenv("CSADP_ROUND_GROUPS");
+		const int want = e && *e ? atoi(e) : kRoundGroups;
+		groups = std::max(1, std::min(std::min(want, max_groups), (int)live.size()));
+	}
+	{
+		const int prc = prepare(groups);
+		if (prc != CSADP_OK) return prc;
+	}
+	if (groups <= 1) {
+		const int rc = drive(live, fills_of(0));
+		if (rc != CSADP_OK) return rc;
+	} else {
+		std::vector<long long> cost(live.size());
+		for (size_t i = 0; i < live.size(); ++i) cost[i] = std::max(1LL, csadp_task_cost(&tasks[live[i]]));
+		std::vector<int> part(live.size());
+		long long maxload = 0;
+		int prc = csadp_partition_lpt(cost.data(), (int)live.size(), groups, part.data(), &maxload);
+		if (prc != CSADP_OK) return prc;
+		std::vector<std::vector<int>> mine((size_t)groups);
+		for (size_t i = 0; i < live.size(); ++i) mine[(size_t)part[i]].push_back(live[i]);
+		for (auto &m : mine) std::sort(m.begin(), m.end());
+		std::vector<RoundFills> fills;
+		for (int g = 0; g < groups; ++g) fills.push_back(fills_of(g));
+		std::vector<int> grc((size_t)groups, CSADP_OK);
+		std::vector<std::thread> threads;
+		for (int g = 1; g < groups; ++g)
+			threads.emplace_back([&, g] { grc[(size_t)g] = enter() == CSADP_OK ? drive(mine[(size_t)g], fills[(size_t)g]) : CSADP_ERR_HIP; });
+		grc[0] = drive(mine[0], fills[0]);
+		for (std::thread &th : threads) th.join();
+		for (int g = 0; g < groups; ++g)
+			if (grc[(size_t)g] != CSADP_OK) return grc[(size_t)g];
+	}
+	parallel_for(ntasks, [&](int t) {
+		if (status[(size_t)t] == CSADP_OK) status[(size_t)t] = prog[(size_t)t].finish(&results[t]);
+		results[t].status = status[(size_t)t];
+	});
+	return CSADP_OK;
+}
+
 /* csadp_align_batch on one engine: lock-step rounds over the engine's cached arena(s) */
 int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result *results)
 {
@@ -254,54 +360,9 @@ int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result 
 		if (rc == CSADP_OK) rc = csadp_pairs_fetch(&b, results);
 		if (rc != kNoDeviceIo) return rc;
 	}
-	std::vector<Progressive> prog((size_t)ntasks);
-	std::vector<int> status((size_t)ntasks, CSADP_OK);
-	parallel_for(ntasks, [&](int t) {
-		memset(&results[t], 0, sizeof(results[t]));
-		status[(size_t)t] = prog[(size_t)t].init(tasks[t]);
-	});
-	/* Lock-step rounds: round i = step i of every task that has one.  A round is [tables -> device -> trace application,
-	 * refinement], and the device idles through the host's part.  Tasks are independent, so the list is dealt (longest
-	 * first) over up to kRoundGroups groups, each driven through its own rounds by its own host thread on its own arena
-	 * and stream: one group's host part runs under the others' device part (the pool serves one parallel region at a
-	 * time; the groups' kernels are small enough to share the chip).  One task, or CSADP_ROUND_GROUPS=1: the plain loop. */
-	auto drive = [&](const std::vector<int> &mine, FillBatch &fb) -> int {
-		for (;;) {
-			std::vector<int> active;
-			for (int t : mine)
-				if (status[(size_t)t] == CSADP_OK && advance(prog[(size_t)t])) active.push_back(t);
-			if (active.empty()) return CSADP_OK;
-			const int rc = run_round(prog, active, fb, status);
-			if (rc != CSADP_OK) return rc;
-		}
-	};
-	std::vector<int> live;
-	for (int t = 0; t < ntasks; ++t)
-		if (status[(size_t)t] == CSADP_OK) live.push_back(t);
-	int groups = 1;
-	{
-		const char *e = getenv("CSADP_ROUND_GROUPS");
-		const int want = e && *e ? atoi(e) : kRoundGroups;
-		groups = std::max(1, std::min(std::min(want, E->main_streams()), (int)live.size()));
-	}
-	if (groups <= 1) {
-		std::lock_guard<std::mutex> lock(E->batch_mutex);
-		if (!E->cached_batch) E->cached_batch = new (std::nothrow) FillBatch(E);
-		if (!E->cached_batch) return CSADP_ERR_NOMEM;
-		E->cached_batch->set_stream_base(0);
-		const int rc = drive(live, *E->cached_batch);
-		if (rc != CSADP_OK) return rc;
-	} else {
-		std::vector<long long> cost(live.size());
-		for (size_t i = 0; i < live.size(); ++i) cost[i] = std::max(1LL, csadp_task_cost(&tasks[live[i]]));
-		std::vector<int> part(live.size());
-		long long maxload = 0;
-		int prc = csadp_partition_lpt(cost.data(), (int)live.size(), groups, part.data(), &maxload);
-		if (prc != CSADP_OK) return prc;
-		std::vector<std::vector<int>> mine((size_t)groups);
-		for (size_t i = 0; i < live.size(); ++i) mine[(size_t)part[i]].push_back(live[i]);
-		for (auto &m : mine) std::sort(m.begin(), m.end());
-		std::lock_guard<std::mutex> lock(E->batch_mutex);
+	/* one FillBatch (arena, streams) per round group: the engine's cached one and its spares */
+	std::lock_guard<std::mutex> lock(E->batch_mutex);
+	auto prepare = [&](int groups) -> int {
 		if (!E->cached_batch) E->cached_batch = new (std::nothrow) FillBatch(E);
 		if (!E->cached_batch) return CSADP_ERR_NOMEM;
 		if ((int)E->extra_batches.size() < groups - 1) E->extra_batches.resize((size_t)groups - 1, nullptr);
@@ -309,25 +370,16 @@ int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result 
 			if (!E->extra_batches[(size_t)g - 1]) E->extra_batches[(size_t)g - 1] = new (std::nothrow) FillBatch(E);
 			if (!E->extra_batches[(size_t)g - 1]) return CSADP_ERR_NOMEM;
 		}
-		std::vector<int> grc((size_t)groups, CSADP_OK);
-		std::vector<std::thread> threads;
-		for (int g = 1; g < groups; ++g)
-			threads.emplace_back([&, g] {
-				FillBatch &fb = *E->extra_batches[(size_t)g - 1];
-				fb.set_stream_base(g);
-				grc[(size_t)g] = E->bind() == CSADP_OK ? drive(mine[(size_t)g], fb) : CSADP_ERR_HIP;
-			});
-		E->cached_batch->set_stream_base(0);
-		grc[0] = drive(mine[0], *E->cached_batch);
-		for (std::thread &th : threads) th.join();
-		for (int g = 0; g < groups; ++g)
-			if (grc[(size_t)g] != CSADP_OK) return grc[(size_t)g];
-	}
-	parallel_for(ntasks, [&](int t) {
-		if (status[(size_t)t] == CSADP_OK) status[(size_t)t] = prog[(size_t)t].finish(&results[t]);
-		results[t].status = status[(size_t)t];
-	});
-	return CSADP_OK;
+		return CSADP_OK;
+	};
+	auto fills_of = [&](int g) -> RoundFills {
+		FillBatch *fb = g == 0 ? E->cached_batch : E->extra_batches[(size_t)g - 1];
+		fb->set_stream_base(g);
+		return [fb](std::vector<Progressive> &tasks_, const std::vector<int> &active, std::vector<RoundTrace> &out, double *ms) {
+			return device_fills(*fb, tasks_, active, out, ms);
+		};
+	};
+	return align_batch_rounds(tasks, ntasks, results, E->main_streams(), prepare, fills_of, [E]() { return E->bind(); });
 }
 
 }  // namespace
@@ -816,6 +868,47 @@ int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fi
 	rc = p.finish(result);
 	result->status = rc;
 	return rc;
+}
+
+/* The same for a BATCH of tasks, through the product's own round driver (align_batch_rounds: lock-step rounds, tasks dealt over
+ * round groups, one host thread per group, per-task host work on the pool) with the caller's filler in place of the device step:
+ * what the thread sanitizer needs to see of csadp_align_batch.  The filler is called from several threads at once. */
+int csadp_debug_align_batch_with_filler(const csadp_task *tasks, int ntasks, csadp_debug_fill_fn fill, void *user, csadp_result *results)
+{
+	if (!tasks || !fill || !results || ntasks < 0) return CSADP_ERR_ARG;
+	struct Scratch {
+		std::vector<std::vector<unsigned char>> ops;
+		std::vector<int32_t> score;
+	};
+	auto fills_of = [&](int) -> RoundFills {
+		std::shared_ptr<Scratch> S = std::make_shared<Scratch>();
+		return [S, fill, user](std::vector<Progressive> &prog, const std::vector<int> &active, std::vector<RoundTrace> &out, double *) -> int {
+			if (S->ops.size() < active.size()) S->ops.resize(active.size());
+			S->score.assign(active.size(), 0);
+			std::vector<int> rcs(active.size(), CSADP_OK);
+			parallel_for((int)active.size(), [&](int j) {
+				Progressive &p = prog[(size_t)active[(size_t)j]];
+				const int nrows = p.nrows(), ncols = p.ncols();
+				std::vector<unsigned char> &ops = S->ops[(size_t)j];
+				ops.assign((size_t)nrows + ncols + 64, 0);
+				std::vector<signed char> rows((size_t)nrows);
+				p.debug_rowcodes(rows.data());
+				int nops = 0, remj = nrows, remk = 0, score = -p.border_i() * nrows;
+				rcs[(size_t)j] = fill(user, nrows, ncols, p.nprev(), p.debug_sv(), rows.data(), p.debug_border_top(), p.border_i(), ops.data(), &nops, &remj,
+				                      &remk, &score);
+				S->score[(size_t)j] = score;
+				out[(size_t)j].ops = ops.data();
+				out[(size_t)j].nops = nops;
+				out[(size_t)j].remj = remj;
+				out[(size_t)j].remk = remk;
+				out[(size_t)j].score = &S->score[(size_t)j];
+			});
+			for (int rc : rcs)
+				if (rc != CSADP_OK) return rc;
+			return CSADP_OK;
+		};
+	};
+	return align_batch_rounds(tasks, ntasks, results, 8, [](int) { return CSADP_OK; }, fills_of, []() { return CSADP_OK; });
 }
 
 }  // extern "C"

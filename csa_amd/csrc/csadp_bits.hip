@@ -39,6 +39,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -191,7 +192,18 @@ __device__ __forceinline__ void chain(uint32_t (&s)[W], uint32_t &acc, uint32_t 
 constexpr int kInjWords = 8;
 enum : int { INJ_X0 = 0, INJ_X1 = 1, INJ_Z2 = 2, INJ_Z1 = 3, INJ_Z0 = 4 };
 
-enum : int { OUT_NONE = 0, OUT_TILE = 1 };
+enum : int { OUT_NONE = 0, OUT_TILE = 1, OUT_WIN = 2 };
+
+/* OUT_WIN (the windowed traceback, K2c below): a piece keeps only the words of a window of kWinWords words of 32 columns around the
+ * planned path.  A tile is [32 rows][kWinPitch cells]; row 31 - t holds step t (rows run UP the matrix, like the walk), cell
+ * gw % kWinWords holds global word gw, the odd pitch's last cell takes the words of a lane outside the window (never read). */
+constexpr int kWinWords = 8;
+constexpr int kWinPitch = kWinWords + 1;
+template <int W>
+struct WinOut {
+	uint2 *cell[W];          /* this lane's cell of word h in row 0 of the piece's tile (the pad cell for a word outside the window) */
+	bool any;                /* some word of the lane lies in the window */
+};
 
 /*
  * 32 steps.  ip: this lane's source of per-step inputs in LDS (the inject rows for a first lane, the constant
@@ -201,9 +213,10 @@ enum : int { OUT_NONE = 0, OUT_TILE = 1 };
  * [32 steps][W words][16 lanes] (+ 1 per step) of (not-diagonal, left) masks, `outm` the same in the tile of match masks (MATCHES).
  */
 template <int W, bool RAMPIN, int OUT, bool MATCHES, int PF>
-__device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K, const uint32_t *ip, uint2 *out, uint32_t *outm, int l0, int lane)
+__device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K, const uint32_t *ip, uint2 *out, uint32_t *outm, int l0, int lane,
+                                           const WinOut<W> *win = nullptr)
 {
-	constexpr bool ROWS = (OUT == OUT_TILE);
+	constexpr bool ROWS = (OUT != OUT_NONE);
 	constexpr bool ACC = (OUT == OUT_NONE);
 	constexpr int pitch = 16 * W + 1;                      /* tile row pitch in cells of W words: odd, so a diagonal walk spreads over the banks */
 	uint4 qa[PF];
@@ -228,6 +241,7 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K
 		S.x1 = x1;
 		[[maybe_unused]] const uint32_t live = RAMPIN ? ((l0 + t >= lane) ? ~0u : 0u) : ~0u;
 		uint32_t nE[W], g2[W], s2[W], G2[W], g1[W], A1[W], s1[W], G1[W], O0[W], G0[W], nH0[W];
+		[[maybe_unused]] uint32_t wnd[W], wlf[W];
 #pragma unroll
 		for (int h = 0; h < W; ++h) {
 			nH0[h] = S.nH0[h];
@@ -274,6 +288,10 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K
 				out[t * pitch + h * 16] = make_uint2(notdiag, left);
 				if (MATCHES) outm[t * pitch + h * 16] = ~nE[h];   /* match mask: the walk scores its path */
 			}
+			if (OUT == OUT_WIN) {
+				wnd[h] = C0 & nE[h];
+				wlf[h] = wnd[h] & nT0;
+			}
 			if (RAMPIN) {
 				nT0 |= ~live;
 				T1 &= live;
@@ -282,6 +300,12 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K
 			S.nH0[h] = nT0;
 			S.H1[h] = T1;
 			S.H2[h] = T2;
+		}
+		if (OUT == OUT_WIN) {
+			if (win->any) {
+#pragma unroll
+				for (int h = 0; h < W; ++h) win->cell[h][(kBitBlock - 1 - t) * kWinPitch] = make_uint2(wnd[h], wlf[h]);
+			}
 		}
 	}
 }
@@ -881,16 +905,368 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
 	}
 }
 
+/*
+ * K2c, windowed (round 4).  The same replay of 16-lane x 32-step pieces, rebuilt around three findings on real genome pairs (a gap move
+ * every 7-9 cells; unrelated letters: every 3-4): the walk was two thirds of a traceback, one D-run and ONE gap move per LDS round
+ * trip (900 cycles at three words per lane); the replay of the next pieces waited for it; and a tile held 16 lanes x W words per
+ * step of which the path crosses one or two.
+ *   - A tile keeps a WINDOW of kWinWords words (256 columns) around the planned path: 2.3 KB instead of 4-12, so two sets of 16
+ *     pieces fit the LDS for every W and the four replaying waves always work one set ahead of the walking one.
+ *   - Tile rows run up the matrix (row = 31 - step) and the sets' tiles are contiguous, so the cell one row up is kWinPitch cells
+ *     further whatever the piece, and the cell one column left is the next lower bit of the same word: ONE address per lane gives the
+ *     walk its own diagonal (cells (r - i, k - i)), the two above (U, UU: two more reads at constant offsets) and the two to the
+ *     left (L, LL: the same words shifted).  Fifteen ballots turn them into scalar masks (not-D, is-L, invalid per diagonal), and a
+ *     scalar loop follows the path through them: a D-run is a find-first-set, a gap move changes diagonal -- towards the main one
+ *     it also consumes a lane -- until the lanes, 64 ops, or the five diagonals are exhausted.  An iteration takes up to 64 ops and
+ *     any number of gap moves that stay within two diagonals of where it began.
+ * The plan (reference cell, strip, slope towards the matrix' corner) outlives a set while the path stays in its windows; a path that
+ * leaves them (a long gap run, the next strip) is planned afresh from the current cell.
+ */
+constexpr int kSetPieces = 16;                         /* pieces per tile set: four replaying waves x four DPP rows */
+constexpr int kSetRows = kSetPieces * kBitBlock;       /* tile rows per set */
+constexpr int kTbThreads = (1 + kSetPieces / 4) * kLanes;
+
+/* the lane column (64 per strip) that owns global word gw >= 0 */
+template <int W>
+__device__ __forceinline__ int lane_of_word(int gw)
+{
+	if constexpr (W == 3) return (int)((unsigned)gw / 3u);
+	else return gw >> (W == 1 ? 0 : W == 2 ? 1 : 2);
+}
+
+struct TbPlan {
+	int kref, l0, s, btop, slope;                      /* the cell the plan starts from: column, local step, strip, block; columns per local step / 1024 */
+};
+
+/* first word of piece dabs' window: the planned path crosses the middle of the piece's 32 steps in column kpred */
+__device__ __forceinline__ int plan_window(const TbPlan &P, int dabs)
+{
+	const int m = max(0, kBitBlock * dabs - kBitBlock / 2 + (P.l0 & (kBitBlock - 1)));
+	const int kpred = P.kref - 1 - ((m * P.slope) >> 10);
+	return (kpred >> 5) - kWinWords / 2;
+}
+
+/*
+ * The scalar walk of one iteration through the masks of its five diagonals (index 0, 1: two, one column left; 2: the lanes' own; 3, 4:
+ * one, two rows up).  p = lane reached, left = ops the iteration may still take (64 at most: one store), dcur = the diagonal it
+ * ends on; GAP / LM: which of the ops taken are gap moves / L.  NOTD: where a run of D ends (invalid cells included), ISL: the gap
+ * move there is L, STOP: the iteration ends there (outside the matrix or the set's windows, or the move leads to a sixth diagonal).
+ * A gap move towards diagonal 2 also passes a lane: cell (r - a - p, k - b - p) with min(a, b) > 0 is the cell one lane further on
+ * diagonal (a - 1, b - 1).
+ * One state per diagonal, written out in assembly: its three masks sit in fixed registers and a segment -- a run of D and the gap
+ * move that ends it -- is ~19 scalar instructions (find-first-set for the run, s_bitcmp1_b64 for the two tests, s_bitset1_b64 for the
+ * op masks).  In C++ the compiler either selected each mask through four compare-and-select pairs per use (75 scalar instructions
+ * per segment) or, given one labelled block per state, rebuilt the jumps between them around a dispatch variable.
+ */
+#define CSADP_WALK_STATE(D, PU, PL)                                                                                                  \
+	"st" #D "_%=:\n\t"                                                                                                               \
+	"s_lshr_b64 %[t], %[n" #D "], %[p]\n\t"                                                                                          \
+	"s_ff1_i32_b64 %[q], %[t]\n\t"                                                                                                   \
+	"s_min_u32 %[q], %[q], %[left]\n\t"                                                                                              \
+	"s_add_i32 %[p], %[p], %[q]\n\t"                                                                                                 \
+	"s_sub_i32 %[left], %[left], %[q]\n\t"                                                                                           \
+	"s_cmp_lt_i32 %[left], 1\n\t"                                                                                                    \
+	"s_cbranch_scc1 end" #D "_%=\n\t"                                                                                                \
+	"s_bitcmp1_b64 %[s" #D "], %[p]\n\t"                                                                                             \
+	"s_cbranch_scc1 end" #D "_%=\n\t"                                                                                                \
+	"s_sub_i32 %[q], 64, %[left]\n\t"                                                                                                \
+	"s_bitset1_b64 %[gap], %[q]\n\t"                                                                                                 \
+	"s_sub_i32 %[left], %[left], 1\n\t"                                                                                              \
+	"s_bitcmp1_b64 %[l" #D "], %[p]\n\t"                                                                                             \
+	"s_cbranch_scc1 left" #D "_%=\n\t" PU "s_branch end" #D "_%=\n\t"                                                                \
+	"left" #D "_%=:\n\t"                                                                                                             \
+	"s_bitset1_b64 %[lm], %[q]\n\t" PL "end" #D "_%=:\n\t"                                                                           \
+	"s_mov_b32 %[d], " #D "\n\t"                                                                                                     \
+	"s_branch out_%=\n\t"
+/* after a gap move from diagonal D to diagonal T: ADD = "s_add_i32 p, p, 1" when the move heads for diagonal 2; then on into state
+ * T unless the ops or the lanes are used up (the iteration then ends ON diagonal T) */
+#define CSADP_WALK_GO(T, ADD) ADD "s_cmp_lt_i32 %[left], 1\n\ts_cbranch_scc1 end" #T "_%=\n\ts_cmp_gt_i32 %[p], 63\n\ts_cbranch_scc1 end" #T "_%=\n\ts_branch st" #T "_%=\n\t"
+#define CSADP_WALK_INC "s_add_i32 %[p], %[p], 1\n\t"
+__device__ __forceinline__ void walk_masks(const unsigned long long (&NOTD)[5], const unsigned long long (&ISL)[5], const unsigned long long (&STOP)[5], int &p,
+                                           int &left, int &dcur, unsigned long long &GAP, unsigned long long &LM)
+{
+	unsigned long long t;
+	int q;
+	asm volatile("s_branch st2_%=\n\t"
+	             /* diagonal 0: L is in STOP[0]; diagonal 4: U is in STOP[4] */
+	             CSADP_WALK_STATE(0, CSADP_WALK_GO(1, CSADP_WALK_INC), "")
+	             CSADP_WALK_STATE(1, CSADP_WALK_GO(2, CSADP_WALK_INC), CSADP_WALK_GO(0, ""))
+	             CSADP_WALK_STATE(2, CSADP_WALK_GO(3, ""), CSADP_WALK_GO(1, ""))
+	             CSADP_WALK_STATE(3, CSADP_WALK_GO(4, ""), CSADP_WALK_GO(2, CSADP_WALK_INC))
+	             CSADP_WALK_STATE(4, "", CSADP_WALK_GO(3, CSADP_WALK_INC))
+	             "out_%=:"
+	             : [p] "+s"(p), [left] "+s"(left), [d] "=&s"(dcur), [gap] "+s"(GAP), [lm] "+s"(LM), [t] "=&s"(t), [q] "=&s"(q)
+	             : [n0] "s"(NOTD[0]), [n1] "s"(NOTD[1]), [n2] "s"(NOTD[2]), [n3] "s"(NOTD[3]), [n4] "s"(NOTD[4]), [l0] "s"(ISL[0]), [l1] "s"(ISL[1]),
+	               [l2] "s"(ISL[2]), [l3] "s"(ISL[3]), [l4] "s"(ISL[4]), [s0] "s"(STOP[0]), [s1] "s"(STOP[1]), [s2] "s"(STOP[2]), [s3] "s"(STOP[3]),
+	               [s4] "s"(STOP[4])
+	             : "scc");
+}
+#undef CSADP_WALK_STATE
+#undef CSADP_WALK_GO
+#undef CSADP_WALK_INC
+
+template <int W>
+__global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
+{
+	__shared__ __attribute__((aligned(16))) uint2 tile[2][(kSetRows + 2) * kWinPitch];   /* + 2 rows: the walk reads U, UU of its last row */
+	__shared__ __attribute__((aligned(16))) uint32_t inject[kSetPieces][kBitBlock * kInjWords];
+	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];
+	__shared__ int wtab[2][kSetPieces + 2];                /* first word of every piece's window, per set */
+	__shared__ int pos[4];
+
+	const BitJob &J = jobs[blockIdx.x];
+	uint8_t *ops = arena + J.ops;
+	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
+	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
+	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
+	const uint4 *ck = reinterpret_cast<const uint4 *>(arena + J.ckpt);
+	const uint2 *hand = reinterpret_cast<const uint2 *>(arena + J.hand);
+	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+	const int nb = J.steps_pad / kBitBlock;
+	int r = J.nrows, k = J.ncols;
+	int n = 0;
+	for (int i = threadIdx.x; i < kBitBlock * kInjWords + 4; i += blockDim.x) konst[i] = kNoCarry;
+	if (threadIdx.x < 4) wtab[threadIdx.x >> 1][kSetPieces + (threadIdx.x & 1)] = 0x40000000;
+	__syncthreads();
+
+	auto acc_of = [&](int st, int blk, int l, uint32_t (&a)[3]) {
+		a[0] = a[1] = a[2] = 0;
+		if (blk < 0 || blk >= nb) return;
+		const size_t at = (size_t)st * nb + blk;
+		a[0] = ck[(at * W) * kLanes + l].w;
+		const uint2 h = hand[at * kLanes + l];
+		a[1] = h.x;
+		a[2] = h.y;
+	};
+	auto row_mask = [&](int plane, int row) -> uint32_t {
+		if (row < 0 || row >= J.steps_pad) return 0u;
+		return 0u - ((rp[(size_t)plane * J.rowwords + (row >> 5)] >> (row & 31)) & 1u);
+	};
+
+	TbPlan plan = {0, 0, 0, 0, 1024};
+	/* piece dabs of the plan into tile x of `set`: called by the replaying waves, a piece per DPP row (x = 4 (wave - 1) + row) */
+	auto replay_piece = [&](const int dabs, const int set, const int x) {
+		const int s = plan.s;
+		const int wlo = plan_window(plan, dabs);
+		const int lane_lo = (wlo >= 0 ? lane_of_word<W>(wlo) : -((W - 1 - wlo) / W)) - kLanes * s;
+		const int f = min(max(lane_lo - 4, 0), kLanes - 16);      /* the window's lanes are lane_lo .. lane_lo + 7 at most */
+		const int b = plan.btop - dabs < 0 ? 0 : plan.btop - dabs;   /* pieces above block 0 replay block 0 and are never read */
+		const int j = lane & 15;
+		const int sl = f + j;                                  /* lane index in the strip */
+		const size_t w0 = ((size_t)s * kLanes + sl) * W;
+		if (j == 0) wtab[set][x] = wlo;
+		uint32_t B0[W], B1[W];
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			B0[h] = cp[w0 + h];
+			B1[h] = cp[J.nwords_pad + w0 + h];
+		}
+		const size_t wl = sl > 0 ? w0 - W : w0;
+		const uint32_t L0 = cp[wl], L1 = cp[J.nwords_pad + wl];
+		BitState<W> S;
+		fresh_state<W>(S);
+		if (b > 0) {
+			const size_t at = (size_t)s * nb + (b - 1);
+			uint4 ckv[W];
+#pragma unroll
+			for (int h = 0; h < W; ++h) ckv[h] = ck[(at * W + h) * kLanes + sl];
+			const uint2 hv = hand[at * kLanes + sl];
+			/* x of the step before the block: the lane worked on row 32 b - 1 - sl then (not yet live: any value) */
+			const int row = b * kBitBlock - 1 - sl;
+			const uint32_t rm0 = row_mask(0, row), rm1 = row_mask(1, row);
+#pragma unroll
+			for (int h = 0; h < W; ++h) {
+				S.nH0[h] = ckv[h].x;
+				S.H1[h] = ckv[h].y;
+				S.H2[h] = ckv[h].z;
+			}
+			S.nO2 = (ckv[0].w & 1u) ? 0u : kNoCarry;             /* what the lane put out in the last step of block b - 1 */
+			S.nO1 = (hv.x & 1u) ? 0u : kNoCarry;
+			S.nO0 = (hv.y & 1u) ? 0u : kNoCarry;
+			S.x0 = B0[0] ^ rm0;
+			S.x1 = B1[0] ^ rm1;
+		}
+		/* what enters the piece's first lane: lane j of the row prepares steps j and j + 16 */
+		uint32_t older[3], newer[3];
+		if (f > 0) {                                           /* the lane to the left, one step earlier */
+			acc_of(s, b - 1, f - 1, older);
+			acc_of(s, b, f - 1, newer);
+		} else if (s > 0) {                                    /* lane 63 of the strip to the left is 63 steps ahead */
+			acc_of(s - 1, b + 1, kLanes - 1, older);
+			acc_of(s - 1, b + 2, kLanes - 1, newer);
+		} else {
+			older[0] = older[1] = older[2] = newer[0] = newer[1] = newer[2] = 0;
+		}
+		const uint32_t bf0 = cp[((size_t)s * kLanes + f) * W], bf1 = cp[J.nwords_pad + ((size_t)s * kLanes + f) * W];
+#pragma unroll
+		for (int hh = 0; hh < 2; ++hh) {
+			const int t = j + 16 * hh;
+			const int row = b * kBitBlock + t - f;                 /* the first lane's row at step t */
+			*reinterpret_cast<uint4 *>(&inject[x][t * kInjWords]) =
+			    make_uint4(bf0 ^ row_mask(0, row), bf1 ^ row_mask(1, row), carry_bit(older[0], newer[0], t), carry_bit(older[1], newer[1], t));
+			inject[x][t * kInjWords + INJ_Z0] = carry_bit(older[2], newer[2], t);
+		}
+		LaneConst<W> K;
+		K.D0 = B0[0] ^ L0;
+		K.D1 = B1[0] ^ L1;
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			K.E0[h] = B0[0] ^ B0[h];
+			K.E1[h] = B1[0] ^ B1[h];
+		}
+		WinOut<W> win;
+		win.any = false;
+		uint2 *piece = &tile[set][x * kBitBlock * kWinPitch];
+#pragma unroll
+		for (int h = 0; h < W; ++h) {
+			const int gw = (int)w0 + h;
+			const bool in = (unsigned)(gw - wlo) < (unsigned)kWinWords;
+			win.cell[h] = piece + (in ? (gw & (kWinWords - 1)) : kWinWords);
+			win.any = win.any | in;
+		}
+		const uint32_t *ip = j == 0 ? &inject[x][0] : &konst[4];
+		const bool ramp = __any(b < 2);                        /* wave-uniform: some piece of this wave is in block 0 or 1 */
+		if (ramp) bits_block<W, true, OUT_WIN, false, 1>(S, K, ip, nullptr, nullptr, b * kBitBlock, sl, &win);
+		else bits_block<W, false, OUT_WIN, false, 1>(S, K, ip, nullptr, nullptr, b * kBitBlock, sl, &win);
+	};
+
+	int dbase = 0, cur = 0;
+	bool need_plan = true, have_next = false;
+#ifdef CSADP_TB_TIMERS
+	unsigned long long tw_work = 0, tw_wait = 0, tw_mark = __builtin_amdgcn_s_memtime();
+	int tw_rounds = 0, tw_plans = 0, tw_iters = 0;
+#define TBW_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tw_mark; tw_mark = now_; } while (0)
+#else
+#define TBW_LAP(acc) do { } while (0)
+#endif
+	while (r > 0 && k > 0) {
+		const int x = 4 * (wv - 1) + (lane >> 4);                /* the replaying waves' piece */
+		const bool planning = need_plan;                        /* a round that only replays: the first set of a new plan */
+		if (planning) {
+			const int wq = lane_column<W>(k - 1);
+			plan.s = wq >> 6;
+			plan.l0 = (r - 1) + (wq & 63);
+			plan.btop = plan.l0 / kBitBlock;
+			plan.kref = k;
+			/* columns per row towards the corner, per local step: a row up is 1 + (columns per row) / (columns per lane) steps */
+			const float cr = (float)k / (float)r;
+			plan.slope = min(max((int)(1024.0f * cr / (1.0f + cr / (float)(32 * W))), 256), 4096);
+			dbase = 0;
+			need_plan = false;
+#ifdef CSADP_TB_TIMERS
+			++tw_plans;
+#endif
+		}
+		TBW_LAP(tw_wait);
+		have_next = planning || plan.btop - (dbase + kSetPieces) >= 0;     /* some piece of the set to replay lies inside the matrix */
+		if (wv > 0) {
+			if (have_next) replay_piece(planning ? x : dbase + kSetPieces + x, planning ? cur : 1 - cur, x);
+		} else if (!planning) {
+			const uint2 *T = tile[cur];
+			const int *wt = wtab[cur];
+			const int G0 = kBitBlock * (plan.btop - dbase) + kBitBlock - 1;     /* tile row of local step l: G0 - l */
+			const int kstrip0 = plan.s * (kLanes * 32 * W);              /* first column (0-based) of the plan's strip */
+			for (;;) {
+				/* lane i looks at cell (r - i, k - i) and its neighbours one and two rows up / columns left.  Which lanes' cells lie in
+				 * the matrix and the plan's strip is a prefix of the lanes: scalar; so is which of them have one / two rows above them */
+				const int nin = min(min(r, k - kstrip0), kLanes);
+				const unsigned long long PRE0 = nin >= kLanes ? ~0ull : (1ull << max(nin, 0)) - 1ull;
+				const unsigned long long PRE1 = PRE0 & (r - 1 >= kLanes ? ~0ull : (1ull << max(r - 1, 0)) - 1ull);
+				const unsigned long long PRE2 = PRE0 & (r - 2 >= kLanes ? ~0ull : (1ull << max(r - 2, 0)) - 1ull);
+				const int kc = k - 1 - lane;
+				const int gw = max(kc, 0) >> 5;
+				const int rel = G0 - r + 1 + lane - (lane_of_word<W>(gw) & 63);
+				const unsigned long long INSET = PRE0 & __ballot((unsigned)rel < (unsigned)kSetRows);
+				const int relc = (INSET >> lane) & 1ull ? rel : 0;
+				const int at = __mul24(relc, kWinPitch) + (gw & (kWinWords - 1));
+				const uint2 c0 = T[at], c1 = T[at + kWinPitch], c2 = T[at + 2 * kWinPitch];
+				const int w0 = wt[relc >> 5];
+				const uint32_t sh = (uint32_t)kc & 31u;
+				const uint32_t t31 = (uint32_t)relc & 31u;
+				/* valid: in the piece's window; the cells above: in the same piece (the next piece's window may differ: a path that
+				 * moves up there ends the iteration and starts the next one on that cell); the cells to the left: in the same word */
+				const unsigned long long V2 = INSET & __ballot((unsigned)(gw - w0) < (unsigned)kWinWords);
+				const unsigned long long V3 = V2 & PRE1 & __ballot(t31 < 31u), V4 = V2 & PRE2 & __ballot(t31 < 30u);
+				const unsigned long long V1 = V2 & __ballot(sh >= 1u), V0 = V2 & __ballot(sh >= 2u);
+				/* the cell's bit to the sign: bit sh of a word lands in bit 31, the two columns to its left in bits 30 and 29 */
+				const uint32_t up = sh ^ 31u;
+				const int a0 = (int)(c0.x << up), b0 = (int)(c0.y << up), a1 = (int)(c1.x << up), b1 = (int)(c1.y << up), a2 = (int)(c2.x << up),
+				          b2 = (int)(c2.y << up);
+				const unsigned long long ND2 = __ballot(a0 < 0), LF2 = __ballot(b0 < 0), ND3 = __ballot(a1 < 0), LF3 = __ballot(b1 < 0), ND4 = __ballot(a2 < 0),
+				                         LF4 = __ballot(b2 < 0), ND1 = __ballot((a0 << 1) < 0), LF1 = __ballot((b0 << 1) < 0), ND0 = __ballot((a0 << 2) < 0),
+				                         LF0 = __ballot((b0 << 2) < 0);
+				/* per diagonal (0, 1: two, one column left; 2: the lanes' own; 3, 4: one, two rows up): where the run of D ends, which of
+				 * those cells say L, and where the iteration must end: outside the set's windows or the matrix, or a gap move that
+				 * leads to a sixth diagonal */
+				unsigned long long NOTD[5] = {ND0 | ~V0, ND1 | ~V1, ND2 | ~V2, ND3 | ~V3, ND4 | ~V4};
+				unsigned long long ISL[5] = {ND0 & LF0 & V0, ND1 & LF1 & V1, ND2 & LF2 & V2, ND3 & LF3 & V3, ND4 & LF4 & V4};
+				unsigned long long STOP[5] = {~V0 | ISL[0], ~V1, ~V2, ~V3, NOTD[4] & ~ISL[4]};
+				int p = 0, left = kLanes, dcur = 2;
+				unsigned long long GAP = 0, LM = 0;
+				walk_masks(NOTD, ISL, STOP, p, left, dcur, GAP, LM);
+				const int nout = kLanes - left;
+				if (lane < nout) ops[n + lane] = (uint8_t)(((GAP >> lane) & 1ull) ? (((LM >> lane) & 1ull) ? DIR_L : DIR_U) : DIR_D);
+				n += nout;
+				r -= p + (dcur > 2 ? dcur - 2 : 0);
+				k -= p + (dcur < 2 ? 2 - dcur : 0);
+#ifdef CSADP_TB_TIMERS
+				++tw_iters;
+#endif
+				if (nout == 0) break;                              /* border, or outside this set */
+			}
+			if (lane == 0) {
+				pos[0] = r;
+				pos[1] = k;
+				pos[2] = n;
+			}
+		}
+		TBW_LAP(tw_work);
+#ifdef CSADP_TB_TIMERS
+		++tw_rounds;
+#endif
+		__syncthreads();
+		if (planning) continue;                                 /* the walk starts in the next round, while the set after this one is replayed */
+		r = pos[0];
+		k = pos[1];
+		n = pos[2];
+		__syncthreads();
+		if (r > 0 && k > 0) {
+			/* does the plan continue?  The current cell must lie in a window of the set just replayed */
+			const int gw = (k - 1) >> 5;
+			const int wi = lane_of_word<W>(gw);
+			const int rel = kBitBlock * (plan.btop - dbase - kSetPieces) + kBitBlock - 1 - ((r - 1) + (wi & 63));
+			bool go = have_next && (wi >> 6) == plan.s && (unsigned)rel < (unsigned)kSetRows;
+			if (go) go = (unsigned)(gw - wtab[1 - cur][rel >> 5]) < (unsigned)kWinWords;
+			if (go) {
+				cur ^= 1;
+				dbase += kSetPieces;
+			} else {
+				need_plan = true;
+			}
+		}
+	}
+#ifdef CSADP_TB_TIMERS
+	if ((threadIdx.x == 0 || threadIdx.x == 64) && blockIdx.x == 0)
+		printf("windowed traceback timers (wave %d, cycles): rounds %d plans %d walk iterations %d  work %llu  waiting %llu  ops %d\n", wv, tw_rounds, tw_plans,
+		       tw_iters, tw_work, tw_wait, n);
+#endif
+	if (threadIdx.x == 0) {
+		summary[0] = n;
+		summary[1] = r;
+		summary[2] = k;
+		summary[3] = 0;
+	}
+}
+
 /* function attributes are per device: called by Engine::init with that device current */
 hipError_t configure_kernels() { return hipSuccess; }
 
 /* static LDS of a fill workgroup of `waves` strips / of a traceback workgroup (without match masks), for the engine's
  * choice of how much dynamic LDS a fill launch reserves on top */
 int fill_bits_lds_bytes(int waves) { return waves * (kRing * 16 + kBitBlock * kInjWords * 4 + 8) + (kBitBlock * kInjWords + 4) * 4; }
-int traceback_bits_lds_bytes(int words)
+int traceback_bits_lds_bytes(int)
 {
-	const int np = words == 1 ? kReplayPieces1 : words == 2 ? kReplayPieces2 : words == 3 ? kReplayPieces3 : kReplayPieces4;
-	return np * (kBitBlock * (16 * words + 1) * 8 + kBitBlock * kInjWords * 4) + (kBitBlock * kInjWords + 4) * 4 + 16;
+	return 2 * (kSetRows + 2) * kWinPitch * 8 + kSetPieces * kBitBlock * kInjWords * 4 + (kBitBlock * kInjWords + 4) * 4 + 2 * (kSetPieces + 2) * 4 + 16;
 }
 
 namespace {
@@ -946,6 +1322,14 @@ hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const Bit
 hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, bool overlap, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
+	if (!scores && !getenv("CSADP_TB_OLD")) {
+		if (words == 1) hipLaunchKernelGGL((nw_traceback_windows<1>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+		else if (words == 2) hipLaunchKernelGGL((nw_traceback_windows<2>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+		else if (words == 3) hipLaunchKernelGGL((nw_traceback_windows<3>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+		else if (words == 4) hipLaunchKernelGGL((nw_traceback_windows<4>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+		else return hipErrorInvalidValue;
+		return hipGetLastError();
+	}
 	if (overlap && words == 1 && !scores) {                    /* the caller leaves the compute units' LDS to these workgroups */
 		hipLaunchKernelGGL((nw_traceback_replay<1, kOverlapPieces, false, true>), dim3(njobs), dim3(kOverlapPieces * 16 + 64), 0, st, arena, jobs);
 		return hipGetLastError();

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "csadp_device.h"
 #include "csadp_kernels.h"
 
@@ -264,7 +266,7 @@ __device__ void walk_band(uint32_t *lds, int nS, int *pos, const uint32_t *__res
 
 __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs)
 {
-	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     /* kScoutStrips * 2 * kBandWords * 64 words */
+	extern __shared__ __attribute__((aligned(16))) uint32_t lds[];     /* guard + (1 + kScoutStrips * 128) columns x kScoutPitch words + 4 per strip */
 	const CellJob &J = jobs[blockIdx.z];
 	const int b = blockIdx.y;
 	if (!J.banded || b >= J.nbands - 1 || (int)blockIdx.x >= J.tb_groups) return;   /* the bottom band is entered in column ncols: walked exactly */
@@ -280,12 +282,21 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 #ifdef CSADP_TB_STATS
 	const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-	/* The scouts' window interleaves the two halves of a strip: word w of column c of strip ds sits at
-	 * [(ds * kBandWords + w) * 128 + c % 128], so a step's address is a multiply-add and an OR instead of the
-	 * half / lane arithmetic of the direction words' own layout (a third of the step's instructions). */
+	/* The scouts' window is column-major with a strip skew: word w of the band (0 .. kBandWords - 1) of window column
+	 * x = c - 128 sLo sits at [kScoutGuard + (x + 1) * kScoutPitch + 4 (x >> 7) + w].  With l' = j - jtop - 1 + (x >> 1) --
+	 * the local step plus 64 per strip -- that is (x + 1) * pitch + (l' >> 4): the step's address is a shift, an add, a shift and
+	 * a multiply-add.  Bank of start t (16 columns apart, lock-step): 16 (t & 1) + ((t & 7) >> 1) + 4 (t >> 3) + const -- the
+	 * 32 lanes of a read group on 32 banks (round 3: rows of 128 columns per strip and word, 64 lanes on 4 banks, 19.5
+	 * conflict cycles per LDS instruction; profiles/r03_pmc_summary.json).
+	 * The step has no validity tests: every tag a scout must not follow reads as 3 = "stay" -- rows at or above the band's
+	 * top (masked while staging: a lane that arrives in row jtop parks there = success), strips left of the matrix, the
+	 * slots between columns, and a guard column at x = -1 that lanes leaving the window on the left are clamped to
+	 * (parked below jtop = unknown).  Round 3's step carried five boolean masks through VCC and back: ~45 instructions,
+	 * 480 cycles; this one is 10 dependent instructions and the read. */
 	{
 		constexpr int kDepth = 8;
 		const int total = kScoutStrips * kCellCols * kBandWords * 16;     /* uint4 units of 4 lanes of one half */
+		for (int e = threadIdx.x; e < kScoutGuard + kScoutPitch; e += 256) lds[e] = ~0u;   /* guard column and the slots below column 0 */
 		for (int e0 = threadIdx.x; e0 < total; e0 += 256 * kDepth) {
 			uint4 v[kDepth];
 #pragma unroll
@@ -293,7 +304,8 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 				const int e = e0 + x * 256;
 				const int slot = e / (kBandWords * 16), u = (e / 16) % kBandWords, q = e % 16;
 				const int sB = sLo + slot / kCellCols, w = wLo + u;
-				v[x] = make_uint4(0, 0, 0, 0);
+				v[x] = make_uint4(~0u, ~0u, ~0u, ~0u);                       /* left of the matrix: stay */
+				if (e < total && sB >= 0) v[x] = make_uint4(0, 0, 0, 0);
 				if (e < total && sB >= 0 && sB < J.nstrips && w < wpitch)
 					v[x] = *reinterpret_cast<const uint4 *>(dirs + ((size_t)(sB * kCellCols + slot % kCellCols) * wpitch + w) * kLanes + 4 * q);
 			}
@@ -302,11 +314,24 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 				const int e = e0 + x * 256;
 				if (e >= total) continue;
 				const int slot = e / (kBandWords * 16), u = (e / 16) % kBandWords, q = e % 16;
-				uint32_t *dst = lds + ((slot / kCellCols) * kBandWords + u) * kCellStripCols + 8 * q + (slot % kCellCols);
-				dst[0] = v[x].x;
-				dst[2] = v[x].y;
-				dst[4] = v[x].z;
-				dst[6] = v[x].w;
+				const int strip = slot / kCellCols;
+				/* lanes 4 q .. 4 q + 3 of half h own columns 128 strip + 2 lane + h; tags of rows <= jtop: local steps
+				 * l - 16 wLo <= lane - 1, i.e. the first (lane - 16 u) tags of word u */
+				uint32_t *dst = lds + kScoutGuard + (strip * kCellStripCols + 8 * q + (slot % kCellCols) + 1) * kScoutPitch + 4 * strip + u;
+				const uint32_t vv[4] = {v[x].x, v[x].y, v[x].z, v[x].w};
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					const int cnt = min(max(4 * q + i - 16 * u, 0), 16);
+					const uint32_t stay = cnt >= 16 ? ~0u : (1u << (2 * cnt)) - 1u;
+					dst[2 * i * kScoutPitch] = vv[i] | stay;
+					if (u == kBandWords - 1) dst[2 * i * kScoutPitch + 1] = ~0u;        /* the slot behind the column's last word */
+				}
+				if (u == 0 && q == 0 && (slot % kCellCols) == 0) {                 /* the four slots the strip skew leaves below a strip's first column */
+					dst[-1] = ~0u;
+					dst[-2] = ~0u;
+					dst[-3] = ~0u;
+					dst[-4] = ~0u;
+				}
 			}
 		}
 	}
@@ -319,28 +344,30 @@ __global__ __launch_bounds__(256) void nw_tb_scout(uint8_t *__restrict__ arena, 
 	if (t >= kScoutStarts) return;                                     /* one wave walks, a start per lane */
 	const int i = i0 + t;
 	const int jtop = b * kBandRows;
-	/* j = row, c = column - 1; a lane whose walk is lost (it left the staged strips, or took more than kScoutMaxLeft L moves:
-	 * a start right of the path on its slow way to it) parks in row jtop - 1: not live, and not a valid result */
-	int j = jtop + kBandRows, c = (i < nstarts ? i * kBandStride : 0) - 1;
-	int nleft = 0;
-	const int jbase = -1 - 16 * wLo;                                 /* l - 16 wLo = j + jbase + lane of the column */
-	for (int steps = 0; steps < kScoutCap; ++steps) {
-		const bool live = (j > jtop) & (c >= 0);
-		if (!__any(live)) break;
-		const int l = j + jbase + ((c >> 1) & 63);                       /* local step relative to the window's first word */
-		const unsigned idx = (unsigned)(((c >> 7) - sLo) * kBandWords + (l >> 4));
-		const bool in = live & (idx < (unsigned)(kScoutStrips * kBandWords));   /* rows of the band: 0 <= l >> 4 < kBandWords */
-		const uint32_t word = lds[in ? (idx << 7) | (unsigned)(c & 127) : 0u];
-		const uint32_t tag = (word >> (2 * (l & 15))) & 3u;
-		nleft += tag == DIR_L;
-		const bool lost = live & (!in | (nleft > kScoutMaxLeft));
-		j -= in & (tag != DIR_L);
-		c -= in & (tag != DIR_U);
-		j = lost ? jtop - 1 : j;
+	/* j = row, x = window column = (column - 1) - 128 sLo.  A lane parks -- its tag reads 3 -- in row jtop (the band is crossed:
+	 * its result), in column 0 of the matrix, or in the guard column (it left the staged strips: unknown).  kScoutCap steps are
+	 * kBandRows rows and kScoutMaxLeft L moves: a start right of the path on its slow way to it is still below jtop then: unknown */
+	const int xoff = kCellStripCols * sLo;
+	int j = jtop + kBandRows, x = (i < nstarts ? i * kBandStride : 0) - 1 - xoff;
+	const int jb = -1 - jtop;
+	for (int steps = 0; steps < kScoutCap; steps += 16) {
+		uint32_t moved = 0;
+#pragma unroll
+		for (int u = 0; u < 16; ++u) {
+			const int xc = max(x, -1);
+			const int l = j + jb + (xc >> 1);                              /* local step relative to the band's first word, + 64 per window strip */
+			const uint32_t word = lds[kScoutGuard + kScoutPitch + __mul24(xc, kScoutPitch) + (l >> 4)];   /* 24-bit multiply-add: v_mul_lo_u32 is quarter rate */
+			const uint32_t tag = (word >> (2 * (l & 15))) & 3u;
+			j -= (int)((5u >> tag) & 1u);                                 /* U, D: a row up;  L, stay: not */
+			x -= (int)((6u >> tag) & 1u);                                 /* L, D: a column left */
+			moved |= tag ^ 3u;
+		}
 #ifdef CSADP_TB_STATS
-		++nsteps;
+		nsteps += 16;
 #endif
+		if (!__any(moved != 0)) break;
 	}
+	const int c = x + xoff;
 #ifdef CSADP_TB_STATS
 	if (t == 0 && blockIdx.x == 1 && b == J.nbands / 2 && J.nbands > 100)
 		printf("scout: staged in %.1f us, %d steps in %.1f us\n", (double)(t1 - t0) / 100.0, nsteps, (double)(__builtin_amdgcn_s_memrealtime() - t1) / 100.0);
@@ -530,7 +557,7 @@ __global__ __launch_bounds__(256) void nw_tb_gather(uint8_t *__restrict__ arena,
 
 int traceback_cells_lds_bytes(bool banded) { return kTbWinWords * 4 + (banded ? kResolveTabBytes : 0); }
 
-constexpr int kScoutLdsBytes = kScoutStrips * kCellCols * kBandWords * kLanes * 4;
+constexpr int kScoutLdsBytes = (kScoutGuard + (kScoutStrips * kCellStripCols + 1) * kScoutPitch + 4 * kScoutStrips) * 4;
 
 hipError_t configure_traceback_cells()
 {
@@ -544,13 +571,18 @@ hipError_t launch_traceback_cells(uint8_t *arena, const CellJob *jobs, int njobs
 {
 	if (njobs <= 0) return hipSuccess;
 	const bool banded = max_bands > 0;
+	/* the banded kernels take their job from the grid's y / z, which end at 65535: more jobs than that go in several launches */
+	constexpr int kGridYZ = 65535;
 	if (banded && max_bands > 1 && max_groups > 0)
-		hipLaunchKernelGGL(nw_tb_scout, dim3(max_groups, max_bands - 1, njobs), dim3(256), kScoutLdsBytes, st, arena, jobs);
+		for (int j0 = 0; j0 < njobs; j0 += kGridYZ)
+			hipLaunchKernelGGL(nw_tb_scout, dim3(max_groups, max_bands - 1, std::min(njobs - j0, kGridYZ)), dim3(256), kScoutLdsBytes, st, arena, jobs + j0);
 	hipLaunchKernelGGL(nw_tb_resolve, dim3(njobs), dim3(256), traceback_cells_lds_bytes(banded), st, arena, jobs);
-	if (banded) {
-		hipLaunchKernelGGL(nw_tb_emit, dim3(max_bands, njobs), dim3(64), 0, st, arena, jobs);
-		hipLaunchKernelGGL(nw_tb_gather, dim3((max_bands + 3) / 4, njobs), dim3(256), 0, st, arena, jobs);
-	}
+	if (banded)
+		for (int j0 = 0; j0 < njobs; j0 += kGridYZ) {
+			const int nj = std::min(njobs - j0, kGridYZ);
+			hipLaunchKernelGGL(nw_tb_emit, dim3(max_bands, nj), dim3(64), 0, st, arena, jobs + j0);
+			hipLaunchKernelGGL(nw_tb_gather, dim3((max_bands + 3) / 4, nj), dim3(256), 0, st, arena, jobs + j0);
+		}
 	return hipGetLastError();
 }
 

@@ -146,9 +146,11 @@ constexpr int kBandRows = 128;       /* rows per band (multiple of 16: a band st
 constexpr int kBandStride = 16;      /* columns between the scouts' start columns                                           */
 constexpr int kBandWords = kBandRows / 16 + 4;   /* direction words of one column that hold a band's rows, lane skew included */
 constexpr int kScoutStarts = 64;     /* start columns per scout workgroup (a lane each): 1024 columns = 8 strips            */
-constexpr int kScoutStrips = kScoutStarts * kBandStride / 128 + 3;     /* strips staged in LDS by a scout workgroup: 66 KiB */
+constexpr int kScoutStrips = kScoutStarts * kBandStride / 128 + 3;     /* strips staged in LDS by a scout workgroup: 72 KiB */
+constexpr int kScoutPitch = kBandWords | 1;   /* words per column of the scouts' window: odd, so that starts 16 columns apart read different banks */
+constexpr int kScoutGuard = 16;      /* words in front of the window's guard column (a parked lane reads up to one word below its column) */
 constexpr int kScoutMaxLeft = 128;   /* L moves after which a scout gives up (a band the path crosses so is walked exactly) */
-constexpr int kScoutCap = kBandRows + kScoutMaxLeft + 1;               /* steps a scout can take                            */
+constexpr int kScoutCap = kBandRows + kScoutMaxLeft;                   /* steps a scout can take (a multiple of 16)         */
 constexpr int kEmitStrips = 4;       /* strips staged by an emitting workgroup                                              */
 constexpr unsigned kBandUnknown = 0xffffu;
 constexpr unsigned kBandMoved = 0x8000u;      /* a scout's `moved` is below this */

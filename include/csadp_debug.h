@@ -32,6 +32,12 @@ typedef int (*csadp_debug_fill_fn)(void *user, int nrows, int ncols, int nprev, 
 CSADP_API int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_fill_fn fill, void *user,
                                   csadp_result *result);
 
+/* The same for a batch of tasks, through the round driver of csadp_align_batch itself -- lock-step rounds, the tasks dealt
+ * over round groups (CSADP_ROUND_GROUPS, default 2), one host thread per group, per-task host work on the pool -- with the
+ * caller's filler where the product runs its device batch.  `fill` is called from several threads at once. */
+CSADP_API int csadp_debug_align_batch_with_filler(const csadp_task *tasks, int ntasks, csadp_debug_fill_fn fill, void *user,
+                                        csadp_result *results);
+
 /* Runs one parallel region of the library's persistent host thread pool (the one that spreads per-task
  * host work: table packing, traceback application, result strings) over `items` work items, each adding
  * its index to an atomic; *sum receives items*(items-1)/2.  For the thread-sanitizer build: callable from

@@ -5,8 +5,9 @@
  * writer/reader, the rotation finder (suffix automata, threaded), the anchor map (index-linked list
  * surgery, threaded), the whole progressive host logic of ProgressiveDP through the test seam
  * (csadp_debug_align_with_filler: ordering, stale-border rule, traceback application, the gap-buffer
- * DeleteGappedColumns) with fills supplied by the oracle, the LPT partitioner, and the persistent host
- * thread pool hammered from several caller threads.  Every result is also checked against the oracle.
+ * DeleteGappedColumns) with fills supplied by the oracle, the round driver of csadp_align_batch (round groups on their own host
+ * threads: csadp_debug_align_batch_with_filler), the LPT partitioner, and the persistent host thread pool hammered from several
+ * caller threads.  Every result is also checked against the oracle.
  *
  *   host_sanitize <tests/golden/data/Primates.txt> <tmpdir>
  */
@@ -156,6 +157,60 @@ int main(int argc, char **argv)
 		for (int s = 0; s < n; ++s) { r[s] = (int)(rnd() % fam[s].size()); en[s] = (int)fam[s].size(); }
 		if (it % 7 == 0) st[0] = en[0] = (int)(rnd() % (fam[0].size() + 1));
 		check_task(fam, r, st, en);
+	}
+
+	/* the round driver of csadp_align_batch itself (lock-step rounds, round groups on their own host threads, per-task host work
+	 * on the pool) with the oracle's fills in place of the device step: a batch of families, large ones included so that the
+	 * speculated refinement runs, through 1, 2 and 3 groups -- equal results, equal to the oracle's */
+	{
+		const int ntasks = 9;
+		std::vector<std::vector<std::string>> fams;
+		std::vector<std::vector<int>> rots, sts, ens;
+		std::vector<std::vector<const char *>> txts;
+		std::vector<std::vector<int>> szs;
+		std::vector<csadp_task> tasks;
+		for (int t = 0; t < ntasks; ++t) {
+			const int n = 3 + (int)(rnd() % 6);
+			fams.push_back(family(n, t < 2 ? 1100 + (int)(rnd() % 200) : 30 + (int)(rnd() % 200), 0.12, t % 3 == 0 ? 0.2 : 0.05));
+			std::vector<int> r(n), st(n, 0), en(n);
+			for (int q = 0; q < n; ++q) { r[q] = (int)(rnd() % fams.back()[q].size()); en[q] = (int)fams.back()[q].size(); }
+			rots.push_back(r); sts.push_back(st); ens.push_back(en);
+		}
+		for (int t = 0; t < ntasks; ++t) {
+			const int n = (int)fams[t].size();
+			txts.emplace_back(n); szs.emplace_back(n);
+			for (int q = 0; q < n; ++q) { txts[t][q] = fams[t][q].c_str(); szs[t][q] = (int)fams[t][q].size(); }
+		}
+		for (int t = 0; t < ntasks; ++t) tasks.push_back({(int)fams[t].size(), txts[t].data(), szs[t].data(), rots[t].data(), sts[t].data(), ens[t].data()});
+		std::vector<std::vector<std::string>> first;
+		for (int groups = 1; groups <= 3; ++groups) {
+			char g[8];
+			snprintf(g, sizeof g, "%d", groups);
+			setenv("CSADP_ROUND_GROUPS", g, 1);
+			std::vector<csadp_result> res(ntasks);
+			CHECK(csadp_debug_align_batch_with_filler(tasks.data(), ntasks, oracle_fill, NULL, res.data()) == CSADP_OK);
+			for (int t = 0; t < ntasks; ++t) {
+				const int n = tasks[t].nseq;
+				CHECK(res[t].status == CSADP_OK && res[t].aligned != nullptr);
+				if (res[t].status != CSADP_OK || !res[t].aligned) continue;
+				if (groups == 1) {
+					std::vector<char *> want(n, nullptr);
+					odp_stats os;
+					const int cons = odp_progressive_dp(n, txts[t].data(), szs[t].data(), rots[t].data(), sts[t].data(), ens[t].data(), want.data(), &os);
+					CHECK(cons == res[t].consensus);
+					first.emplace_back();
+					for (int q = 0; q < n; ++q) {
+						CHECK(want[q] && strcmp(want[q], res[t].aligned[q]) == 0);
+						first.back().push_back(res[t].aligned[q]);
+						odp_free(want[q]);
+					}
+				} else {
+					for (int q = 0; q < n; ++q) CHECK(first[t][q] == res[t].aligned[q]);
+				}
+				csadp_free_result(&res[t], n);
+			}
+		}
+		unsetenv("CSADP_ROUND_GROUPS");
 	}
 
 	/* partitioner and digests */
