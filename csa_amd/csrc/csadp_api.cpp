@@ -183,7 +183,6 @@ int device_fills(FillBatch &fb, std::vector<Progressive> &tasks, const std::vect
 		out[j].nops = sm[0];
 		out[j].remj = sm[1];
 		out[j].remk = sm[2];
-		out[j].score = fb.device_scores() ? &sm[3] : nullptr;   /* where the device has scored its path, the host's own sum along the trace must agree */
 	}
 	return CSADP_OK;
 }
@@ -487,7 +486,7 @@ int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp_result *r
 	return CSADP_OK;
 }
 
-static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores);
+static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool scores_only);
 
 int csadp_pairs_create(const csadp_task *tasks, int ntasks, csadp_pairbatch **out)
 {
@@ -576,16 +575,15 @@ static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntas
 	return fb.upload_async();
 }
 
-/* device_scores: the caller only wants DP scores -- where the traceback kernel can sum its path
- * itself it does, and the host never walks the traces */
-static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool device_scores)
+/* scores_only: the caller only wants DP scores: device-I/O batches then skip the aligned rows (nw_expand_rows sums the path) */
+static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pairbatch **out, bool scores_only)
 {
 	std::unique_ptr<csadp_pairbatch> b(new (std::nothrow) csadp_pairbatch(E));
 	if (!b) return CSADP_ERR_NOMEM;
 	for (int t = 0; t < ntasks; ++t)
 		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
 	if (env_on("CSADP_BITS", true) && env_on("CSADP_DEVICE_IO", true)) {
-		const int rc = pairs_create_io(b.get(), tasks, ntasks, true, !device_scores);
+		const int rc = pairs_create_io(b.get(), tasks, ntasks, true, !scores_only);
 		if (rc == CSADP_OK) {
 			*out = b.release();
 			return CSADP_OK;
@@ -623,7 +621,6 @@ static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pa
 			unit = unit && b->tasks[t].unit_borders();
 		}
 		b->fb.allow_bits(unit);
-		b->fb.want_scores(device_scores);
 		int rc = b->fb.layout();
 		if (rc != CSADP_OK) return rc;
 		lap("layout");
@@ -735,7 +732,7 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 		parallel_for((int)b->active.size(), [&](int j) {
 			const int32_t *sm = b->fb.summary(j);
 			const size_t t = (size_t)b->active[(size_t)j];
-			const int a = b->tasks[t].apply_trace(b->fb.ops(j), sm[0], sm[1], sm[2], b->fb.device_scores() ? &sm[3] : nullptr);
+			const int a = b->tasks[t].apply_trace(b->fb.ops(j), sm[0], sm[1], sm[2]);
 			if (a != CSADP_OK) b->status[t] = a;
 		});
 	}
@@ -771,10 +768,6 @@ int csadp_score_pairs(const csadp_task *tasks, int ntasks, int *scores, int *sta
 			if (sm[4] & 1) b->status[t] = CSADP_ERR_ALPHABET;
 			else if (sm[4] != 0) b->status[t] = CSADP_ERR_HIP;
 			else scores[t] = sm[3];
-			return;
-		}
-		if (b->fb.device_scores()) {                     /* the traceback kernel has already summed its path */
-			scores[t] = sm[3];
 			return;
 		}
 		const int a = b->tasks[t].score_from_trace(b->fb.ops(j), sm[0], sm[1], sm[2], &scores[t]);

@@ -6,7 +6,7 @@
  *   nw_fill_bits<W, WAVES, WORK>   K1b: a lane owns W words of 32 columns, a wave a strip of 2048 W columns, a
  *                                  workgroup WAVES strips; WORK = false: one workgroup per matrix, WORK = true:
  *                                  a workgroup per chunk of WAVES strips of a matrix (work list)
- *   nw_traceback_replay<W, NP, SCORE>   K2c: replays the 16-lane x 32-step pieces the path crosses, walks them
+ *   nw_traceback_windows<W>        K2c: replays the 16-lane x 32-step pieces the path crosses into windowed LDS tiles, walks them
  *
  * Why it is exact.  Let u = H[r][k-1] - H[r-1][k-1] (vertical step left of the cell), w =
  * H[r-1][k] - H[r-1][k-1] (horizontal step above it), both in {-1,0,1,2}.  The reference's cell
@@ -192,7 +192,7 @@ __device__ __forceinline__ void chain(uint32_t (&s)[W], uint32_t &acc, uint32_t 
 constexpr int kInjWords = 8;
 enum : int { INJ_X0 = 0, INJ_X1 = 1, INJ_Z2 = 2, INJ_Z1 = 3, INJ_Z0 = 4 };
 
-enum : int { OUT_NONE = 0, OUT_TILE = 1, OUT_WIN = 2 };
+enum : int { OUT_NONE = 0, OUT_WIN = 2 };
 
 /* OUT_WIN (the windowed traceback, K2c below): a piece keeps only the words of a window of kWinWords words of 32 columns around the
  * planned path.  A tile is [32 rows][kWinPitch cells]; row 31 - t holds step t (rows run UP the matrix, like the walk), cell
@@ -208,17 +208,15 @@ struct WinOut {
 /*
  * 32 steps.  ip: this lane's source of per-step inputs in LDS (the inject rows for a first lane, the constant
  * rows for all others), read PF steps ahead.  RAMPIN: lanes whose row index is still negative keep an empty
- * row above.  OUT_NONE (fill): ACC is on, nothing is stored.  OUT_TILE (replay): the wave is four independent
- * pieces of 16 lanes (DPP stays inside a row), `out` = this lane's slot in step 0 of its piece's LDS tile
- * [32 steps][W words][16 lanes] (+ 1 per step) of (not-diagonal, left) masks, `outm` the same in the tile of match masks (MATCHES).
+ * row above.  OUT_NONE (fill): ACC is on, nothing is stored.  OUT_WIN (traceback replay): the wave is four independent
+ * pieces of 16 lanes (DPP stays inside a row) and every step's (not-diagonal, left) masks of the words in the piece's
+ * window go to its LDS tile (`win`).
  */
-template <int W, bool RAMPIN, int OUT, bool MATCHES, int PF>
-__device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K, const uint32_t *ip, uint2 *out, uint32_t *outm, int l0, int lane,
-                                           const WinOut<W> *win = nullptr)
+template <int W, bool RAMPIN, int OUT, int PF>
+__device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K, const uint32_t *ip, int l0, int lane, const WinOut<W> *win = nullptr)
 {
 	constexpr bool ROWS = (OUT != OUT_NONE);
 	constexpr bool ACC = (OUT == OUT_NONE);
-	constexpr int pitch = 16 * W + 1;                      /* tile row pitch in cells of W words: odd, so a diagonal walk spreads over the banks */
 	uint4 qa[PF];
 	uint32_t qb[PF];
 	asm volatile("s_nop 1");                               /* whatever the block loop moved into the state registers has landed */
@@ -282,12 +280,6 @@ __device__ __forceinline__ void bits_block(BitState<W> &S, const LaneConst<W> &K
 			uint32_t T1 = BITOP3(G0[h], a1, C0, (LA & LB) | (~LA & LC));
 			const uint32_t b0 = BITOP3(C0, G1[h], G0[h], LC & (~LA | LB));
 			uint32_t nT0 = BITOP3(b0, C1, G2[h], LA & (~LB | LC));
-			if (OUT == OUT_TILE) {
-				const uint32_t notdiag = C0 & nE[h];
-				const uint32_t left = notdiag & nT0;
-				out[t * pitch + h * 16] = make_uint2(notdiag, left);
-				if (MATCHES) outm[t * pitch + h * 16] = ~nE[h];   /* match mask: the walk scores its path */
-			}
 			if (OUT == OUT_WIN) {
 				wnd[h] = C0 & nE[h];
 				wlf[h] = wnd[h] & nT0;
@@ -431,8 +423,8 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 	} else {
 		jp = &jobs[blockIdx.x];
 	}
-	const BitJob &J = *jp;
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+	const BitJob &J = *jp;
 	const int s = chunk * WAVES + wv;                            /* this wave's strip */
 	if (threadIdx.x < WAVES) {
 		made[threadIdx.x] = 0;
@@ -550,9 +542,9 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 			*reinterpret_cast<uint4 *>(&inject[wv][t * kInjWords]) = make_uint4(b00 ^ r0, b10 ^ r1, z2, z1);
 			inject[wv][t * kInjWords + INJ_Z0] = z0;
 		}
-		if constexpr (RAMP) bits_block<W, true, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
+		if constexpr (RAMP) bits_block<W, true, OUT_NONE, PF>(S, K, ip, b * kBitBlock, lane);
 		else if constexpr (LONE && W == 1) bits_block_lone(S, K, ip);
-		else bits_block<W, false, OUT_NONE, false, PF>(S, K, ip, nullptr, nullptr, b * kBitBlock, lane);
+		else bits_block<W, false, OUT_NONE, PF>(S, K, ip, b * kBitBlock, lane);
 		save_state<W>(ck, hand, (size_t)s * nb + b, lane, S);
 		if (feeds) {
 			/* the ring slot of this block last held block b - kRing, which the consumer fetches while preparing its blocks
@@ -584,22 +576,6 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 		if (!block_of(b, std::false_type{})) return;
 }
 
-/*
- * K2c.  Traceback: no direction planes exist in HBM.  A round starts at the current cell (r, k): lane `lane0` of strip s,
- * block btop.  Going up its diagonal the path reaches block btop - d around lane lane0 - d / W, so piece d = (block
- * btop - d, the 16 lanes around the diagonal there) is replayed with the fill's own step function: lane state from the
- * checkpoint before the block, the carries entering the piece's first lane from the accumulators of the lane to its left
- * (every lane has them: a piece starts at ANY lane; round 2 kept marks for lanes 16 / 32 / 48 only, planned a round around
- * the 16-lane groups and replayed the block in which the diagonal changes group twice).  A wave replays 4 pieces at once (one
- * per DPP row); wave 0 then walks inside the NP tiles, run-batched, until the path leaves them.  Replay work: ~(nrows +
- * ncols) / 31 pieces of 16 lanes x 32 steps, 3 % of the fill's work for square matrices and W = 1.
- * LDS tiles: [32 steps][16 lanes x W words + 1] cells of (not-diagonal, left) masks: the walk's 64 lanes read cells
- * (r - i, k - i), one step-row apart; with the round-2 pitch of 16 cells = 128 bytes they hit two bank pairs (6.5 - 17
- * conflict cycles per LDS instruction, profiles/r02_pmc_summary.json), with an odd pitch 32 different ones.
- */
-constexpr int kOverlapPieces = 16;         /* a 16 kbp pair: 0.29 ms; 12 pieces (three replaying waves + the walking one, a SIMD each) 0.305;
-                                            * 16 pieces on eight replaying waves of two pieces each (two waves per SIMD) 0.34 */
-
 /* the lane column (64 per strip) of 0-based matrix column c: 32 W columns per lane; floor for negative c (left of the matrix) */
 template <int W>
 __device__ __forceinline__ int lane_column(int c)
@@ -608,305 +584,13 @@ __device__ __forceinline__ int lane_column(int c)
 	else return c >> (W == 1 ? 5 : W == 2 ? 6 : 7);
 }
 
-/* slope: columns the planned path moves left per local step, in 1/1024 (1024: the diagonal, what the plain kernel plans with;
- * the overlapped one plans along the line to the matrix' corner: a pair of 12.5 k x 16.3 k letters -- the first fill of Set3's
- * wide gap -- leaves every diagonal plan within a round) */
-template <int W>
-__device__ __forceinline__ int piece_first_lane(int k0, int l0, int s, int d, int slope = 1024)
-{
-	const int m = max(0, 32 * d - 31 + (l0 & 31));             /* steps up the planned path to the piece's block (upper bound) */
-	const int le = lane_column<W>(k0 - 1 - ((m * slope) >> 10)) - 64 * s;   /* lane of the path there; negative: left of this strip */
-	return min(max(le - 8, 0), kLanes - 16);
-}
-
-/* SCORE: also sum the move scores of the path (score-only callers skip the host walk).
- * OVERLAP (a few large matrices, the LDS of a compute unit to one workgroup): a fifth wave does nothing but walk, and while it
- * walks the NP pieces of one tile set the other four replay the NEXT NP pieces up the same predicted diagonal into a second
- * set; a round is then max(walk, loads + replay) instead of their sum.  When the path leaves the prediction (it changes
- * strip, or drifts more than 8 lanes) the walk stops as ever, the pieces are planned afresh from the current cell and their
- * replay is waited for -- what every round costs without the overlap. */
-template <int W, int NP, bool SCORE, bool OVERLAP>
-__global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_replay(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs)
-{
-	static_assert(!(OVERLAP && SCORE), "no room for two sets of match masks");
-	constexpr int pitch = 16 * W + 1;
-	constexpr int kSets = OVERLAP ? 2 : 1;
-	__shared__ __attribute__((aligned(16))) uint2 tile[kSets * NP][kBitBlock * pitch];
-	__shared__ uint32_t mtile[SCORE ? NP : 1][SCORE ? kBitBlock * pitch : 1];    /* match masks of the same cells */
-	__shared__ __attribute__((aligned(16))) uint32_t inject[NP][kBitBlock * kInjWords];
-	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];   /* 4 words off the banks of the inject rows */
-	__shared__ int pos[4];
-
-	const BitJob &J = jobs[blockIdx.x];
-	uint8_t *ops = arena + J.ops;
-	int32_t *summary = reinterpret_cast<int32_t *>(arena + J.summary);
-	const uint32_t *cp = reinterpret_cast<const uint32_t *>(arena + J.colplanes);
-	const uint32_t *rp = reinterpret_cast<const uint32_t *>(arena + J.rowplanes);
-	const uint4 *ck = reinterpret_cast<const uint4 *>(arena + J.ckpt);
-	const uint2 *hand = reinterpret_cast<const uint2 *>(arena + J.hand);
-	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-	const int nb = J.steps_pad / kBitBlock;
-	int r = J.nrows, k = J.ncols;
-	int n = 0;
-	int score = 0;                                             /* sum of the move scores along the path (:993-998 for i = 1) */
-	for (int i = threadIdx.x; i < kBitBlock * kInjWords + 4; i += blockDim.x) konst[i] = kNoCarry;
-	__syncthreads();
-
-	/* the three accumulators lane `l` of strip `st` saved after block `blk` (0 outside the matrix' blocks) */
-	auto acc_of = [&](int st, int blk, int l, uint32_t (&a)[3]) {
-		a[0] = a[1] = a[2] = 0;
-		if (blk < 0 || blk >= nb) return;
-		const size_t at = (size_t)st * nb + blk;
-		a[0] = ck[(at * W) * kLanes + l].w;
-		const uint2 h = hand[at * kLanes + l];
-		a[1] = h.x;
-		a[2] = h.y;
-	};
-	/* mask of bit `row` of a row plane (rows beyond the planes: never on a path) */
-	auto row_mask = [&](int plane, int row) -> uint32_t {
-		if (row < 0 || row >= J.steps_pad) return 0u;
-		return 0u - ((rp[(size_t)plane * J.rowwords + (row >> 5)] >> (row & 31)) & 1u);
-	};
-
-#ifdef CSADP_TB_TIMERS
-	unsigned long long tm_load = 0, tm_replay = 0, tm_walk = 0, tm_sync = 0, tm_mark = __builtin_amdgcn_s_memtime();
-	int tm_rounds = 0;
-#define TB_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tm_mark; tm_mark = now_; } while (0)
-#else
-#define TB_LAP(acc) do { } while (0)
-#endif
-	/* OVERLAP: the plan (reference cell and its block) outlives a round; dbase = first piece of tile set `cur` */
-	int kref = 0, s = 0, l0 = 0, btop = 0, dbase = 0, cur = 0;
-	int slope = 1024;
-	bool plan = true;
-	/* one piece: d = its number up the planned diagonal, into tile `slot` */
-	/* One piece in two halves: what it reads from HBM (checkpoint of its lanes, the accumulators that enter its first lane, letters
-	 * and row bits), and the 32 replay steps into a tile.  (OVERLAP requested the inputs of the NEXT round's piece before replaying
-	 * this round's at first: the 5 k cycles in front of the steps are address arithmetic on a lone wave, not the loads' trip, and the
-	 * extra registers and copies cost 4 %: dropped.) */
-	struct PieceIn {
-		int f, b;
-		uint32_t B0[W], B1[W], L0, L1;                       /* column letters of the lane's words; word 0 of the lane to the left */
-		uint4 ckv[W];
-		uint2 hv;
-		uint32_t older[3], newer[3];
-		uint32_t bf0, bf1;
-		uint32_t rmx[2], rmi[2][2];                          /* row bits: the step before the block; the first lane's rows at steps j, j + 16 */
-	};
-	auto fetch_piece = [&](const int d, PieceIn &P) {
-		const int f = piece_first_lane<W>(kref, l0, s, d, slope);     /* pieces stay in the plan's strip: one that followed the diagonal into the
-		                                                        * strip to the left would share its block number with one in this strip (the
-		                                                        * crossing falls inside a block), and two strips are 63 steps apart in time */
-		const int b = btop - d < 0 ? 0 : btop - d;             /* pieces above block 0 replay block 0 and are never read */
-		const int j = lane & 15;
-		const int sl = f + j;                                  /* lane index in the strip */
-		const size_t w0 = ((size_t)s * kLanes + sl) * W;
-		P.f = f;
-		P.b = b;
-#pragma unroll
-		for (int h = 0; h < W; ++h) {
-			P.B0[h] = cp[w0 + h];
-			P.B1[h] = cp[J.nwords_pad + w0 + h];
-		}
-		const size_t wl = sl > 0 ? w0 - W : w0;
-		P.L0 = cp[wl];
-		P.L1 = cp[J.nwords_pad + wl];
-		P.hv = make_uint2(0, 0);
-		P.rmx[0] = P.rmx[1] = 0;
-#pragma unroll
-		for (int h = 0; h < W; ++h) P.ckv[h] = make_uint4(0, 0, 0, 0);
-		if (b > 0) {
-			const size_t at = (size_t)s * nb + (b - 1);
-#pragma unroll
-			for (int h = 0; h < W; ++h) P.ckv[h] = ck[(at * W + h) * kLanes + sl];
-			P.hv = hand[at * kLanes + sl];
-			/* x of the step before the block: the lane worked on row 32 b - 1 - sl then (not yet live: any value) */
-			const int row = b * kBitBlock - 1 - sl;
-			P.rmx[0] = row_mask(0, row);
-			P.rmx[1] = row_mask(1, row);
-		}
-		/* what enters the piece's first lane: lane j of the row prepares steps j and j + 16 */
-		if (f > 0) {                                           /* the lane to the left, one step earlier */
-			acc_of(s, b - 1, f - 1, P.older);
-			acc_of(s, b, f - 1, P.newer);
-		} else if (s > 0) {                                    /* lane 63 of the strip to the left is 63 steps ahead */
-			acc_of(s - 1, b + 1, kLanes - 1, P.older);
-			acc_of(s - 1, b + 2, kLanes - 1, P.newer);
-		} else {
-			P.older[0] = P.older[1] = P.older[2] = P.newer[0] = P.newer[1] = P.newer[2] = 0;
-		}
-		P.bf0 = cp[((size_t)s * kLanes + f) * W];
-		P.bf1 = cp[J.nwords_pad + ((size_t)s * kLanes + f) * W];
-#pragma unroll
-		for (int hh = 0; hh < 2; ++hh) {
-			const int row = b * kBitBlock + (j + 16 * hh) - f;     /* the first lane's row at step t */
-			P.rmi[hh][0] = row_mask(0, row);
-			P.rmi[hh][1] = row_mask(1, row);
-		}
-	};
-	auto compute_piece = [&](const PieceIn &P, const int slot) {
-		const int j = lane & 15;
-		const int sl = P.f + j;
-		BitState<W> S;
-		fresh_state<W>(S);
-		LaneConst<W> K;
-		K.D0 = P.B0[0] ^ P.L0;
-		K.D1 = P.B1[0] ^ P.L1;
-#pragma unroll
-		for (int h = 0; h < W; ++h) {
-			K.E0[h] = P.B0[0] ^ P.B0[h];
-			K.E1[h] = P.B1[0] ^ P.B1[h];
-		}
-		if (P.b > 0) {
-#pragma unroll
-			for (int h = 0; h < W; ++h) {
-				S.nH0[h] = P.ckv[h].x;
-				S.H1[h] = P.ckv[h].y;
-				S.H2[h] = P.ckv[h].z;
-			}
-			S.nO2 = (P.ckv[0].w & 1u) ? 0u : kNoCarry;          /* what the lane put out in the last step of block b - 1 */
-			S.nO1 = (P.hv.x & 1u) ? 0u : kNoCarry;
-			S.nO0 = (P.hv.y & 1u) ? 0u : kNoCarry;
-			S.x0 = P.B0[0] ^ P.rmx[0];
-			S.x1 = P.B1[0] ^ P.rmx[1];
-		}
-#pragma unroll
-		for (int hh = 0; hh < 2; ++hh) {
-			const int t = j + 16 * hh;
-			*reinterpret_cast<uint4 *>(&inject[slot % NP][t * kInjWords]) = make_uint4(
-			    P.bf0 ^ P.rmi[hh][0], P.bf1 ^ P.rmi[hh][1], carry_bit(P.older[0], P.newer[0], t), carry_bit(P.older[1], P.newer[1], t));
-			inject[slot % NP][t * kInjWords + INJ_Z0] = carry_bit(P.older[2], P.newer[2], t);
-		}
-		const uint32_t *ip = j == 0 ? &inject[slot % NP][0] : &konst[4];
-		uint2 *out = &tile[slot][j];                           /* a step's row of a tile: [word][lane], so the 16 lanes of a store are contiguous */
-		uint32_t *outm = &mtile[SCORE ? slot : 0][SCORE ? j : 0];
-		const bool ramp = __any(P.b < 2);                      /* wave-uniform: some piece of this wave is in block 0 or 1 */
-#ifdef CSADP_TB_TIMERS
-		if (!OVERLAP) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      /* (OVERLAP: the next piece's requests stay in flight) */
-#endif
-		TB_LAP(tm_load);
-		if (ramp) bits_block<W, true, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, P.b * kBitBlock, sl);
-		else bits_block<W, false, OUT_TILE, SCORE, 1>(S, K, ip, out, outm, P.b * kBitBlock, sl);
-		TB_LAP(tm_replay);
-	};
-	while (r > 0 && k > 0) {
-		if (!OVERLAP || plan) {                                  /* plan the pieces from the current cell */
-			const int wq = lane_column<W>(k - 1);                  /* lane column of the current cell */
-			s = wq >> 6;
-			l0 = (r - 1) + (wq & 63);
-			btop = l0 / kBitBlock;
-			kref = k;
-			dbase = 0;
-			if (OVERLAP) {
-				/* columns per row towards the corner, per local step: a row up is 1 + (columns per row) / (columns per lane) steps */
-				const float cr = (float)k / (float)r;
-				slope = min(max((int)(1024.0f * cr / (1.0f + cr / (float)(32 * W))), 256), 4096);
-			}
-			if (!OVERLAP || wv > 0) {
-				const int x = 4 * (OVERLAP ? wv - 1 : wv) + (lane >> 4);
-				PieceIn P;
-				fetch_piece(x, P);
-				compute_piece(P, (OVERLAP ? cur * NP : 0) + x);
-			}
-			plan = false;
-			__syncthreads();
-			TB_LAP(tm_sync);
-		}
-		if (OVERLAP && wv > 0) {
-			/* the next NP pieces up the same diagonal, into the other set, while wave 0 walks this one */
-			const int x = 4 * (wv - 1) + (lane >> 4);
-			PieceIn P;
-			fetch_piece(dbase + NP + x, P);
-			compute_piece(P, (1 - cur) * NP + x);
-		}
-		if (wv == 0) {
-			const int k0 = kref;
-			const uint2 *tiles = &tile[OVERLAP ? cur * NP : 0][0];   /* the NP tiles are one array: ONE look-up per iteration, no nested regions */
-			[[maybe_unused]] const uint32_t *mtiles = &mtile[0][0];
-			for (;;) {
-				/* lane i looks at cell (r - i, k - i); straight-line: the validity tests are one mask, the address of an invalid
-				 * lane is 0, both masks of the cell come from one 8-byte read (the nested form read them one after the other:
-				 * two LDS round trips per iteration on a wave that has its SIMD to itself) */
-				const int ri = r - lane, ki = k - lane;
-				const int kc = ki - 1;
-				const int wi = lane_column<W>(kc);             /* floor: cells left of the matrix fail the strip test */
-				const int sl = wi & 63;
-				const int l = (ri - 1) + sl;
-				const int dabs = btop - (l >> 5);                     /* piece number up the planned diagonal */
-				const int d = dabs - dbase;                            /* its tile in this set */
-				const int rel = sl - piece_first_lane<W>(k0, l0, s, dabs, slope);
-				const bool ok = (ri > 0) & (ki > 0) & ((wi >> 6) == s) & ((unsigned)d < (unsigned)NP) & ((unsigned)rel < 16u);
-				const int at = ok ? d * (kBitBlock * pitch) + (l & 31) * pitch + (W == 3 ? (unsigned)(kc >> 5) % 3u : (unsigned)(kc >> 5) & (unsigned)(W - 1)) * 16 + rel : 0;
-				const uint2 dd = tiles[at];
-				const uint32_t sh = (uint32_t)kc & 31u;
-				const uint32_t nd = (dd.x >> sh) & 1u, lf = (dd.y >> sh) & 1u;
-				const uint32_t code = ok ? (nd ? lf : (uint32_t)DIR_D) : 3u;      /* U = 0, L = 1, D = 2; 3 = stop: border or outside the pieces */
-				bool match = false;
-				if (SCORE) match = ok && ((mtiles[SCORE ? at : 0] >> sh) & 1u) != 0;
-				/* a run of 'D' and the gap move that ends it are taken in ONE iteration, written by ONE store */
-				const unsigned long long stop = __ballot(code != DIR_D);
-				const int run = stop ? __builtin_ctzll(stop) : kLanes;
-				const uint32_t c0 = run < kLanes ? (uint32_t)__builtin_amdgcn_readlane((int)code, run) : 3u;
-				const int gap = c0 != 3u;
-				if (lane < run + gap) ops[n + lane] = (uint8_t)(lane < run ? (uint32_t)DIR_D : c0);
-				if (SCORE) {
-					const unsigned long long hits = __ballot(match) & (run == kLanes ? ~0ull : ((1ull << run) - 1));
-					score += 2 * __builtin_popcountll(hits) - run - gap;      /* +1 per match, -1 per mismatch, -1 for the gap */
-				}
-				n += run + gap;
-				r -= run + (gap & (c0 != DIR_L));
-				k -= run + (c0 == DIR_L);
-				if (run + gap == 0) break;                          /* border, or outside the replayed pieces */
-			}
-			if (lane == 0) {
-				pos[0] = r;
-				pos[1] = k;
-				pos[2] = n;
-				pos[3] = score;
-			}
-		}
-		TB_LAP(tm_walk);
-		__syncthreads();
-		r = pos[0];
-		k = pos[1];
-		n = pos[2];
-		score = pos[3];
-		__syncthreads();
-		TB_LAP(tm_sync);
-		if (OVERLAP && r > 0 && k > 0) {
-			/* did the walk end where the plan continues?  The current cell must lie in a piece of the set just replayed */
-			const int wq = lane_column<W>(k - 1), sl = wq & 63;
-			const int dabs = btop - (((r - 1) + sl) >> 5);
-			const unsigned rel = (unsigned)(sl - piece_first_lane<W>(kref, l0, s, dabs, slope));
-			if ((wq >> 6) == s && dabs >= dbase + NP && dabs < dbase + 2 * NP && rel < 16u) {
-				cur ^= 1;
-				dbase += NP;
-			} else {
-				plan = true;
-			}
-		}
-#ifdef CSADP_TB_TIMERS
-		++tm_rounds;
-#endif
-	}
-#ifdef CSADP_TB_TIMERS
-	if (OVERLAP && threadIdx.x == 64 && blockIdx.x == 0)
-		printf("traceback timers (wave 1, cycles): rounds %d  loads+inputs %llu  replay %llu  walk %llu  barriers %llu  per round %llu\n", tm_rounds, tm_load,
-		       tm_replay, tm_walk, tm_sync, (tm_load + tm_replay + tm_walk + tm_sync) / (tm_rounds ? tm_rounds : 1));
-	if (threadIdx.x == 0 && blockIdx.x == 0)
-		printf("traceback timers (wave 0, cycles): rounds %d  loads+inputs %llu  replay %llu  walk %llu  barriers %llu  per round %llu\n", tm_rounds, tm_load,
-		       tm_replay, tm_walk, tm_sync, (tm_load + tm_replay + tm_walk + tm_sync) / (tm_rounds ? tm_rounds : 1));
-#endif
-	if (threadIdx.x == 0) {
-		summary[0] = n;
-		summary[1] = r;
-		summary[2] = k;
-		summary[3] = SCORE ? score - r - k : 0;               /* + the border cell the walk stopped on: H[r][0] = -r, H[0][k] = -k */
-	}
-}
-
 /*
- * K2c, windowed (round 4).  The same replay of 16-lane x 32-step pieces, rebuilt around three findings on real genome pairs (a gap move
+ * K2c.  Traceback (dynamicprogramming.c:1037-1047): no direction planes exist in HBM.  From the current cell (r, k) -- lane `lane0` of
+ * strip s, block btop -- the path goes up through block btop - d around lane lane0 - d / W, so piece d = (block btop - d, the 16 lanes
+ * around the planned path there) is replayed with the fill's own step function: lane state from the checkpoint before the block, the
+ * carries entering the piece's first lane from the accumulators of the lane to its left (every lane has them: a piece starts at ANY
+ * lane).  A wave replays 4 pieces at once (one per DPP row) into LDS tiles of (not-diagonal, left) masks; one wave walks them.
+ * Round 4 rebuilt the kernel around three findings on real genome pairs (a gap move
  * every 7-9 cells; unrelated letters: every 3-4): the walk was two thirds of a traceback, one D-run and ONE gap move per LDS round
  * trip (900 cycles at three words per lane); the replay of the next pieces waited for it; and a tile held 16 lanes x W words per
  * step of which the path crosses one or two.
@@ -922,7 +606,10 @@ __global__ __launch_bounds__(NP * 16 + (OVERLAP ? 64 : 0)) void nw_traceback_rep
  * The plan (reference cell, strip, slope towards the matrix' corner) outlives a set while the path stays in its windows; a path that
  * leaves them (a long gap run, the next strip) is planned afresh from the current cell.
  */
-constexpr int kSetPieces = 16;                         /* pieces per tile set: four replaying waves x four DPP rows */
+#ifndef CSADP_TB_SET_PIECES
+#define CSADP_TB_SET_PIECES 16
+#endif
+constexpr int kSetPieces = CSADP_TB_SET_PIECES;        /* pieces per tile set: four replaying waves x four DPP rows */
 constexpr int kSetRows = kSetPieces * kBitBlock;       /* tile rows per set */
 constexpr int kTbThreads = (1 + kSetPieces / 4) * kLanes;
 
@@ -935,16 +622,23 @@ __device__ __forceinline__ int lane_of_word(int gw)
 }
 
 struct TbPlan {
-	int kref, l0, s, btop, slope;                      /* the cell the plan starts from: column, local step, strip, block; columns per local step / 1024 */
+	int kref, l0, s, btop, slope;                      /* reference column (1-based), local step of the first piece's top, strip, its block; columns per local step / 1024 */
+	int m0;                                            /* local steps below the reference cell the pieces begin (a plan laid across a strip boundary: slack) */
 };
 
 /* first word of piece dabs' window: the planned path crosses the middle of the piece's 32 steps in column kpred */
 __device__ __forceinline__ int plan_window(const TbPlan &P, int dabs)
 {
-	const int m = max(0, kBitBlock * dabs - kBitBlock / 2 + (P.l0 & (kBitBlock - 1)));
+	const int m = max(0, kBitBlock * dabs - kBitBlock / 2 + (P.l0 & (kBitBlock - 1)) - P.m0);
 	const int kpred = P.kref - 1 - ((m * P.slope) >> 10);
 	return (kpred >> 5) - kWinWords / 2;
 }
+
+/* a tile set: sixteen consecutive pieces (dbase .. dbase + 15) of a plan */
+struct TbSet {
+	TbPlan plan;
+	int dbase;
+};
 
 /*
  * The scalar walk of one iteration through the masks of its five diagonals (index 0, 1: two, one column left; 2: the lanes' own; 3, 4:
@@ -1029,50 +723,59 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 	if (threadIdx.x < 4) wtab[threadIdx.x >> 1][kSetPieces + (threadIdx.x & 1)] = 0x40000000;
 	__syncthreads();
 
-	auto acc_of = [&](int st, int blk, int l, uint32_t (&a)[3]) {
+	/* 32-bit indices off the job's bases: an index computed in 64 bits costs three or four instructions, and the replaying waves spend
+	 * as long on the addresses of a piece's inputs as on its 32 steps */
+	const unsigned unb = (unsigned)nb, nwp = (unsigned)J.nwords_pad, rww = (unsigned)J.rowwords;
+	auto acc_of = [&](unsigned st, int blk, unsigned l, uint32_t (&a)[3]) {
 		a[0] = a[1] = a[2] = 0;
 		if (blk < 0 || blk >= nb) return;
-		const size_t at = (size_t)st * nb + blk;
+		const unsigned at = st * unb + (unsigned)blk;
 		a[0] = ck[(at * W) * kLanes + l].w;
 		const uint2 h = hand[at * kLanes + l];
 		a[1] = h.x;
 		a[2] = h.y;
 	};
-	auto row_mask = [&](int plane, int row) -> uint32_t {
-		if (row < 0 || row >= J.steps_pad) return 0u;
-		return 0u - ((rp[(size_t)plane * J.rowwords + (row >> 5)] >> (row & 31)) & 1u);
+	auto row_mask = [&](unsigned plane, int row) -> uint32_t {
+		if ((unsigned)row >= (unsigned)J.steps_pad) return 0u;
+		return 0u - ((rp[plane * rww + ((unsigned)row >> 5)] >> (row & 31)) & 1u);
 	};
 
-	TbPlan plan = {0, 0, 0, 0, 1024};
-	/* piece dabs of the plan into tile x of `set`: called by the replaying waves, a piece per DPP row (x = 4 (wave - 1) + row) */
-	auto replay_piece = [&](const int dabs, const int set, const int x) {
-		const int s = plan.s;
+	/* the set being walked and the one being replayed (two named structs, not an array indexed by `cur`: a private array indexed by a
+	 * variable lives in vector registers, and everything derived from it -- the walk's lane masks -- would no longer count as uniform) */
+	TbSet Cs, Ns;
+	Cs.plan = Ns.plan = TbPlan{0, 0, 0, 0, 1024, 0};
+	Cs.dbase = Ns.dbase = 0;
+	/* piece x of set S into tile set `set`: called by the replaying waves, a piece per DPP row (x = 4 (wave - 1) + row) */
+	auto replay_piece = [&](const TbSet &St, const int set, const int x) {
+		const TbPlan &plan = St.plan;
+		const int dabs = St.dbase + x;
+		const unsigned s = (unsigned)plan.s;
 		const int wlo = plan_window(plan, dabs);
-		const int lane_lo = (wlo >= 0 ? lane_of_word<W>(wlo) : -((W - 1 - wlo) / W)) - kLanes * s;
+		const int lane_lo = (wlo >= 0 ? lane_of_word<W>(wlo) : -((W - 1 - wlo) / W)) - kLanes * plan.s;
 		const int f = min(max(lane_lo - 4, 0), kLanes - 16);      /* the window's lanes are lane_lo .. lane_lo + 7 at most */
 		const int b = plan.btop - dabs < 0 ? 0 : plan.btop - dabs;   /* pieces above block 0 replay block 0 and are never read */
 		const int j = lane & 15;
-		const int sl = f + j;                                  /* lane index in the strip */
-		const size_t w0 = ((size_t)s * kLanes + sl) * W;
+		const unsigned sl = (unsigned)(f + j);                   /* lane index in the strip */
+		const unsigned w0 = (s * kLanes + sl) * W;
 		if (j == 0) wtab[set][x] = wlo;
 		uint32_t B0[W], B1[W];
 #pragma unroll
 		for (int h = 0; h < W; ++h) {
 			B0[h] = cp[w0 + h];
-			B1[h] = cp[J.nwords_pad + w0 + h];
+			B1[h] = cp[nwp + w0 + h];
 		}
-		const size_t wl = sl > 0 ? w0 - W : w0;
-		const uint32_t L0 = cp[wl], L1 = cp[J.nwords_pad + wl];
+		const unsigned wl = sl > 0 ? w0 - W : w0;
+		const uint32_t L0 = cp[wl], L1 = cp[nwp + wl];
 		BitState<W> S;
 		fresh_state<W>(S);
 		if (b > 0) {
-			const size_t at = (size_t)s * nb + (b - 1);
+			const unsigned at = s * unb + (unsigned)(b - 1);
 			uint4 ckv[W];
 #pragma unroll
 			for (int h = 0; h < W; ++h) ckv[h] = ck[(at * W + h) * kLanes + sl];
 			const uint2 hv = hand[at * kLanes + sl];
 			/* x of the step before the block: the lane worked on row 32 b - 1 - sl then (not yet live: any value) */
-			const int row = b * kBitBlock - 1 - sl;
+			const int row = b * kBitBlock - 1 - (int)sl;
 			const uint32_t rm0 = row_mask(0, row), rm1 = row_mask(1, row);
 #pragma unroll
 			for (int h = 0; h < W; ++h) {
@@ -1089,15 +792,16 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 		/* what enters the piece's first lane: lane j of the row prepares steps j and j + 16 */
 		uint32_t older[3], newer[3];
 		if (f > 0) {                                           /* the lane to the left, one step earlier */
-			acc_of(s, b - 1, f - 1, older);
-			acc_of(s, b, f - 1, newer);
+			acc_of(s, b - 1, (unsigned)(f - 1), older);
+			acc_of(s, b, (unsigned)(f - 1), newer);
 		} else if (s > 0) {                                    /* lane 63 of the strip to the left is 63 steps ahead */
 			acc_of(s - 1, b + 1, kLanes - 1, older);
 			acc_of(s - 1, b + 2, kLanes - 1, newer);
 		} else {
 			older[0] = older[1] = older[2] = newer[0] = newer[1] = newer[2] = 0;
 		}
-		const uint32_t bf0 = cp[((size_t)s * kLanes + f) * W], bf1 = cp[J.nwords_pad + ((size_t)s * kLanes + f) * W];
+		const unsigned wf = (s * kLanes + (unsigned)f) * W;
+		const uint32_t bf0 = cp[wf], bf1 = cp[nwp + wf];
 #pragma unroll
 		for (int hh = 0; hh < 2; ++hh) {
 			const int t = j + 16 * hh;
@@ -1126,46 +830,83 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 		}
 		const uint32_t *ip = j == 0 ? &inject[x][0] : &konst[4];
 		const bool ramp = __any(b < 2);                        /* wave-uniform: some piece of this wave is in block 0 or 1 */
-		if (ramp) bits_block<W, true, OUT_WIN, false, 1>(S, K, ip, nullptr, nullptr, b * kBitBlock, sl, &win);
-		else bits_block<W, false, OUT_WIN, false, 1>(S, K, ip, nullptr, nullptr, b * kBitBlock, sl, &win);
+		if (ramp) bits_block<W, true, OUT_WIN, 1>(S, K, ip, b * kBitBlock, (int)sl, &win);
+		else bits_block<W, false, OUT_WIN, 1>(S, K, ip, b * kBitBlock, (int)sl, &win);
 	};
+	/* columns per local step (/ 1024) along the line from cell (r, k) to the matrix' corner: a row up is 1 + (columns per row) /
+	 * (columns per lane) local steps */
+	auto slope_to_corner = [](int rr, int kk) -> int {
+		const float cr = (float)kk / (float)max(rr, 1);
+		return min(max((int)(1024.0f * cr / (1.0f + cr / (float)(32 * W))), 256), 4096);
+	};
+	constexpr int kStripCols = kLanes * 32 * W;
+	constexpr int kEntrySlack = 4 * kBitBlock;                 /* local steps a plan laid across a strip boundary begins below the predicted crossing */
 
-	int dbase = 0, cur = 0;
+	int cur = 0;
 	bool need_plan = true, have_next = false;
 #ifdef CSADP_TB_TIMERS
-	unsigned long long tw_work = 0, tw_wait = 0, tw_mark = __builtin_amdgcn_s_memtime();
-	int tw_rounds = 0, tw_plans = 0, tw_iters = 0;
-#define TBW_LAP(acc) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - tw_mark; tw_mark = now_; } while (0)
+	/* in-kernel clocks (tools/r04/tb_timers.sh): kept in LDS, not in registers -- the walk's fifteen lane masks leave no scalar
+	 * registers to spare.  Per wave: [0] work, [1] waiting, [2] mark, [3] rounds, [4] plans, [5] walk iterations */
+	__shared__ unsigned tmr[kTbThreads / kLanes][8];
+	if (lane < 8) tmr[wv][lane] = lane == 2 ? (unsigned)__builtin_amdgcn_s_memtime() : 0u;
+#define TBW_LAP(slot) do { if (lane == 0) { const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); tmr[wv][slot] += now_ - tmr[wv][2]; tmr[wv][2] = now_; } } while (0)
+#define TBW_COUNT(slot) do { if (lane == 0) ++tmr[wv][slot]; } while (0)
 #else
-#define TBW_LAP(acc) do { } while (0)
+#define TBW_LAP(slot) do { } while (0)
+#define TBW_COUNT(slot) do { } while (0)
 #endif
 	while (r > 0 && k > 0) {
 		const int x = 4 * (wv - 1) + (lane >> 4);                /* the replaying waves' piece */
 		const bool planning = need_plan;                        /* a round that only replays: the first set of a new plan */
 		if (planning) {
+			TbPlan &P = Cs.plan;
 			const int wq = lane_column<W>(k - 1);
-			plan.s = wq >> 6;
-			plan.l0 = (r - 1) + (wq & 63);
-			plan.btop = plan.l0 / kBitBlock;
-			plan.kref = k;
-			/* columns per row towards the corner, per local step: a row up is 1 + (columns per row) / (columns per lane) steps */
-			const float cr = (float)k / (float)r;
-			plan.slope = min(max((int)(1024.0f * cr / (1.0f + cr / (float)(32 * W))), 256), 4096);
-			dbase = 0;
+			P.s = wq >> 6;
+			P.l0 = (r - 1) + (wq & 63);
+			P.btop = P.l0 / kBitBlock;
+			P.kref = k;
+			P.slope = slope_to_corner(r, k);
+			P.m0 = 0;
+			Cs.dbase = 0;
 			need_plan = false;
-#ifdef CSADP_TB_TIMERS
-			++tw_plans;
-#endif
+			TBW_COUNT(4);
+		} else {
+			/* the set to replay while this one is walked: the next sixteen pieces of the same plan -- or, when the planned line leaves
+			 * the strip inside the set being walked, a plan laid from the predicted crossing into the strip to the left (a strip
+			 * further left the local steps of a row are 63 higher: other blocks, other lanes; round 3 and the first form of this
+			 * kernel planned afresh there, one serial round per strip) */
+			const TbPlan &C = Cs.plan;
+			TbSet &N = Ns;
+			const int kstrip0 = C.s * kStripCols;
+			const int m_exit = C.m0 + (int)(((long long)max(C.kref - kstrip0, 0) << 10) / C.slope);   /* local steps below l0 at which the line is in the strip's first column */
+			const int d_exit = (m_exit + kBitBlock / 2 - (C.l0 & (kBitBlock - 1)) + kBitBlock - 1) / kBitBlock;
+			if (C.s > 0 && d_exit < Cs.dbase + kSetPieces) {
+				const int rx = max(C.l0 - m_exit + 1, 1);                      /* the row of the crossing: lane 0 of the strip works on row l + 1 */
+				N.plan.s = C.s - 1;
+				N.plan.kref = kstrip0;                                        /* the strip's last column, 1-based */
+				N.plan.l0 = (rx - 1) + (kLanes - 1) + kEntrySlack;
+				N.plan.btop = N.plan.l0 / kBitBlock;
+				N.plan.slope = slope_to_corner(rx, kstrip0);
+				N.plan.m0 = kEntrySlack;
+				N.dbase = 0;
+			} else {
+				N.plan = C;
+				N.dbase = Cs.dbase + kSetPieces;
+			}
 		}
-		TBW_LAP(tw_wait);
-		have_next = planning || plan.btop - (dbase + kSetPieces) >= 0;     /* some piece of the set to replay lies inside the matrix */
+		TBW_LAP(1);
+		const TbSet &Rs = planning ? Cs : Ns;                   /* the set the replaying waves fill this round */
+		have_next = Rs.plan.btop - Rs.dbase >= 0;               /* some piece of it lies inside the matrix */
 		if (wv > 0) {
-			if (have_next) replay_piece(planning ? x : dbase + kSetPieces + x, planning ? cur : 1 - cur, x);
+			if (have_next) replay_piece(Rs, planning ? cur : 1 - cur, x);
 		} else if (!planning) {
+			__builtin_amdgcn_s_setprio(3);                       /* the walk is a chain of dependent instructions: ahead of the fills' waves on its SIMD (config 4: +2 %) */
+			const TbPlan &plan = Cs.plan;
+			const int dbase = Cs.dbase;
 			const uint2 *T = tile[cur];
 			const int *wt = wtab[cur];
 			const int G0 = kBitBlock * (plan.btop - dbase) + kBitBlock - 1;     /* tile row of local step l: G0 - l */
-			const int kstrip0 = plan.s * (kLanes * 32 * W);              /* first column (0-based) of the plan's strip */
+			const int kstrip0 = plan.s * kStripCols;                     /* first column (0-based) of the plan's strip */
 			for (;;) {
 				/* lane i looks at cell (r - i, k - i) and its neighbours one and two rows up / columns left.  Which lanes' cells lie in
 				 * the matrix and the plan's strip is a prefix of the lanes: scalar; so is which of them have one / two rows above them */
@@ -1209,9 +950,7 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 				n += nout;
 				r -= p + (dcur > 2 ? dcur - 2 : 0);
 				k -= p + (dcur < 2 ? 2 - dcur : 0);
-#ifdef CSADP_TB_TIMERS
-				++tw_iters;
-#endif
+				TBW_COUNT(5);
 				if (nout == 0) break;                              /* border, or outside this set */
 			}
 			if (lane == 0) {
@@ -1220,10 +959,8 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 				pos[2] = n;
 			}
 		}
-		TBW_LAP(tw_work);
-#ifdef CSADP_TB_TIMERS
-		++tw_rounds;
-#endif
+		TBW_LAP(0);
+		TBW_COUNT(3);
 		__syncthreads();
 		if (planning) continue;                                 /* the walk starts in the next round, while the set after this one is replayed */
 		r = pos[0];
@@ -1231,15 +968,16 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 		n = pos[2];
 		__syncthreads();
 		if (r > 0 && k > 0) {
-			/* does the plan continue?  The current cell must lie in a window of the set just replayed */
+			/* does the walk go on in the set just replayed?  The current cell must lie in one of its windows */
+			const TbPlan &Np = Ns.plan;
 			const int gw = (k - 1) >> 5;
 			const int wi = lane_of_word<W>(gw);
-			const int rel = kBitBlock * (plan.btop - dbase - kSetPieces) + kBitBlock - 1 - ((r - 1) + (wi & 63));
-			bool go = have_next && (wi >> 6) == plan.s && (unsigned)rel < (unsigned)kSetRows;
+			const int rel = kBitBlock * (Np.btop - Ns.dbase) + kBitBlock - 1 - ((r - 1) + (wi & 63));
+			bool go = have_next && (wi >> 6) == Np.s && (unsigned)rel < (unsigned)kSetRows;
 			if (go) go = (unsigned)(gw - wtab[1 - cur][rel >> 5]) < (unsigned)kWinWords;
 			if (go) {
 				cur ^= 1;
-				dbase += kSetPieces;
+				Cs = Ns;
 			} else {
 				need_plan = true;
 			}
@@ -1247,8 +985,8 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 	}
 #ifdef CSADP_TB_TIMERS
 	if ((threadIdx.x == 0 || threadIdx.x == 64) && blockIdx.x == 0)
-		printf("windowed traceback timers (wave %d, cycles): rounds %d plans %d walk iterations %d  work %llu  waiting %llu  ops %d\n", wv, tw_rounds, tw_plans,
-		       tw_iters, tw_work, tw_wait, n);
+		printf("windowed traceback timers (wave %d, cycles): rounds %u plans %u walk iterations %u  work %u  waiting %u  ops %d\n", wv, tmr[wv][3], tmr[wv][4],
+		       tmr[wv][5], tmr[wv][0], tmr[wv][1], n);
 #endif
 	if (threadIdx.x == 0) {
 		summary[0] = n;
@@ -1319,33 +1057,14 @@ hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const Bit
 	return launch_fill_any(words, waves, true, arena, jobs, njobs, passes, waves * kLanes, work, nwork, epoch, abort_word, st);
 }
 
-hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, bool overlap, hipStream_t st)
+hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
-	if (!scores && !getenv("CSADP_TB_OLD")) {
-		if (words == 1) hipLaunchKernelGGL((nw_traceback_windows<1>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
-		else if (words == 2) hipLaunchKernelGGL((nw_traceback_windows<2>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
-		else if (words == 3) hipLaunchKernelGGL((nw_traceback_windows<3>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
-		else if (words == 4) hipLaunchKernelGGL((nw_traceback_windows<4>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
-		else return hipErrorInvalidValue;
-		return hipGetLastError();
-	}
-	if (overlap && words == 1 && !scores) {                    /* the caller leaves the compute units' LDS to these workgroups */
-		hipLaunchKernelGGL((nw_traceback_replay<1, kOverlapPieces, false, true>), dim3(njobs), dim3(kOverlapPieces * 16 + 64), 0, st, arena, jobs);
-		return hipGetLastError();
-	}
-	/* with match masks next to the direction tiles, half as many pieces of two words fit the LDS */
-#define CSADP_TB(W_, NP_, NPS_)                                                                                                        \
-	do {                                                                                                                               \
-		if (scores) hipLaunchKernelGGL((nw_traceback_replay<W_, NPS_, true, false>), dim3(njobs), dim3(NPS_ * 16), 0, st, arena, jobs);        \
-		else hipLaunchKernelGGL((nw_traceback_replay<W_, NP_, false, false>), dim3(njobs), dim3(NP_ * 16), 0, st, arena, jobs);                \
-	} while (0)
-	if (words == 1) CSADP_TB(1, kReplayPieces1, kReplayPieces1);
-	else if (words == 2) CSADP_TB(2, kReplayPieces2, 8);
-	else if (words == 3) CSADP_TB(3, kReplayPieces3, 6);
-	else if (words == 4) CSADP_TB(4, kReplayPieces4, kReplayPieces4);
+	if (words == 1) hipLaunchKernelGGL((nw_traceback_windows<1>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+	else if (words == 2) hipLaunchKernelGGL((nw_traceback_windows<2>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+	else if (words == 3) hipLaunchKernelGGL((nw_traceback_windows<3>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
+	else if (words == 4) hipLaunchKernelGGL((nw_traceback_windows<4>), dim3(njobs), dim3(kTbThreads), 0, st, arena, jobs);
 	else return hipErrorInvalidValue;
-#undef CSADP_TB
 	return hipGetLastError();
 }
 

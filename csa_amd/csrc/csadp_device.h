@@ -49,21 +49,11 @@ struct TileRef {
  * step with word-wide logic and carry-propagating additions (csadp_bits.hip: nw_fill_bits).
  * A wave owns a strip of 64 * wpl words; lane L of a strip computes row (l - L) at its local step l.
  * The fill stores no directions: after every block of 32 steps a lane saves its state and the 3 x 32
- * carries it has put out, and the traceback replays the 16-lane x 32-step pieces its path crosses.
+ * carries it has put out, and the traceback replays the 16-lane x 32-step pieces its path crosses (csadp_bits.hip, K2c).
  */
 constexpr int kBitMaxStrips = 16;    /* waves per workgroup */
 constexpr int kBitBlock = 32;        /* steps per hand-off block between strips */
 constexpr int kBitMaxWords = 4;      /* words per lane: 1, 2 or 3 chosen per batch, 4 on request (csadp_engine.cpp: layout_bits) */
-/* pieces (16 lanes x 32 steps) a traceback round replays, by words per lane (70 / 101 / 67 KB of LDS tiles).  Two words: 8 pieces
- * 44.6 TCUPS, 12 pieces 45.8-46.1, 16 pieces 23 (151 KB: no room for a fill workgroup next to it; profiles/r03_ab_*.txt) */
-#ifndef CSADP_TB_NP2
-#define CSADP_TB_NP2 12
-#endif
-#ifndef CSADP_TB_NP1
-#define CSADP_TB_NP1 16
-#endif
-constexpr int kReplayPieces1 = CSADP_TB_NP1, kReplayPieces2 = CSADP_TB_NP2, kReplayPieces3 = 8, kReplayPieces4 = 4;
-
 struct BitJob {
 	uint64_t colplanes;       /* u32 [2][nwords_pad] bit b of word w of plane p = bit p of the letter code of column 32w+b */
 	uint64_t rowplanes;       /* u32 [2][rowwords]   same for the rows (0-based), zero padded                             */

@@ -530,9 +530,7 @@ int FillBatch::layout_bits()
 	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
 	bits_maxstrips_ = 1;
 	bits_wide_ = false;
-	if (env_int("CSADP_FORCE_SCORES", 0) != 0) want_scores_ = true;   /* testing: every traceback sums its path, every fetch cross-checks it */
 	test_abort_ = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;        /* testing: read once per layout, not per launch */
-	tb_overlap_ = env_int("CSADP_TB_OVERLAP", 1) != 0;
 	bits_lds_pad_ = -1;                                             /* chosen below, once the launch shape is known */
 	/* Words of 32 columns per lane (1, 2 or 3 by default; 4 on request: CSADP_BITS_WORDS).  More words per lane amortise what a step spends on its neighbours (the three
 	 * borrow instructions, the letter chain, the accumulators: 11 of W = 1's 31 instructions, 11 of W = 2's 53) and halve the
@@ -1024,11 +1022,7 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
-	/* a few large matrices: the traceback that walks one tile set while the next is replayed (a workgroup then takes nearly all
-	 * the LDS of its compute unit: not beside chip-filling fills; a batch that is not pipelined -- mode N's first fills -- has
-	 * the chip to itself while it walks) */
-	const bool overlap = tb_overlap_ && bits_words_ == 1 && !want_scores_ && g * nj <= (pipelined_ ? 32 : E_->compute_units());
-	HIP_TRY(launch_traceback_bits(bits_words_, arena_, bj, g * nj, want_scores_, overlap, side));
+	HIP_TRY(launch_traceback_bits(bits_words_, arena_, bj, g * nj, side));
 	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
 	HIP_TRY(hipEventRecord(ev[2], side));
 	slot_used_[first] = true;

@@ -158,10 +158,8 @@ public:
 	int sync();                      /* flush, then wait for all streams */
 	int download();                  /* results of the LAST run() -> host (blocking) */
 	const uint8_t *ops(int j) const;
-	const int32_t *summary(int j) const;   /* nops, remj, remk, DP score if device_scores() else 0 */
+	const int32_t *summary(int j) const;   /* nops, remj, remk, 0 */
 	/* the traceback kernel summed the move scores of its path (checkpoint mode of the bit-parallel path) */
-	void want_scores(bool on) { want_scores_ = on; }
-	bool device_scores() const { return bits_ && want_scores_; }
 	int timing(csadp_timing *t);
 
 private:
@@ -190,7 +188,6 @@ private:
 	int bits_lds_pad_ = 0;                        /* dynamic LDS a one-workgroup-per-job fill launch reserves on top (bounds the workgroups per compute unit) */
 	bool test_abort_ = false;                     /* CSADP_TEST_FORCE_ABORT, read when the batch is laid out */
 	bool pull_uploads_ = true;                    /* CSADP_PULL_UPLOADS: profile steps' tables are read from pinned memory by a kernel */
-	bool tb_overlap_ = true;                      /* CSADP_TB_OVERLAP: few-job batches walk and replay side by side */
 	int base_stream_ = 0, last_stream_ = 0, last_first_ = 0, launch_no_ = 0;
 	bool pull_pending_ = false;                   /* a pull upload of the staging may still be running on home_stream(0) */
 	void settle_pull();
@@ -204,7 +201,7 @@ private:
 	int finish_layout();
 	std::vector<BitJob> bjobs_;
 	std::vector<BitExtra> bextra_;
-	bool bits_ = false, bits_allowed_ = false, bits_wide_ = false, want_scores_ = false;
+	bool bits_ = false, bits_allowed_ = false, bits_wide_ = false;
 	int bits_maxstrips_ = 1, bits_chunk_ = kBitMaxStrips;
 	int *h_abort_ = nullptr;
 	std::vector<FillJob> jobs_;

@@ -20,7 +20,7 @@ int fill_bits_lds_bytes(int waves);          /* static LDS of a fill workgroup *
 int traceback_bits_lds_bytes(int words);    /* ... of a traceback workgroup */
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
 /* overlap: one word per lane, no scores, few jobs and nothing else on the chip: walk and replay side by side (156 KB of LDS per workgroup) */
-hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, bool scores, bool overlap, hipStream_t st);
+hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st);
 
 /* csadp_cells.hip: any fill as a persistent cell-per-lane wavefront; work = (job, chunk) items */
 /* epoch: a value no earlier launch on this memory has used (24 bits): it tags the hand-off granules between chunks */

@@ -18,13 +18,9 @@ def device():
 
 # words of 32 columns per lane: the engine picks 1, 2 or 3 by the shape of the batch (layout_bits); every test below runs with
 # each of the three kernels
-# Batches of at most 32 one-word jobs take the traceback that walks one tile set while the next is replayed
-# (CSADP_TB_OVERLAP, default on); "1 word, replay then walk" runs the same cases through the plain one.
-@pytest.fixture(params=["1 word", "1 word, replay then walk", "2 words", "3 words", "4 words"])
+@pytest.fixture(params=["1 word", "2 words", "3 words", "4 words"])
 def bits_mode(request, monkeypatch):
     monkeypatch.setenv("CSADP_BITS_WORDS", request.param.split()[0])
-    if "then walk" in request.param:
-        monkeypatch.setenv("CSADP_TB_OVERLAP", "0")
     return request.param
 
 
@@ -192,13 +188,9 @@ def test_thousands_of_small_jobs_in_one_batch(bits_mode):
     assert got[77]["aligned"] == strs and got[77]["score"] == st.last_score
 
 
-@pytest.mark.parametrize("scores", [False, True])
-def test_chip_filling_batch_of_two_to_five_strip_jobs(bits_mode, monkeypatch, scores):
+def test_chip_filling_batch_of_two_to_five_strip_jobs(bits_mode):
     """700 pairs of 2-5 strips (at one word per lane) = ~2400 strips per launch, several waves on every SIMD; every
-    result by its properties, a sample of them (every strip count, the longest) against the oracle; with `scores` the
-    traceback also sums its path and every fetch cross-checks it."""
-    if scores:
-        monkeypatch.setenv("CSADP_FORCE_SCORES", "1")
+    result by its properties, a sample of them (every strip count, the longest) against the oracle."""
     r = rng(1109)
     base = bytes(r.choice(b"ACGT") for _ in range(20000))
     lens = (2100, 4200, 6300, 8400, 2049, 4097, 6145, 8193, 3000, 7000)
@@ -244,10 +236,9 @@ def test_extreme_aspect_ratios(bits_mode):
     _properties(tasks, got)
 
 
-def test_device_path_scores_cross_checked(monkeypatch):
-    """CSADP_FORCE_SCORES=1: every replay traceback also sums the move scores of its path and every
-    fetch compares that with the host's own sum along the trace (a mismatch fails the task)."""
-    monkeypatch.setenv("CSADP_FORCE_SCORES", "1")
+def test_gap_runs_repeats_and_unrelated_cores(bits_mode):
+    """Paths that leave the traceback's windows and diagonals: a 2500-letter overhang in front of a shared core (one
+    long gap run), shifted dinucleotide repeats (a gap move every other cell), homopolymers of two different letters."""
     r = rng(110)
     tasks = []
     for n in (40, 130, 200, 700, 2048, 2100, 5000, 9000):
@@ -264,6 +255,48 @@ def test_device_path_scores_cross_checked(monkeypatch):
     got = pb.fetch()
     pb.close()
     assert all(g["status"] == 0 for g in got)
+
+
+def test_traceback_leaves_its_windows_and_diagonals(bits_mode):
+    """The windowed traceback keeps 256 columns around a planned line per 32-step piece and follows five diagonals per
+    iteration: blocks of 1-700 inserted / deleted letters (the path leaves the windows: planned afresh), runs of three
+    and more gap moves one way (a sixth diagonal), indels every few letters in alternating directions (the path
+    oscillates between diagonals), lengths 3 : 4 (the plan's slope), and all of it across strip boundaries."""
+    r = rng(4242)
+    base = bytes(r.choice(b"ACGT") for _ in range(13000))
+
+    def edited(src, blocks):
+        out = bytearray(src)
+        for n in blocks:
+            q = r.randrange(len(out) - n - 1)
+            if r.random() < 0.5:
+                del out[q:q + n]
+            else:
+                out[q:q] = bytes(r.choice(b"ACGT") for _ in range(n))
+        return bytes(out)
+
+    def rippled(src, period, run):
+        out = bytearray()
+        for i, ch in enumerate(src):
+            ph = (i // period) % 2
+            if i % period < run and ph == 0:
+                continue                                    # `run` letters deleted ...
+            out.append(ch)
+            if i % period < run and ph == 1:
+                out.append(r.choice(b"ACGT"))               # ... then `run` inserted, one period on
+        return bytes(out)
+
+    tasks = [
+        ([base, edited(base, [1, 2, 3, 5, 40, 130, 300, 700])], None, None, None),
+        ([base[:7000], edited(base[:7000], [260, 270, 280, 512, 33])], [3000, 100], None, None),
+        ([base[:9000], base], None, None, None),                       # 9000 columns x 13000 rows
+        ([base[2000:11000], edited(base, [64, 65])], None, None, None),
+        ([base[:6000], rippled(base[:6000], 7, 1)], None, None, None),
+        ([base[:6000], rippled(base[:6000], 9, 3)], None, None, None),
+        ([base[:6000], rippled(base[:6000], 16, 5)], [17, 4000], None, None),
+        ([base[:2500], bytes(r.choice(b"ACGT") for _ in range(2600))], None, None, None),
+    ]
+    check(tasks)
 
 
 def test_chunked_fills_either_side_of_the_epoch_wrap():
