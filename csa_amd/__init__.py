@@ -84,7 +84,7 @@ EXPORTS = [
     "csadp_partition_lpt", "csadp_fnv1a", "csadp_load_fasta", "csadp_free_fasta",
     "csadp_sp_score", "csadp_write_rotated_fasta", "csadp_read_rotations", "csadp_score_pairs", "csadp_find_rotations",
     "csadp_build_anchor_map", "csadp_free_anchor_map", "csadp_msa", "csadp_free_rows", "csadp_write_aligned_fasta",
-    "csadp_debug_align_with_filler", "csadp_debug_align_batch_with_filler", "csadp_debug_pool_selftest", "csadp_debug_set_epoch",
+    "csadp_debug_align_with_filler", "csadp_debug_align_batch_with_filler", "csadp_debug_reload_config", "csadp_debug_pool_selftest", "csadp_debug_set_epoch",
 ]
 
 DEBUG_FILL_FN = ctypes.CFUNCTYPE(
@@ -137,6 +137,11 @@ def init(device=-1, tile_rows=0, verbose=0):
 
 def shutdown():
     lib().csadp_shutdown()
+
+
+def reload_config():
+    """The library reads its environment switches once per process; the test-suite flips them between calls: read them again."""
+    lib().csadp_debug_reload_config()
 
 
 def device_info():

@@ -31,6 +31,7 @@
 
 #include "csadp.h"
 #include "csadp_hostpar.h"
+#include "csadp_config.h"
 
 using csadp::host_parallel_for;
 
@@ -108,7 +109,7 @@ struct Border {
 int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Border *out)
 {
 	const int N = (int)rev.size();
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	const bool trace = csadp::config().trace_host;
 	auto tp = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) {
 		if (!trace) return;
@@ -667,7 +668,7 @@ int csadp_build_anchor_map(int nseq, const char *const *texts, const int *sizes,
 			if (collides[(size_t)i]) return CSADP_ERR_RANGE;
 	}
 
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	const bool trace = csadp::config().trace_host;
 	auto t0 = std::chrono::steady_clock::now();
 	Loop loop;
 	loop.N = nseq;

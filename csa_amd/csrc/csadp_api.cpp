@@ -21,11 +21,13 @@
 #include "csadp_debug.h"
 #include <hip/hip_runtime_api.h>
 
+#include "csadp_config.h"
 #include "csadp_engine.h"
 #include "csadp_hostpar.h"
 #include "csadp_kernels.h"
 #include "csadp_progressive.h"
 
+using csadp::config;
 using csadp::Engine;
 using csadp::FillBatch;
 using csadp::Progressive;
@@ -36,12 +38,6 @@ namespace {
  * independent across tasks: spread it over the process' persistent pool of host threads (csadp_hostpar.h),
  * at most 16 of them here: more only adds allocator contention (measured); n small -> run inline. */
 constexpr int kNoDeviceIo = 1;    /* pairs_create_io: use the host-I/O path instead (never leaves this file) */
-
-bool env_on(const char *name, bool dflt)
-{
-	const char *v = getenv(name);
-	return (v && *v) ? atoi(v) != 0 : dflt;
-}
 
 template <class F>
 void parallel_for(int n, F &&fn)
@@ -190,7 +186,7 @@ int device_fills(FillBatch &fb, std::vector<Progressive> &tasks, const std::vect
 /* one lock-step round: every task with a pending fill contributes one job */
 int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, const RoundFills &fills, std::vector<int> &status)
 {
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	const bool trace = config().trace_host;
 	auto tick = std::chrono::steady_clock::now();
 	double ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 	int phase = 0;
@@ -274,7 +270,7 @@ static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntas
 
 namespace {
 
-constexpr int kRoundGroups = 2;   /* task groups whose rounds run side by side (measured: DESIGN.md section 4) */
+/* (task groups whose rounds run side by side: Config::round_groups, default 2 -- measured: DESIGN.md section 4) */
 
 /* N independent ProgressiveDP calls as lock-step rounds over round groups; `fills_of(g)` = group g's fills, `prepare(groups)` readies
  * them, `enter()` runs first on every extra group's thread (the product binds its device there). */
@@ -289,7 +285,7 @@ int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *result
 	});
 	/* Lock-step rounds: round i = step i of every task that has one.  A round is [tables -> device -> trace application,
 	 * refinement], and the device idles through the host's part.  Tasks are independent, so the list is dealt (longest
-	 * first) over up to kRoundGroups groups, each driven through its own rounds by its own host thread on its own arena
+	 * first) over up to config().round_groups groups, each driven through its own rounds by its own host thread on its own arena
 	 * and stream: one group's host part runs under the others' device part (the pool serves one parallel region at a
 	 * time; the groups' kernels are small enough to share the chip).  One task, or CSADP_ROUND_GROUPS=1: the plain loop. */
 	auto drive = [&](const std::vector<int> &mine, const RoundFills &fills) -> int {
@@ -307,8 +303,7 @@ int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *result
 		if (status[(size_t)t] == CSADP_OK) live.push_back(t);
 	int groups = 1;
 	{
-		const char *e = getenv("CSADP_ROUND_GROUPS");
-		const int want = e && *e ? atoi(e) : kRoundGroups;
+		const int want = config().round_groups;
 		groups = std::max(1, std::min(std::min(want, max_groups), (int)live.size()));
 	}
 	{
@@ -350,7 +345,7 @@ int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *result
 int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result *results)
 {
 	/* a batch of 2-sequence tasks takes the device-I/O pair path: letters up, rows down */
-	bool all_pairs = ntasks > 0 && env_on("CSADP_BITS", true) && env_on("CSADP_DEVICE_IO", true);
+	bool all_pairs = ntasks > 0 && config().bits && config().device_io;
 	for (int t = 0; t < ntasks && all_pairs; ++t) all_pairs = tasks[t].nseq == 2;
 	if (all_pairs) {
 		csadp_pairbatch b(E);
@@ -582,7 +577,7 @@ static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pa
 	if (!b) return CSADP_ERR_NOMEM;
 	for (int t = 0; t < ntasks; ++t)
 		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
-	if (env_on("CSADP_BITS", true) && env_on("CSADP_DEVICE_IO", true)) {
+	if (config().bits && config().device_io) {
 		const int rc = pairs_create_io(b.get(), tasks, ntasks, true, !scores_only);
 		if (rc == CSADP_OK) {
 			*out = b.release();
@@ -598,7 +593,7 @@ static int pairs_create(Engine *E, const csadp_task *tasks, int ntasks, csadp_pa
 		if (tasks[t].nseq != 2) return CSADP_ERR_ARG;
 	std::vector<char> pending((size_t)ntasks, 0);
 	csadp_pairbatch *bp = b.get();
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	const bool trace = config().trace_host;
 	auto tick = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) {
 		if (!trace) return;
@@ -671,7 +666,7 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 {
 	if (!b || !results) return CSADP_ERR_ARG;
 	if (!b->ran || b->fetched) return CSADP_ERR_STATE;
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	const bool trace = config().trace_host;
 	auto tick = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) {
 		if (!trace) return;
@@ -722,7 +717,9 @@ int csadp_pairs_fetch(csadp_pairbatch *b, csadp_result *results)
 			R.status = st;
 		});
 		lap("result strings");
-		b->fetched = true;
+		/* a device-I/O batch keeps nothing on the host that a fetch uses up: it may run and be fetched again (tasks without a
+		 * matrix are finished by the host logic, once) */
+		b->fetched = b->active.size() != b->tasks.size();
 		return CSADP_OK;
 	}
 	if (!b->active.empty()) {

@@ -1,6 +1,7 @@
 /*
  * csadp_engine.cpp -- device runtime of libcsadp (see csadp_engine.h).
  */
+#include "csadp_config.h"
 #include "csadp_engine.h"
 
 #include <hip/hip_runtime.h>
@@ -17,13 +18,6 @@ namespace csadp {
 namespace {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-int env_int(const char *name, int dflt)
-{
-	const char *v = getenv(name);
-	if (!v || !*v) return dflt;
-	return atoi(v);
-}
 
 #define HIP_TRY(expr)                                                                         \
 	do {                                                                                      \
@@ -49,7 +43,7 @@ Engine *Engine::open(int device, const csadp_config *cfg, int *rc)
 	std::lock_guard<std::mutex> lock(g_registry_mutex);
 	/* An engine runs two fill streams, their side streams and a copy stream; the HIP runtime multiplexes all streams of a
 	 * process onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run in order -- a fill
-	 * behind somebody else's traceback (rocprofv3 trace of tools/stream_probe2.py).  Ask for 8 unless the caller has
+	 * behind somebody else's traceback (rocprofv3 trace of tools/history/stream_probe2.py).  Ask for 8 unless the caller has
 	 * chosen: ONCE per process, under the registry lock, in front of the library's first HIP call -- later calls would
 	 * change nothing (the runtime reads it when it initialises) and would write the environment next to other threads'
 	 * getenv.  Without effect when the process has initialised HIP before (then the caller sets it, as bench.py does;
@@ -68,7 +62,7 @@ Engine *Engine::open(int device, const csadp_config *cfg, int *rc)
 	if (device < 0 || device >= kMaxDevices) { *rc = CSADP_ERR_ARG; return nullptr; }
 	if (device >= count) {
 		/* several ranks on one GPU give per-GPU numbers that are not per-GPU: only on request (rehearsals) */
-		if (env_int("CSADP_SHARE_DEVICE", 0) == 0) {
+		if (!config().share_device) {
 			fprintf(stderr, "csadp: HIP device %d requested, %d visible (CSADP_SHARE_DEVICE=1 maps ranks onto the visible ones)\n", device, count);
 			*rc = CSADP_ERR_NO_DEVICE;
 			return nullptr;
@@ -93,7 +87,7 @@ Engine *Engine::primary(const csadp_config *cfg, int *rc)
 		}
 	}
 	int dev = cfg ? cfg->device : -1;
-	if (dev < 0) dev = env_int("LOCAL_RANK", 0);
+	if (dev < 0) dev = config().local_rank;
 	return open(dev, cfg, rc);
 }
 
@@ -142,7 +136,7 @@ int Engine::init(int dev, const csadp_config *cfg)
 	device_ = dev;
 	snprintf(name_, sizeof(name_), "%s (%s)", prop.name, prop.gcnArchName);
 	cus_ = prop.multiProcessorCount;
-	slots_ = env_int("CSADP_SLOTS", 4);
+	slots_ = config().slots;
 	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
 	nstreams_ = 2 * main_streams();
 	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
@@ -349,7 +343,7 @@ int FillBatch::layout()
 	wide_ = false;
 	bits_ = false;
 	cells_mode_ = false;
-	if (bits_allowed_ && nj >= 1 && env_int("CSADP_BITS", 1) != 0) {
+	if (bits_allowed_ && nj >= 1 && config().bits) {
 		bits_ = true;
 		for (const FillJob &J : jobs_)
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) bits_ = false;
@@ -373,10 +367,11 @@ int FillBatch::layout_cells()
 	Engine &E = *E_;
 	const int nj = (int)jobs_.size();
 	cells_mode_ = true;
-	const int band_min = env_int("CSADP_TB_BAND_MIN", 512);       /* rows; 0x7fffffff: never */
-	pull_uploads_ = env_int("CSADP_PULL_UPLOADS", 1) != 0;
-	const bool band_forced = getenv("CSADP_TB_BAND_MIN") != nullptr;
-	const int tb_corridor = env_int("CSADP_TB_CORRIDOR", 3);      /* groups of 1024 start columns scouted per band */
+	const Config &cfg = config();
+	const int band_min = cfg.tb_band_min;                         /* rows; 0x7fffffff: never */
+	pull_uploads_ = cfg.pull_uploads;
+	const bool band_forced = cfg.tb_band_forced;
+	const int tb_corridor = cfg.tb_corridor;                      /* groups of 1024 start columns scouted per band */
 	tb_max_bands_ = tb_max_groups_ = 0;
 	cjobs_.assign((size_t)nj, CellJob());
 	tiles_.clear();
@@ -530,7 +525,8 @@ int FillBatch::layout_bits()
 	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
 	bits_maxstrips_ = 1;
 	bits_wide_ = false;
-	test_abort_ = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;        /* testing: read once per layout, not per launch */
+	const Config &cfg = config();
+	test_abort_ = cfg.test_force_abort;
 	bits_lds_pad_ = -1;                                             /* chosen below, once the launch shape is known */
 	/* Words of 32 columns per lane (1, 2 or 3 by default; 4 on request: CSADP_BITS_WORDS).  More words per lane amortise what a step spends on its neighbours (the three
 	 * borrow instructions, the letter chain, the accumulators: 11 of W = 1's 31 instructions, 11 of W = 2's 53) and halve the
@@ -563,7 +559,7 @@ int FillBatch::layout_bits()
 		long long best = cost[1] * 100 / 93;
 		if (ok2 && cost[2] <= best) { w = 2; best = cost[2]; }
 		if (ok3 && cost[3] < best) { w = 3; best = cost[3]; }
-		w = env_int("CSADP_BITS_WORDS", w);
+		if (cfg.bits_words >= 0) w = cfg.bits_words;
 		bits_words_ = (w >= 2 && w <= 4) ? w : 1;
 	}
 	const int wpl = bits_words_;
@@ -600,11 +596,12 @@ int FillBatch::layout_bits()
 	if (pipelined_) {
 		/* workgroups of at most three strips (real mitochondrial genomes at three words per lane: 16.3-17.7 k columns) leave a
 		 * SIMD of their compute unit idle and a pass is few waves (66 pairs: 198): four launches in flight, and no LDS
-		 * reservation below, so that a compute unit takes three or four of them (profiles/r04_sweep_real.txt, 48 steps:
-		 * 66 Mammals pairs 24.6 -> 29.6 TCUPS, 120 Primates pairs 31.2 -> 33.7) */
+		 * reservation below, so that a compute unit takes three or four of them (profiles/r04_sweep_real.txt, 48 steps, with
+		 * round 3's traceback: 66 Mammals pairs 24.6 -> 29.6 TCUPS, 120 Primates pairs 31.2 -> 33.7; with the windowed traceback
+		 * 32-33 and 36-38 in every shape of four launches; synthetic pairs of the same shape: profiles/r04_shape_probe.txt) */
 		const bool small_wgs = bits_maxstrips_ <= 3;
 		const int dflt_streams = small_wgs ? 4 : 2;
-		/* passes per launch: one workgroup per compute unit (tools/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
+		/* passes per launch: one workgroup per compute unit (tools/history/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
 		 * per lane 2 streams x 2 passes = two waves per SIMD runs 44 TCUPS, 4 x 2 39-43, 2 x 4 37-40: more workgroups than compute
 		 * units per launch are not spread evenly over them) */
 		/* ... so a launch of workgroups of four strips holds as many passes as give every compute unit at most ONE of them
@@ -614,8 +611,8 @@ int FillBatch::layout_bits()
 		const int want = std::max(E.compute_units(), 1);
 		if (bits_maxstrips_ <= 4) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
 		else bits_group_ = std::max(1, std::min((2 * want + nj - 1) / nj, 4));
-		bits_group_ = std::max(1, std::min(env_int("CSADP_BITS_GROUP", bits_group_), 8));
-		bits_streams_ = std::max(1, std::min(env_int("CSADP_BITS_STREAMS", dflt_streams), E.main_streams()));
+		bits_group_ = std::max(1, std::min(cfg.bits_group >= 0 ? cfg.bits_group : bits_group_, 8));
+		bits_streams_ = std::max(1, std::min(cfg.bits_streams >= 0 ? cfg.bits_streams : dflt_streams, E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
 		 * stream while the next fill of the stream already works on the other range */
 		bits_streams_ = std::max(1, std::min(bits_streams_, Engine::kMaxSlots / (2 * bits_group_)));
@@ -633,7 +630,7 @@ int FillBatch::layout_bits()
 		const long long simds = 4LL * std::max(E.compute_units(), 1);
 		if (launch_strips <= simds) bits_chunk_ = 4;
 		else if (launch_strips <= 2 * simds) bits_chunk_ = 8;
-		const int forced = env_int("CSADP_BITS_CHUNK", 0);
+		const int forced = cfg.bits_chunk;
 		if (forced == 4 || forced == 8 || forced == 16) bits_chunk_ = forced;
 	}
 	bits_wide_ = false;
@@ -642,7 +639,7 @@ int FillBatch::layout_bits()
 	if (!bits_wide_) bits_chunk_ = kBitMaxStrips;
 	/* Pipelined launches of one workgroup per job: the dispatcher hands a compute unit as many workgroups as fit, not one of each
 	 * launch in flight -- three fills on one unit and one on the next run at the pace of the fuller one.  Every fill workgroup
-	 * reserves dynamic LDS so that exactly two of them fit next to one traceback workgroup (tools/sweep_pad.sh,
+	 * reserves dynamic LDS so that exactly two of them fit next to one traceback workgroup (tools/history/sweep_pad.sh,
 	 * profiles/r03_sweep_pad.txt: +2-4 %, and a collapse of 25 % as soon as two fills and a traceback no longer fit). */
 	bits_lds_pad_ = 0;
 	if (pipelined_ && !bits_wide_ && bits_maxstrips_ > 3) {
@@ -651,18 +648,70 @@ int FillBatch::layout_bits()
 		bits_lds_pad_ = std::max(0, std::min(room, 60 * 1024)) & ~255;
 	}
 	{
-		const int forced = env_int("CSADP_BITS_LDS_PAD", -1);
+		const int forced = cfg.bits_lds_pad;
 		if (forced >= 0) bits_lds_pad_ = std::min(forced, 60) * 1024;
 	}
 	next_slot_ = 0;
+	/* the lone shape (csadp_engine.h): device-I/O batches whose planes are per-slot scratch, more than one word per lane, and
+	 * no more strips at one word per lane than the chip has SIMDs */
+	lone_ = LoneShape();
+	last_lone_ = false;
+	std::vector<BitJob> lone_jobs;
+	{
+		const bool io_batch = (int)pairio_.size() == nj && nj > 0;
+		long long strips1 = 0;
+		for (const FillJob &J : jobs_) strips1 += ((J.ncols + 31) / 32 + kLanes - 1) / kLanes;
+		const long long simds = 4LL * std::max(E.compute_units(), 1);
+		lone_.on = pipelined_ && io_batch && bits_words_ > 1 && !bits_wide_ && strips1 <= simds && nslots_ < Engine::kMaxSlots &&
+		           cfg.lone_shape;
+	}
+	if (lone_.on) {
+		lone_.slot = nslots_;
+		lone_.chunk = 4;
+		lone_jobs = bjobs_;
+		for (BitJob &B : lone_jobs) {
+			const int words = (B.ncols + 31) / 32;
+			B.wpl = 1;
+			B.nstrips = (words + kLanes - 1) / kLanes;
+			B.nwords_pad = B.nstrips * kLanes;
+			if (B.nstrips > lone_.chunk) lone_.wide = true;
+		}
+	}
 	size_t off = 0;
-	for (int sl = 0; sl < nslots_; ++sl) {
+	for (int sl = 0; sl < nslots_ + (lone_.on ? 1 : 0); ++sl) {
 		jobs_off_[sl] = off;
 		off += (size_t)nj * sizeof(BitJob);
 	}
 	off = align_up(off, 256);
 	abort_off_ = off;                             /* one abort word for every launch of the batch, zeroed by upload() */
 	off += 256;
+	if (lone_.on && lone_.wide) {
+		/* its work list: (job, chunk of four strips), the longest jobs first, a job's chunks ascending; and once more grouped by
+		 * chunk index for the wait-free repeat (as for the batch's own chunked shape below) */
+		std::vector<int> order((size_t)nj);
+		for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+			return (long long)lone_jobs[(size_t)a].steps_pad * lone_jobs[(size_t)a].nstrips > (long long)lone_jobs[(size_t)b].steps_pad * lone_jobs[(size_t)b].nstrips;
+		});
+		for (int j : order)
+			for (int c = 0; c * lone_.chunk < lone_jobs[(size_t)j].nstrips; ++c) {
+				TileRef t;
+				t.job = j;
+				t.a = c;
+				t.s = 0;
+				t.first = 0;
+				lone_.tiles.push_back(t);
+			}
+		lone_.tiles_off = off;
+		off = align_up(off + lone_.tiles.size() * sizeof(TileRef), 256);
+		lone_.serial_off = off;
+		lone_.serial_tiles = lone_.tiles;
+		std::stable_sort(lone_.serial_tiles.begin(), lone_.serial_tiles.end(), [](const TileRef &a, const TileRef &b) { return a.a < b.a; });
+		for (size_t i = 0; i < lone_.serial_tiles.size(); ++i)
+			if (i == 0 || lone_.serial_tiles[i].a != lone_.serial_tiles[i - 1].a) lone_.chunk_first.push_back(i);
+		lone_.chunk_first.push_back(lone_.serial_tiles.size());
+		off = align_up(off + lone_.serial_tiles.size() * sizeof(TileRef), 256);
+	}
 	tiles_off_ = off;
 	chunk_first_.clear();
 	if (bits_wide_) {
@@ -725,7 +774,24 @@ int FillBatch::layout_bits()
 	}
 	in_bytes_ = off;
 	std::vector<std::vector<BitJob>> slot_jobs((size_t)nslots_, bjobs_);
-	for (int sl = 0; sl < nslots_; ++sl) {
+	if (lone_.on) {
+		for (int j = 0; j < nj; ++j) {                     /* the texts' places and status words: assigned above, after lone_jobs was copied */
+			BitJob &L = lone_jobs[(size_t)j];
+			const BitJob &B = bjobs_[(size_t)j];
+			for (int w = 0; w < 2; ++w) {
+				L.text[w] = B.text[w];
+				L.size[w] = B.size[w];
+				L.first[w] = B.first[w];
+			}
+			L.istatus = B.istatus;
+		}
+		slot_jobs.push_back(lone_jobs);
+	}
+	const int nslots_all = (int)slot_jobs.size();
+	for (int sl = 0; sl < nslots_all; ++sl) {
+		const bool lone_slot = lone_.on && sl == lone_.slot;
+		const int chunk_of_slot = lone_slot ? lone_.chunk : bits_chunk_;
+		const bool wide_of_slot = lone_slot ? lone_.wide : bits_wide_;
 		res_off_[sl] = off;
 		if (io_) {
 			/* results = [summaries][aligned rows]: the host never sees the op lists */
@@ -778,20 +844,30 @@ int FillBatch::layout_bits()
 			B.hand = off;
 			off = align_up(off + blocks * kLanes * 8, 256);
 		}
-		hand_off_[sl] = off;                      /* the granules between the chunks of all jobs, contiguous: zeroed by upload() */
+		const size_t hand0 = off;                 /* the granules between the chunks of all jobs, contiguous: zeroed by upload() */
 		for (int j = 0; j < nj; ++j) {
 			BitJob &B = slot_jobs[(size_t)sl][(size_t)j];
 			B.xhand = off;
-			const int nchunks = (B.nstrips + bits_chunk_ - 1) / bits_chunk_;
-			if (bits_wide_ && nchunks > 1) off = align_up(off + (size_t)(nchunks - 1) * (B.steps_pad / kBitBlock) * 24, 256);
+			const int nchunks = (B.nstrips + chunk_of_slot - 1) / chunk_of_slot;
+			if (wide_of_slot && nchunks > 1) off = align_up(off + (size_t)(nchunks - 1) * (B.steps_pad / kBitBlock) * 24, 256);
 		}
-		hand_bytes_ = off - hand_off_[sl];
+		if (lone_slot) {
+			lone_.hand_off = hand0;
+			lone_.hand_bytes = off - hand0;
+		} else {
+			hand_off_[sl] = hand0;
+			hand_bytes_ = off - hand0;
+		}
 	}
 	total_bytes_ = off;
 	const int rc = finish_layout();
 	if (rc != CSADP_OK) return rc;
-	for (int sl = 0; sl < nslots_; ++sl)
+	for (int sl = 0; sl < nslots_all; ++sl)
 		memcpy(h_in_ + jobs_off_[sl], slot_jobs[(size_t)sl].data(), (size_t)nj * sizeof(BitJob));
+	if (lone_.on && !lone_.tiles.empty()) {
+		memcpy(h_in_ + lone_.tiles_off, lone_.tiles.data(), lone_.tiles.size() * sizeof(TileRef));
+		memcpy(h_in_ + lone_.serial_off, lone_.serial_tiles.data(), lone_.serial_tiles.size() * sizeof(TileRef));
+	}
 	if (!tiles_.empty()) {
 		memcpy(h_in_ + tiles_off_, tiles_.data(), tiles_.size() * sizeof(TileRef));
 		memcpy(h_in_ + serial_off_, serial_tiles_.data(), serial_tiles_.size() * sizeof(TileRef));
@@ -803,7 +879,7 @@ int FillBatch::layout_bits()
 	/* ... unless ONE pass of the batch already covers the chip: then batches take turns on the same stream (first in,
 	 * first out, each traceback under the next batch's fill).  Side by side, three such batches progress at equal rates,
 	 * all complete late and together, and the caller's pipeline runs dry in between: 4.9 vs 4.25 ms per 512-pair batch. */
-	const bool rotate = env_int("CSADP_STREAM_ROTATE", nj < E.compute_units() ? 1 : 0) != 0;
+	const bool rotate = cfg.stream_rotate >= 0 ? cfg.stream_rotate != 0 : nj < E.compute_units();
 	base_stream_ = rotate ? E.rotate_stream() % E.main_streams() : 0;
 	issued_ = 0;
 	bjobs_ = slot_jobs[0];
@@ -869,6 +945,9 @@ int FillBatch::finish_layout()
 		for (auto &e : ev_[sl])
 			if (!e) HIP_TRY(hipEventCreate(&e));
 	}
+	if (bits_ && lone_.on)
+		for (auto &e : ev_[lone_.slot])
+			if (!e) HIP_TRY(hipEventCreate(&e));
 	/* zeroed inputs (padding the kernels rely on, the abort word, the status words) -- except the raw texts of
 	 * a device-I/O batch, which the caller overwrites letter for letter: a streaming caller's create() would
 	 * otherwise clear megabytes of pinned memory twice */
@@ -897,6 +976,7 @@ int FillBatch::upload()
 	if (!laid_out_) return CSADP_ERR_STATE;
 	if ((cells_mode_ || (bits_ && bits_wide_)) && hand_bytes_ > 0)
 		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, home_stream(0)));
+	if (bits_ && lone_.on && lone_.hand_bytes > 0) HIP_TRY(hipMemsetAsync(arena_ + lone_.hand_off, 0, lone_.hand_bytes, home_stream(0)));
 	/* every slot's stream must see the inputs: copy on the batch's first stream and wait (upload is not on the
 	 * timed path; run() calls may follow on any stream) */
 	if (cells_mode_ && nslots_ == 1 && pull_uploads_ && in_bytes_ <= (size_t)4 << 20) {
@@ -927,6 +1007,7 @@ int FillBatch::upload_async()
 			if ((issued_ >> first) & 1ull) HIP_TRY(hipStreamWaitEvent(s0, ev_[first][2], 0));
 	if (bits_ && bits_wide_ && hand_bytes_ > 0)
 		for (int sl = 0; sl < nslots_; ++sl) HIP_TRY(hipMemsetAsync(arena_ + hand_off_[sl], 0, hand_bytes_, s0));
+	if (bits_ && lone_.on && lone_.hand_bytes > 0) HIP_TRY(hipMemsetAsync(arena_ + lone_.hand_off, 0, lone_.hand_bytes, s0));
 	HIP_TRY(hipMemcpyAsync(arena_, h_in_, in_bytes_, hipMemcpyHostToDevice, s0));
 	if (!ev_up_) HIP_TRY(hipEventCreateWithFlags(&ev_up_, hipEventDisableTiming));
 	HIP_TRY(hipEventRecord(ev_up_, s0));
@@ -969,6 +1050,15 @@ int FillBatch::flush_bits(int k)
 {
 	Engine &E = *E_;
 	const int mainN = E.main_streams();
+	if (k == 1 && lone_.on && idle_now()) {
+		const int q = base_stream_ % mainN;
+		const int rc = launch_bits_pass(lone_.slot, 1, E.stream(q), E.stream(mainN + q), false, true);
+		if (rc != CSADP_OK) return rc;
+		last_stream_ = mainN + q;
+		last_first_ = last_slot_ = lone_.slot;
+		last_group_ = 1;
+		return CSADP_OK;
+	}
 	while (k > 0) {
 		const bool piped = nslots_ > 1;
 		const int qi = piped ? next_stream_ : 0;                        /* which of the batch's streams */
@@ -994,35 +1084,48 @@ int FillBatch::flush_bits(int k)
  * rows] on `side` behind an event, so st is free for the fill of its other slot range at once; a range is
  * re-entered only after its own previous traceback has finished.  The three events of a launch live at
  * ev_[first].  serial = the wait-free form of the chunked fill: one launch per chunk index (check_abort). */
-int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial)
+bool FillBatch::idle_now()
+{
+	for (int first = 0; first < Engine::kMaxSlots && first < 64; ++first)
+		if (((issued_ >> first) & 1ull) && hipEventQuery(ev_[first][2]) != hipSuccess) return false;
+	return true;
+}
+
+int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial, bool lone)
 {
 	const int nj = (int)bjobs_.size();
+	/* the shape of this launch: the batch's own, or the lone pass's (csadp_engine.h) */
+	const int words = lone ? 1 : bits_words_, chunk = lone ? lone_.chunk : bits_chunk_;
+	const bool wide = lone ? lone_.wide : bits_wide_;
+	const size_t tiles_off = lone ? lone_.tiles_off : tiles_off_, serial_off = lone ? lone_.serial_off : serial_off_;
+	const size_t ntiles = lone ? lone_.tiles.size() : tiles_.size();
+	const std::vector<size_t> &chunk_first = lone ? lone_.chunk_first : chunk_first_;
+	last_lone_ = lone;
 	hipEvent_t *ev = ev_[first];
 	const BitJob *bj = reinterpret_cast<const BitJob *>(arena_ + jobs_off_[first]);
 	int *abort_word = reinterpret_cast<int *>(arena_ + abort_off_);
 	if (slot_used_[first] && side != st) HIP_TRY(hipStreamWaitEvent(st, ev[2], 0));
 	HIP_TRY(hipEventRecord(ev[0], st));
 	if (io_) HIP_TRY(launch_pack_planes(arena_, bj, g * nj, st));
-	if (bits_wide_) {
+	if (wide) {
 		/* hand-off words between the chunks of a job carry this pass' epoch (see nw_fill_bits_wide) */
 		const uint32_t epoch = Engine::next_epoch();
 		if (!serial) {
-			HIP_TRY(launch_fill_bits_wide(bits_words_, bits_chunk_, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_),
-			                              (int)tiles_.size(), epoch, abort_word, st));
+			HIP_TRY(launch_fill_bits_wide(words, chunk, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off), (int)ntiles, epoch,
+			                              abort_word, st));
 		} else {
-			for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
-				HIP_TRY(launch_fill_bits_wide(bits_words_, bits_chunk_, arena_, bj, nj, g,
-				                              reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
-				                              (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
+			for (size_t c = 0; c + 1 < chunk_first.size(); ++c)
+				HIP_TRY(launch_fill_bits_wide(words, chunk, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off) + chunk_first[c],
+				                              (int)(chunk_first[c + 1] - chunk_first[c]), epoch, abort_word, st));
 		}
 	} else {
-		HIP_TRY(launch_fill_bits(bits_words_, arena_, bj, g * nj, bits_maxstrips_, bits_lds_pad_, abort_word, st));
+		HIP_TRY(launch_fill_bits(words, arena_, bj, g * nj, lone ? 4 : bits_maxstrips_, lone ? 0 : bits_lds_pad_, abort_word, st));
 	}
-	if (!serial && bits_wide_ && test_abort_)             /* testing: see run_slot_cells */
+	if (!serial && wide && test_abort_)                   /* testing: see run_slot_cells */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));
 	HIP_TRY(hipEventRecord(ev[1], st));
 	if (side != st) HIP_TRY(hipStreamWaitEvent(side, ev[1], 0));
-	HIP_TRY(launch_traceback_bits(bits_words_, arena_, bj, g * nj, side));
+	HIP_TRY(launch_traceback_bits(words, arena_, bj, g * nj, side));
 	if (io_) HIP_TRY(launch_expand_rows(arena_, bj, g * nj, side));
 	HIP_TRY(hipEventRecord(ev[2], side));
 	slot_used_[first] = true;
@@ -1061,14 +1164,14 @@ int FillBatch::check_abort()
 	HIP_TRY(hipStreamSynchronize(E_->copy_stream()));
 	if (*h_abort_ == 0) return CSADP_OK;
 	hipStream_t st = E_->stream(last_stream_);
-	if (!bits_wide_) {
+	if (!(last_lone_ ? lone_.wide : bits_wide_)) {
 		fprintf(stderr, "csadp: a wait inside the bit-parallel fill kernel timed out\n");
 		return CSADP_ERR_HIP;
 	}
 	fprintf(stderr, "csadp: a cross-workgroup wait of the chunked fill timed out; repeating the pass chunk by chunk\n");
 	++recoveries_;
 	HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 0, 4, st));
-	const int rc = launch_bits_pass(last_first_, last_slot_ - last_first_ + 1, st, st, true);
+	const int rc = launch_bits_pass(last_first_, last_slot_ - last_first_ + 1, st, st, true, last_lone_);
 	if (rc != CSADP_OK) return rc;
 	HIP_TRY(hipMemcpyAsync(h_abort_, arena_ + abort_off_, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(hipStreamSynchronize(st));
@@ -1198,7 +1301,7 @@ int FillBatch::timing(csadp_timing *t)
 	t->recoveries = recoveries_;
 	t->device_io = io_ ? 1 : 0;
 	t->bit_parallel = bits_ ? 2 : 0;
-	t->words_per_lane = bits_ ? bits_words_ : 0;
+	t->words_per_lane = bits_ ? (last_lone_ ? 1 : bits_words_) : 0;
 	t->streams = bits_ ? bits_streams_ : 1;
 	t->cells = cells_;
 	t->fill_launches = (int)diag_off_.size() - 1;

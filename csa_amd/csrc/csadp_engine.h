@@ -181,7 +181,7 @@ private:
 	bool cells_mode_ = false;
 	size_t hand_off_[Engine::kMaxSlots] = {}, hand_bytes_ = 0;
 	int flush_bits(int k);
-	int launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial);
+	int launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial, bool lone = false);
 	int check_abort();
 	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0;
 	int bits_words_ = 1;                          /* words of 32 columns per lane of this batch's bit-parallel kernels */
@@ -203,6 +203,21 @@ private:
 	std::vector<BitExtra> bextra_;
 	bool bits_ = false, bits_allowed_ = false, bits_wide_ = false;
 	int bits_maxstrips_ = 1, bits_chunk_ = kBitMaxStrips;
+	/* A pipelined batch whose single pass does not fill the chip keeps a SECOND shape for a pass that is flushed alone onto an
+	 * idle device: one word per lane, its strips spread four to a workgroup over every compute unit (one wave per SIMD), on
+	 * one extra slot with its own job table, work list and scratch; texts and results are the batch's own.  The batch's
+	 * regular shape (two or three words per lane, several passes in flight) is the fast one in a steady state, a third of
+	 * it for one pass of 128 pairs (BENCH_r03 one_shot: 0.315 of value). */
+	struct LoneShape {
+		bool on = false;
+		int slot = -1, chunk = 4;
+		bool wide = false;
+		size_t tiles_off = 0, serial_off = 0, hand_off = 0, hand_bytes = 0;
+		std::vector<TileRef> tiles, serial_tiles;
+		std::vector<size_t> chunk_first;
+	} lone_;
+	bool last_lone_ = false;                      /* the last launch took the lone shape */
+	bool idle_now();                              /* every launch of the batch on record has finished */
 	int *h_abort_ = nullptr;
 	std::vector<FillJob> jobs_;
 	std::vector<Extra> extra_;

@@ -9,6 +9,7 @@
 #ifndef CSADP_HOSTPAR_H
 #define CSADP_HOSTPAR_H
 
+#include "csadp_config.h"
 #include <stdlib.h>
 
 #include <algorithm>
@@ -52,8 +53,7 @@ public:
 private:
 	HostPool()
 	{
-		const char *e = getenv("CSADP_HOST_THREADS");
-		int t = e && *e ? atoi(e) : (int)std::thread::hardware_concurrency();
+		int t = config().host_threads > 0 ? config().host_threads : (int)std::thread::hardware_concurrency();
 		nthreads_ = t < 1 ? 1 : (t > 64 ? 64 : t);
 		go_.assign((size_t)nthreads_, 0);
 		cv_ = std::vector<std::condition_variable>((size_t)nthreads_);

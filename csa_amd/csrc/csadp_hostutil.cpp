@@ -11,7 +11,10 @@
 #include <string>
 #include <vector>
 
+#include <mutex>
 #include "csadp.h"
+#include "csadp_config.h"
+#include "csadp_debug.h"
 
 extern "C" {
 
@@ -167,3 +170,59 @@ void csadp_free_fasta(char **texts, char **descs, int *sizes, int nseq)
 }
 
 }  // extern "C"
+
+/* ---- environment switches: read once (csadp_config.h) ------------------------------------------------------------ */
+namespace csadp {
+namespace {
+int env_int(const char *name, int dflt)
+{
+	const char *v = getenv(name);
+	return v && *v ? atoi(v) : dflt;
+}
+Config read_config()
+{
+	Config c;
+	c.bits = env_int("CSADP_BITS", 1) != 0;
+	c.device_io = env_int("CSADP_DEVICE_IO", 1) != 0;
+	c.bits_words = env_int("CSADP_BITS_WORDS", -1);
+	c.bits_chunk = env_int("CSADP_BITS_CHUNK", 0);
+	c.bits_group = env_int("CSADP_BITS_GROUP", -1);
+	c.bits_streams = env_int("CSADP_BITS_STREAMS", -1);
+	c.bits_lds_pad = env_int("CSADP_BITS_LDS_PAD", -1);
+	c.lone_shape = env_int("CSADP_LONE_SHAPE", 1) != 0;
+	c.stream_rotate = env_int("CSADP_STREAM_ROTATE", -1);
+	c.slots = env_int("CSADP_SLOTS", 4);
+	c.tb_band_min = env_int("CSADP_TB_BAND_MIN", 512);
+	c.tb_band_forced = getenv("CSADP_TB_BAND_MIN") != nullptr;
+	c.tb_corridor = env_int("CSADP_TB_CORRIDOR", 3);
+	c.pull_uploads = env_int("CSADP_PULL_UPLOADS", 1) != 0;
+	c.round_groups = env_int("CSADP_ROUND_GROUPS", 2);
+	c.refine_speculate = env_int("CSADP_REFINE_SPECULATE", 0);
+	c.host_threads = env_int("CSADP_HOST_THREADS", 0);
+	c.trace_host = getenv("CSADP_TRACE_HOST") != nullptr;
+	c.share_device = env_int("CSADP_SHARE_DEVICE", 0) != 0;
+	c.local_rank = env_int("LOCAL_RANK", 0);
+	c.test_force_abort = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;
+	return c;
+}
+std::mutex g_config_mutex;
+Config *g_config = nullptr;        /* published once; a reload publishes a new one and leaks the old (a test seam: a handful per process) */
+}  // namespace
+
+const Config &config()
+{
+	Config *c = __atomic_load_n(&g_config, __ATOMIC_ACQUIRE);
+	if (c) return *c;
+	std::lock_guard<std::mutex> lock(g_config_mutex);
+	if (!g_config) __atomic_store_n(&g_config, new Config(read_config()), __ATOMIC_RELEASE);
+	return *g_config;
+}
+
+void reload_config()
+{
+	std::lock_guard<std::mutex> lock(g_config_mutex);
+	__atomic_store_n(&g_config, new Config(read_config()), __ATOMIC_RELEASE);
+}
+}  // namespace csadp
+
+extern "C" void csadp_debug_reload_config(void) { csadp::reload_config(); }

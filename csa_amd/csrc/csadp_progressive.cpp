@@ -13,6 +13,7 @@
 #include <stdio.h>
 
 #include "csadp_device.h"
+#include "csadp_config.h"
 
 namespace csadp {
 
@@ -622,7 +623,7 @@ void Progressive::refine_commit()
 	const int numseqs = refine_numseqs_, maxnongaps = numseqs / 2;
 	if (numseqs == 0) return;
 	refine_numseqs_ = 0;
-	static const bool trace = getenv("CSADP_TRACE_HOST") != nullptr;
+	const bool trace = config().trace_host;
 	const auto t0 = std::chrono::steady_clock::now();
 	/*
 	 * Storage during the pass: a gap buffer.  The reference deletes a run of all-gap columns by moving
@@ -734,8 +735,7 @@ void Progressive::delete_gapped_columns(int numseqs, int maxnongaps)
 {
 	(void)maxnongaps;                                                 /* = numseqs / 2 (:1157) */
 	refine_numseqs_ = numseqs;
-	const char *env = getenv("CSADP_REFINE_SPECULATE");           /* read per call: the tests switch it */
-	const int speculate = env ? atoi(env) : 0;                    /* 1: on this thread, 2: chunks over short-lived threads */
+	const int speculate = config().refine_speculate;              /* 1: on this thread, 2: chunks over the host pool */
 	if (speculate) {
 		const int chunks = refine_prepare();
 		if (speculate >= 2) host_parallel_for(chunks, [this](int c) { refine_speculate(c); });

@@ -31,6 +31,7 @@
 
 #include "csadp.h"
 #include "csadp_hostpar.h"
+#include "csadp_config.h"
 
 using csadp::host_parallel_for;
 
@@ -163,7 +164,7 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 	const int cap = minlen - 1;
 	if (cap < 1) return CSADP_ERR_ARG;
 
-	const bool trace = getenv("CSADP_TRACE_HOST") != NULL;
+	const bool trace = csadp::config().trace_host;
 	auto tp = std::chrono::steady_clock::now();
 	auto lap = [&](const char *what) {
 		if (!trace) return;

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CSADP_VERSION 201
+#define CSADP_VERSION 400
 
 /* only the C-ABI below is exported from libcsadp.so */
 #define CSADP_API __attribute__((visibility("default")))
@@ -158,8 +158,12 @@ CSADP_API int csadp_align_batch_multi(const csadp_task *tasks, int ntasks, csadp
  * called repeatedly before a sync() (benchmark steps, streaming use): consecutive passes are merged
  * into launches that rotate over independent result/scratch slots on separate HIP streams.  A
  * streaming caller keeps several batches in flight: create + run + flush of batch n+1 before fetch
- * of batch n.  (CSADP_DEVICE_IO=0 or CSADP_BITS=0: the host packs tables and applies traces, as for
- * N-sequence tasks.)
+ * of batch n.  A pass that is flushed ALONE while the device holds nothing else of the batch takes a
+ * shape of its own where one pass does not fill the chip (one word of 32 columns per lane, a matrix'
+ * strips spread over all compute units: 128 pairs of 16 kbp in 1.9 instead of 2.6 ms).  After a fetch
+ * the batch may run and be fetched again, as long as every task has a matrix (no empty region).
+ * (CSADP_DEVICE_IO=0 or CSADP_BITS=0: the host packs tables and applies traces, as for N-sequence
+ * tasks; such a batch is fetched once.)
  */
 typedef struct csadp_pairbatch csadp_pairbatch;
 

@@ -38,6 +38,10 @@ CSADP_API int csadp_debug_align_with_filler(const csadp_task *task, csadp_debug_
 CSADP_API int csadp_debug_align_batch_with_filler(const csadp_task *tasks, int ntasks, csadp_debug_fill_fn fill, void *user,
                                         csadp_result *results);
 
+/* The library reads its environment switches ONCE per process (csa_amd/csrc/csadp_config.h; INTEGRATION.md lists them).  This
+ * reads them again: the test-suite flips switches between calls inside one process. */
+CSADP_API void csadp_debug_reload_config(void);
+
 /* Runs one parallel region of the library's persistent host thread pool (the one that spreads per-task
  * host work: table packing, traceback application, result strings) over `items` work items, each adding
  * its index to an atomic; *sum receives items*(items-1)/2.  For the thread-sanitizer build: callable from

@@ -24,3 +24,25 @@ def built_libraries():
         import __graft_entry__
         __graft_entry__.build()
     yield
+
+
+@pytest.fixture(autouse=True)
+def csadp_switches(monkeypatch):
+    """libcsadp.so reads its environment switches once per process (csadp_config.h).  Tests flip them with monkeypatch inside
+    one process: the library re-reads them before every test (the previous test's variables are restored by then) and after
+    every variable a test sets or deletes."""
+    import csa_amd
+    csa_amd.reload_config()
+    setenv, delenv = monkeypatch.setenv, monkeypatch.delenv
+
+    def set_and_reload(name, value, *args, **kwargs):
+        setenv(name, value, *args, **kwargs)
+        csa_amd.reload_config()
+
+    def del_and_reload(name, *args, **kwargs):
+        delenv(name, *args, **kwargs)
+        csa_amd.reload_config()
+
+    monkeypatch.setenv = set_and_reload
+    monkeypatch.delenv = del_and_reload
+    yield

@@ -139,6 +139,51 @@ def test_pair_batch_pipelined_passes_agree(bits_mode):
         assert g["aligned"] == strs and g["score"] == st.last_score
 
 
+def test_pair_batch_run_once_then_many_times(bits_mode):
+    """A pipelined batch of one workgroup per job whose single pass does not fill the chip keeps a second shape for a pass
+    flushed alone onto an idle device (one word per lane, four strips per workgroup over all compute units:
+    csadp_engine.h).  Run once, fetch; run many times, fetch; alone again: the same results each time, whichever shape
+    took the pass -- the timing record says which."""
+    r = rng(1106)
+    base = bytes(r.choice(b"ACGT") for _ in range(12000))
+    tasks = []
+    for i in range(130):
+        n = (2100, 4200, 6300, 8000, 5000)[i % 5] + i
+        o = r.randrange(len(base) - n)
+        a = base[o:o + n]
+        b = bytearray(a)
+        for _ in range(n // 9):
+            b[r.randrange(len(b))] = r.choice(b"ACGT")
+        for _ in range(n // 70):
+            q = r.randrange(len(b) - 8)
+            if r.random() < 0.5:
+                del b[q:q + 1 + i % 4]
+            else:
+                b[q:q] = bytes(r.choice(b"ACGT") for _ in range(1 + i % 3))
+        tasks.append(([a, bytes(b)], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    sample = (0, 1, 2, 3, 4, 77, 129)
+    want = {i: oracle_progressive(tasks[i][0], tasks[i][1]) for i in sample}
+    words = int(bits_mode.split()[0])
+    pb = csa_amd.PairBatch(tasks)
+    seen, first = [], None
+    for passes in (1, 7, 1, 2, 1):
+        for _ in range(passes):
+            pb.run()
+        pb.sync()
+        seen.append(pb.timing()["words_per_lane"])
+        got = pb.fetch()
+        _properties(tasks, got)
+        for i in sample:
+            cons, strs, st = want[i]
+            assert got[i]["aligned"] == strs and got[i]["score"] == st.last_score and got[i]["consensus"] == cons, (passes, i)
+        rows = [g["aligned"] for g in got]
+        assert first is None or rows == first, passes
+        first = rows
+    pb.close()
+    assert seen[1] == words and seen[3] == words, seen
+    assert seen[0] == seen[2] == seen[4] == 1, seen              # the lone passes took the spread shape (one word per lane)
+
+
 def test_first_step_of_families_uses_unit_borders_only():
     """Progressive tasks: step 1 runs bit-parallel, later steps the profile kernel; sub-regions and
     rotations included.  (Golden families cover this too; this one adds longer sequences.)"""
