@@ -7,7 +7,7 @@ Default workload (every N): each GPU aligns its share of config 4 -- 1024 synthe
 pairs over 8 GPUs = 128 pairs per GPU, weak scaling.  A STEP is one pass of the hot path over that
 batch starting from the raw circular letters resident in HBM and ending with the two aligned rows
 of every pair in HBM: nw_pack_planes (CharAt + letter codes) -> nw_fill_bits (the matrix fill) ->
-nw_traceback_replay (the direction walk) -> nw_expand_rows (traceback application + DP score).
+nw_traceback_windows (the direction walk) -> nw_expand_rows (traceback application + DP score).
 One process per GPU; `python bench.py --gpus N` starts its own ranks when it was not launched by
 torch.distributed.run.  No collective inside the timed region (independent tasks); afterwards the
 16-byte result records of every rank are all-gathered over RCCL and rank 0 checks them.
@@ -67,7 +67,7 @@ ALG_BYTES_PER_CELL = 0.25             # the 2-bit direction of ever
 def pmc_summary(kernel):
     """Per-launch PMC figures of `kernel` from this round's committed rocprofv3 passes, or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_summary.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")) as f:
             return json.load(f)[kernel]
     except Exception:
         return None
@@ -163,7 +163,9 @@ def one_shot_leg(csa_amd, tasks):
         if best is None or cur["device_ms"] < best["device_ms"]:
             best = cur
     best["what"] = ("one pass of the same %d pairs with nothing else on the chip (best of 3): device_ms = HIP events around pack + fill + "
-                    "traceback + expand; create_to_fetch = host letters to host strings, Python unpacking included" % len(tasks))
+                    "traceback + expand; create_to_fetch = host letters to host strings, Python unpacking included.  A pass flushed alone "
+                    "onto an idle device takes the batch's second shape (one word per lane, four strips per workgroup over all compute "
+                    "units: csadp_engine.h); round 3 ran it in the steady-state shape: 2.7 ms" % len(tasks))
     return best
 
 
@@ -639,7 +641,7 @@ def main():
                                               "achieved": round(alone_tops, 2), "frac": round(alone_tops / VALU_PEAK_TOPS, 4),
                                               "what": "HIP events around ONE launch with nothing else in flight (one workgroup "
                                                       "per compute unit; the timed region keeps two such launches in "
-                                                      "flight); rocprofv3: profiles/r03_bench_kernel_solo.csv"},
+                                                      "flight); rocprofv3: profiles/r04_bench_kernel_solo.csv"},
                          "calibrated": {"peak_gcups": round(calibrated_peak_gcups, 1),
                                         "frac_alone": round(launch_cells / fill_s / 1e9 / calibrated_peak_gcups, 4),
                                         "frac_sustained": round(value / args.gpus / calibrated_peak_gcups, 4),

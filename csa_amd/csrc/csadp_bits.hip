@@ -855,7 +855,11 @@ __global__ __launch_bounds__(kTbThreads) void nw_traceback_windows(uint8_t *__re
 #define TBW_LAP(slot) do { } while (0)
 #define TBW_COUNT(slot) do { } while (0)
 #endif
-	while (r > 0 && k > 0) {
+	/* every walking round takes at least one op (the first cell after a plan lies in its own piece's window) and every planning round is
+	 * followed by a walking one: more rounds than this is a defect, and the walk then stops short -- which nw_expand_rows / the host's
+	 * trace application report as CSADP_ERR_HIP -- instead of keeping the device busy for ever */
+	int rounds_left = 2 * (J.nrows + J.ncols) + 16;
+	while (r > 0 && k > 0 && --rounds_left >= 0) {
 		const int x = 4 * (wv - 1) + (lane >> 4);                /* the replaying waves' piece */
 		const bool planning = need_plan;                        /* a round that only replays: the first set of a new plan */
 		if (planning) {

@@ -197,6 +197,24 @@ def test_banded_traceback_unmerged_bands_early_ends_and_borders(monkeypatch):
             assert g["aligned"] == strs and g["score"] == st.last_score and g["fills"] == st.fills
 
 
+def test_more_banded_jobs_than_a_grid_dimension(monkeypatch):
+    """The band-parallel traceback kernels take their job from the grid's y / z dimension, which ends at 65535: 66 000 tiny
+    three-sequence tasks with every matrix banded (CSADP_TB_BAND_MIN=1) in one lock-step round go in two launches
+    (round-3 ADVICE).  A sample against the oracle, all by their status and shape."""
+    monkeypatch.setenv("CSADP_TB_BAND_MIN", "1")
+    r = rng(65536)
+    kinds = []
+    for _ in range(40):
+        fam = [bytes(r.choice(b"ACGT") for _ in range(r.randrange(2, 7))) for _ in range(3)]
+        kinds.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    tasks = [kinds[i % len(kinds)] for i in range(66000)]
+    got = csa_amd.align_batch(tasks)
+    want = [oracle_progressive(k[0], k[1]) for k in kinds]
+    for i, g in enumerate(got):
+        cons, strs, st = want[i % len(kinds)]
+        assert g["status"] == 0 and g["consensus"] == cons and g["aligned"] == strs, i
+
+
 def test_device_io_alphabet_regions_and_rotations():
     """The device-side input path (nw_pack_planes): CharAt's single wrap at every rotation/start
     combination, sub-regions, shared texts (one upload per distinct text), letters outside A,C,G,T

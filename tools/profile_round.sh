@@ -3,7 +3,7 @@
 #   tools/profile_round.sh gpurun_out/r03   (then: python tools/summarize_profile.py gpurun_out/r03 profiles/r03)
 # Per workload one --kernel-trace --stats run, then separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not
 # fit one pass on gfx950, MI355X_MICROARCH.md).  The program itself follows "--".
-#   bench    bench.py's timed region: nw_pack_planes, nw_fill_bits, nw_traceback_replay, nw_expand_rows
+#   bench    bench.py's timed region: nw_pack_planes, nw_fill_bits, nw_traceback_windows, nw_expand_rows
 #   msa      tools/msa_probe.py (mode N of the example sets): nw_fill_cells, nw_tb_scout / _resolve / _emit / _gather
 set -e
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

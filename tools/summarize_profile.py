@@ -17,7 +17,7 @@ import os
 import shutil
 import sys
 
-KERNELS = ["nw_fill_bits", "nw_traceback_replay", "nw_fill_cells", "nw_tb_scout", "nw_tb_resolve", "nw_tb_emit", "nw_tb_gather", "nw_pack_planes", "nw_expand_rows", "sp_columns"]
+KERNELS = ["nw_fill_bits", "nw_traceback_windows", "nw_fill_cells", "nw_tb_scout", "nw_tb_resolve", "nw_tb_emit", "nw_tb_gather", "nw_pack_planes", "nw_expand_rows", "sp_columns"]
 
 
 def kernel_key(name):
@@ -86,7 +86,7 @@ def main():
             out[key] = top
     with open(prefix + "_pmc_summary.json", "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print(json.dumps({k: v for k, v in out.items() if k in ("nw_fill_bits", "nw_traceback_replay")}, indent=1, sort_keys=True)[:3000])
+    print(json.dumps({k: v for k, v in out.items() if k in ("nw_fill_bits", "nw_traceback_windows")}, indent=1, sort_keys=True)[:3000])
 
 
 if __name__ == "__main__":
