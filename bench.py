@@ -205,6 +205,14 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
                       "GPU strings %s" % (n, secs, "identical" if mismatches == 0 else "MISMATCH x%d" % mismatches)}
 
 
+def mammals_tasks():
+    """The 66 whole-sequence pairs of the reference's Mammals set with the reference's rotations (numpy / file reading only)."""
+    from helpers import GOLDEN, load_golden, read_fasta
+    _, seqs = read_fasta(os.path.join(GOLDEN, "data", "Mammals.txt"))
+    rots = load_golden("pipeline.json")["Mammals"]["rotations"]
+    return [([seqs[a], seqs[b]], [rots[a], rots[b]], None, None) for a in range(len(seqs)) for b in range(a + 1, len(seqs))]
+
+
 def cpu_many_cores(tasks, per_proc=2, o3=False):
     """The same CPU code in P independent processes (the reference keeps global state, so no
     threads), `per_proc` pairs each.  Runs BEFORE this process touches the GPU, so the forked
@@ -444,11 +452,14 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    many_cores = many_cores_o3 = None
+    many_cores = many_cores_o3 = many_cores_c3 = None
     if args.gpus == 1 and not args.no_cpu_baseline:
         from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
         many_cores = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length))
         many_cores_o3 = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length), o3=True)
+        many_cores_c3 = cpu_many_cores(mammals_tasks()[:64])       # configs 3 AND 4
+        if many_cores_c3:
+            many_cores_c3["sample"] = "config 3 (Mammals whole-sequence pairs): " + many_cores_c3["sample"]
 
     import csa_amd
     from csa_amd import dist as cdist
@@ -683,6 +694,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(tasks, results)
             line["cpu_baseline"]["many_cores"] = many_cores
             line["cpu_baseline"]["many_cores_o3"] = many_cores_o3
+            line["cpu_baseline"]["many_cores_config3"] = many_cores_c3
             line["cpu_baseline"]["host"] = host_description()
             line["cpu_baseline"]["reference_faithful"] = reference_faithful_sample(csa_amd)
     batch.close()
