@@ -603,11 +603,14 @@ __device__ __forceinline__ int lane_column(int c)
  *     scalar loop follows the path through them: a D-run is a find-first-set, a gap move changes diagonal -- towards the main one
  *     it also consumes a lane -- until the lanes, 64 ops, or the five diagonals are exhausted.  An iteration takes up to 64 ops and
  *     any number of gap moves that stay within two diagonals of where it began.
- * The plan (reference cell, strip, slope towards the matrix' corner) outlives a set while the path stays in its windows; a path that
- * leaves them (a long gap run, the next strip) is planned afresh from the current cell.
+ * The plan (reference cell, strip, slope towards the matrix' corner) outlives a set while the path stays in its windows, and carries
+ * on across a strip boundary (the set replayed while the path nears the strip's first column is laid from the predicted crossing into
+ * the strip to the left); a path that leaves its windows (a long gap run) is planned afresh from the current cell: one serial round.
+ * Every round takes at least one op and the rounds are counted: a defect ends the walk short (reported by nw_expand_rows / the host's
+ * trace application as CSADP_ERR_HIP), it does not hang the device.
  */
 #ifndef CSADP_TB_SET_PIECES
-#define CSADP_TB_SET_PIECES 16
+#define CSADP_TB_SET_PIECES 16                         /* (12 and 8 -- three / two replaying waves -- measured slower: profiles/r04_ab_traceback_variants.txt) */
 #endif
 constexpr int kSetPieces = CSADP_TB_SET_PIECES;        /* pieces per tile set: four replaying waves x four DPP rows */
 constexpr int kSetRows = kSetPieces * kBitBlock;       /* tile rows per set */
