@@ -455,3 +455,15 @@ def debug_align_with_filler(task, filler):
     if rc != OK:
         return {"status": rc, "aligned": None, "consensus": 0, "score": 0, "fills": 0, "cells": 0}
     return _unpack([res], ta.nseq)[0]
+
+
+def debug_align_batch_with_filler(tasks, filler):
+    """The same seam for a batch: the product's round driver (lock-step rounds, round groups on their own host threads,
+    CSADP_ROUND_GROUPS) with `filler` in place of the device step.  The filler is called from several threads."""
+    ta = TaskArray(tasks)
+    res = (Result * ta.n)()
+    cb = DEBUG_FILL_FN(filler)
+    L = lib()
+    L.csadp_debug_align_batch_with_filler.argtypes = [ctypes.POINTER(Task), ctypes.c_int, DEBUG_FILL_FN, ctypes.c_void_p, ctypes.POINTER(Result)]
+    _check(L.csadp_debug_align_batch_with_filler(ta.arr, ta.n, cb, None, res), "csadp_debug_align_batch_with_filler")
+    return _unpack(res[:ta.n], ta.nseq)

@@ -85,6 +85,24 @@ def test_host_logic_medium_families_vs_oracle(refine_mode):
         assert got["score"] == st.last_score and got["cells"] == st.cells and got["fills"] == st.fills
 
 
+def test_round_driver_with_one_two_and_three_groups(monkeypatch):
+    """csadp_align_batch's own round driver (lock-step rounds; the tasks dealt longest first over round groups, a host thread
+    each) on the CPU, the oracle's fills in place of the device step: the same strings whatever the number of groups, and the
+    oracle's.  The switch is read once per process: tests/conftest.py reloads it after every monkeypatched variable."""
+    fill = oracle_filler()
+    r = rng(321)
+    tasks = []
+    for n, length in [(4, 150), (3, 40), (6, 90), (5, 1200), (8, 60), (3, 300), (7, 30)]:
+        fam = random_family(r, n, length, mut=0.12, indel=0.08)
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    for groups in ("1", "2", "3"):
+        monkeypatch.setenv("CSADP_ROUND_GROUPS", groups)
+        got = csa_amd.debug_align_batch_with_filler(tasks, fill)
+        for (cons, strs, st), g in zip(want, got):
+            assert g["status"] == 0 and g["aligned"] == strs and g["consensus"] == cons and g["fills"] == st.fills, groups
+
+
 def test_free_results_counts_failures_and_frees_everything():
     """csadp_free_results (one call per batch for streaming callers): frees every result, reports how many carried an
     error; results of the test seam serve as input (one of them fails on its alphabet)."""
