@@ -20,7 +20,8 @@
  * (odd); A's left neighbour and the letter offset of that row come from lane L-1 (its column B; DPP
  * wave_shr:1), which had the row one step earlier, B's left neighbour is A's fresh value.  Lane 0
  * takes the VALUE per block of 32 steps from the border column (first strip of a job), from the words
- * the previous strip's lane 63 left in the LDS ring 63 steps earlier (same workgroup), or from `hand`
+ * the previous strip's lane 63 left in the LDS ring 63 steps earlier (same workgroup; counted in HALF blocks
+ * since round 4: a strip follows its neighbour at 80 steps, not 96 -- RingHalf below), or from `hand`
  * in HBM (previous chunk: 8-byte granules tagged with the launch's epoch, written through by one store
  * each and requested two blocks ahead by the consumer -- no counter, no fence); the LETTER offsets of a
  * block's rows it reads from the row table itself (scalar loads), whatever the strip.  Directions:
@@ -113,18 +114,26 @@ __device__ __forceinline__ int32_t cell_ramp(CellColumn &C, int32_t in, uint32_t
 }
 
 template <bool WIDE, int ROLE>
-__device__ __forceinline__ void cell_block_ramp(CellState &S, const uint32_t *xin, int32_t xfirst, int32_t leftmul,
+__device__ __forceinline__ bool cell_block_ramp(CellState &S, const uint32_t *xin, int32_t xfirst, int32_t leftmul,
                                                 const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
-                                                int l0, int lane)
+                                                int l0, int lane, const int *counter, int need2)
 {
 	uint32_t ioff = 0;
 	asm volatile("" : "+v"(ioff));                     /* keep the address in a VGPR: broadcast LDS reads */
 	uint32_t inx[kCellBlock];
+	/* ROLE_RING: the hand-off values of steps 0..16 now, the rest in front of step 17, when the producer's half-block counter says
+	 * so (as the hand-scheduled blocks do: a strip starts 80 steps behind its left neighbour, not 96) */
+	constexpr int kFirstHalf = ROLE == ROLE_RING ? 17 : kCellBlock;
 #pragma unroll
-	for (int t = 0; t < kCellBlock; ++t) inx[t] = ROLE == ROLE_FIRST ? (uint32_t)(xfirst + leftmul * t) : xin[ioff + t];
+	for (int t = 0; t < kFirstHalf; ++t) inx[t] = ROLE == ROLE_FIRST ? (uint32_t)(xfirst + leftmul * t) : xin[ioff + t];
 	uint32_t accA = 0, accB = 0;
 #pragma unroll
 	for (int t = 0; t < kCellBlock; ++t) {
+		if (ROLE == ROLE_RING && t == kFirstHalf) {
+			if (!wait_lds(counter, need2)) return false;
+#pragma unroll
+			for (int u = kFirstHalf; u < kCellBlock; ++u) inx[u] = xin[ioff + u];
+		}
 		/* column A's left neighbour is the left lane's column B of the same row; column B's is column A */
 		const int32_t in = __builtin_amdgcn_update_dpp((int)inx[t], S.B.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
 		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)letter_of(lw, t), (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
@@ -138,6 +147,7 @@ __device__ __forceinline__ void cell_block_ramp(CellState &S, const uint32_t *xi
 			words[1][t >> 4] = accB;
 		}
 	}
+	return true;
 }
 
 /*
@@ -160,25 +170,46 @@ __device__ __forceinline__ void cell_block_ramp(CellState &S, const uint32_t *xi
  */
 #include "csadp_cells_block.inc"
 
+/* Half-block hand-off inside a workgroup (round 4).  A strip's lane 0 needs, at its step t of block b, what the left strip's lane 63
+ * put out at that strip's step 32 b + t + 63.  Waiting for whole blocks (round 3) started a strip 96 steps behind its neighbour;
+ * now the producer also counts HALF blocks (after its 16th step, inside the generated block) and the consumer reads its window in
+ * two halves: words 0..19 before the block (the producer's first half of block b + 2), words 20..35 in front of step 17 behind a
+ * bounded poll (its second half): 80 steps.  `made` counts half blocks: 2 b + 1 after half a block, 2 b + 2 after block b. */
+struct RingHalf {
+	const uint32_t *window_b;     /* the window's words 4.. come from here + 16 q bytes (the ring's start - 16 bytes where the window straddles its end) */
+	const int *counter;           /* the producer's half-block counter */
+	int need2;                    /* its value from which the window's second half may be read */
+	uint32_t *cslot;              /* where THIS wave counts its own half blocks (lane 63: the counter; other lanes: scrap) */
+	int chalf;                    /* 2 b + 1 */
+};
+
 template <bool WIDE, int ROLE>
-__device__ __forceinline__ void cell_block_fast(CellState &S, const uint32_t *window, int32_t xfirst, int32_t leftmul,
-                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16])
+__device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *window, int32_t xfirst, int32_t leftmul,
+                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
+                                                const RingHalf &R)
 {
 	int32_t outvA = S.A.outv, outvB = S.B.outv, dgA = S.A.diag, dgB = S.B.diag;
 	uint32_t sh = S.outs, w0A, w1A, w0B, w1B;
 	const uint32_t waddr = (uint32_t)(uintptr_t)lanebuf;       /* LDS byte address = low half of the generic pointer */
 	const uint32_t raddr = (uint32_t)(uintptr_t)window;
+	const uint32_t raddrb = (uint32_t)(uintptr_t)R.window_b, paddr = (uint32_t)(uintptr_t)R.counter, caddr = (uint32_t)(uintptr_t)R.cslot;
+	const uint32_t chalf = (uint32_t)R.chalf;
+	uint32_t tmo = 0, scnt, sval, vtmp;
 	const int32_t c2A = 2 - S.A.leftc, c2B = 2 - S.B.leftc;
 #define CELLS_BLOCK_OPERANDS                                                                                                   \
 	: [outvA] "+v"(outvA), [outvB] "+v"(outvB), [dgA] "+v"(dgA), [dgB] "+v"(dgB), [sh] "+v"(sh), [w0A] "=&v"(w0A),             \
-	  [w1A] "=&v"(w1A), [w0B] "=&v"(w0B), [w1B] "=&v"(w1B)                                                                    \
+	  [w1A] "=&v"(w1A), [w0B] "=&v"(w0B), [w1B] "=&v"(w1B), [tmo] "+s"(tmo), [scnt] "=&s"(scnt), [sval] "=&s"(sval),           \
+	  [vtmp] "=&v"(vtmp)                                                                                                       \
 	: [tabA] "v"(S.A.tabf), [tabB] "v"(S.B.tabf), [leftcA] "v"(S.A.leftc), [leftcB] "v"(S.B.leftc), [c2A] "v"(c2A),           \
 	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [l0] "s"(lw[0]),            \
-	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7])   \
-	: CELLS_BLOCK_CLOBBERS
+	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7]),  \
+	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need2] "s"(R.need2), [caddr] "v"(caddr), [chalf] "v"(chalf)                   \
+	: CELLS_BLOCK_CLOBBERS, "scc"
 	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
+	else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
 	else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
 	else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
+	else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
 	else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
 #undef CELLS_BLOCK_OPERANDS
 	S.A.outv = S.A.hup = outvA;
@@ -190,9 +221,10 @@ __device__ __forceinline__ void cell_block_fast(CellState &S, const uint32_t *wi
 	words[0][1] = w1A;
 	words[1][0] = w0B;
 	words[1][1] = w1B;
+	return tmo == 0;
 }
 
-constexpr int kRingWords = kRingSteps + 2 * kCellBlock;    /* the ring + the mirror of its first two blocks */
+constexpr int kRingWords = kRingSteps;                     /* (round 3: + a mirror of the first two blocks; the window is read from two addresses now) */
 constexpr int kInjectWords = 40;                           /* X of step t at word 3 + t: the same 9 x 16-byte window as the ring's */
 constexpr int kScrapWords = 4 * kLanes + 64;               /* lane l: 16 bytes at 16 l (+ 16 q per store of a block) */
 
@@ -269,10 +301,19 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 #pragma unroll
 		for (int q = 0; q < kCellBlock / 4; ++q) lw[q] = nx[q];
 		const uint32_t *window = L.inject_mine;                 /* 16-byte aligned; X of step t at word 3 + t */
+		RingHalf R;
+		R.window_b = window;
+		R.counter = &L.made[wv > 0 ? wv - 1 : 0];
+		R.need2 = 0;
 		if (ROLE == ROLE_RING) {
-			const int need = (b + 3 < nb) ? b + 3 : nb;           /* producer steps up to 32b + 94 */
-			if (!wait_lds(&L.made[wv - 1], need)) return false;
-			window = L.ring_prev + (b * kCellBlock + 60) % kRingSteps;   /* 36 consecutive words thanks to the mirror */
+			/* `made` counts half blocks.  The hand-scheduled blocks (b >= 2) read their window in two halves: words 0..19 need the
+			 * producer's steps up to 32 b + 79 = the first half of its block b + 2; so do the ramp blocks (plain C++) */
+			const int need_all = std::min(2 * (b + 3), 2 * nb), need_half = std::min(2 * (b + 2) + 1, 2 * nb);
+			if (!wait_lds(&L.made[wv - 1], need_half)) return false;
+			R.need2 = need_all;
+			const int start = (b * kCellBlock + 60) % kRingSteps;      /* 36 words from here; at 252 they straddle the ring's end */
+			window = L.ring_prev + start;
+			R.window_b = start + 36 > kRingSteps ? L.ring_prev - 4 : window;
 		} else if (ROLE == ROLE_CHUNK) {
 			const int ps = b * kCellBlock + 63 + t;               /* the producer's lane 63 is 63 steps ahead */
 			granule_wait(pre);
@@ -313,29 +354,23 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			known_taken = __hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		const int32_t xfirst = leftmul * (b * kCellBlock + 1);     /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
+		R.cslot = (feeds && lane == kLanes - 1) ? reinterpret_cast<uint32_t *>(&L.made[wv]) : L.scrap_mine + 4 * lane;
+		R.chalf = 2 * b + 1;
 		if (b < 2) {
-			cell_block_ramp<WIDE, ROLE>(S, window + 3, xfirst, leftmul, lw, lanebuf, words, b * kCellBlock, lane);
+			if (!cell_block_ramp<WIDE, ROLE>(S, window + 3, xfirst, leftmul, lw, lanebuf, words, b * kCellBlock, lane, R.counter, R.need2)) return false;
 			if (b == 1) {                                       /* the hand-scheduled blocks keep D = diag + leftc */
 				S.A.diag += S.A.leftc;
 				S.B.diag += S.B.leftc;
 			}
 		} else {
-			cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words);
+			if (!cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R)) return false;   /* the poll inside ran out */
 		}
 		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers */
 			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (feeds || publishes) {
-			if ((b * kCellBlock) % kRingSteps < 2 * kCellBlock) {  /* mirror the ring's first two blocks behind its end */
-				if (lane < kCellBlock) {                            /* (no wait: the LDS runs this wave's accesses in order) */
-					const int at = (b * kCellBlock) % kRingSteps + lane;
-					L.ring_mine[kRingSteps + at] = L.ring_mine[at];
-				}
-			}
-		}
 		if (feeds) {
 			/* no wait: the LDS executes this wave's stores in the order they were issued, so whoever sees the
-			 * counter sees the block's ring words (and the mirror copy above) */
-			if (lane == kLanes - 1) __hip_atomic_store(&L.made[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			 * counter sees the block's ring words */
+			if (lane == kLanes - 1) __hip_atomic_store(&L.made[wv], 2 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
 		/* the block's 32 values for the next chunk: read back from the ring now (in order behind the block's
 		 * stores), sent at the head of the next block, when the LDS round trip has long passed */
@@ -364,9 +399,9 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
                                                                     const TileRef *__restrict__ work, uint32_t epoch,
                                                                     int *__restrict__ abort_word)
 {
-	/* the ring is mirrored: a block written to words [0, 64) is also written to [256, 320), so that the 36
-	 * consecutive words a consumer block reads never wrap */
-	__shared__ __attribute__((aligned(16))) uint32_t ring[kCellWaves][kRingWords];
+	/* four words in front of every ring: a window that straddles the ring's end is read from two addresses, the second of them
+	 * "ring start - 16 bytes" + 16 q (q >= 1) -- never below the array */
+	__shared__ __attribute__((aligned(16))) uint32_t ring[kCellWaves][4 + kRingWords];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kCellWaves][kInjectWords];
 	__shared__ __attribute__((aligned(16))) uint32_t scrap[kCellWaves][kScrapWords];
 	__shared__ int made[kCellWaves], taken[kCellWaves];
@@ -410,8 +445,8 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	S.B.outv = S.B.hup;
 	S.outs = 0;
 	StripShared L;
-	L.ring_mine = ring[wv];
-	L.ring_prev = ring[wv > 0 ? wv - 1 : 0];
+	L.ring_mine = ring[wv] + 4;
+	L.ring_prev = ring[wv > 0 ? wv - 1 : 0] + 4;
 	L.inject_mine = inject[wv];
 	L.scrap_mine = scrap[wv];
 	L.made = made;

@@ -27,7 +27,32 @@ def gain(wide, ysrc, col):
     return ["v_bfe_u32 v%d, %%[tab%s], v%d, 8" % (G, col, ysrc)]
 
 
-def block(wide, first):
+def ring_second_half():
+    """ROLE_RING: steps 17..31 need the producer's second half of its block two ahead.  Bounded poll of its half-block counter
+    (in LDS: %[paddr], the same address in every lane), then the rest of the window and its presets.  %[tmo] = 1: the poll ran out
+    (the caller raises the abort word; the values read are then garbage)."""
+    a = ["s_mov_b32 %[scnt], 0x400000",
+         "1:",
+         "ds_read_b32 %[vtmp], %[paddr]",
+         "s_waitcnt lgkmcnt(0)",
+         "v_readfirstlane_b32 %[sval], %[vtmp]",
+         "s_cmp_ge_i32 %[sval], %[need2]",
+         "s_cbranch_scc1 2f",
+         "s_sub_u32 %[scnt], %[scnt], 1",
+         "s_cmp_lg_u32 %[scnt], 0",
+         "s_cbranch_scc1 1b",
+         "s_mov_b32 %[tmo], 1",
+         "2:"]
+    for q in range(5, 9):
+        a.append("ds_read_b128 v[%d:%d], %%[raddrb] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
+    a.append("s_waitcnt lgkmcnt(0)")
+    for t in range(17, 32):
+        a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
+    return a
+
+
+def block(wide, role):
+    first = role == "FIRST"
     a = []
     if first:
         # the job's first strip: hand-off value of row r = border column X[r][0] = leftmul * r (:967); %[x0] = that of
@@ -35,6 +60,16 @@ def block(wide, first):
         a.append("v_mov_b32 v%d, %%[x0]" % PX)
         for t in range(1, 32):
             a.append("v_add_u32 v%d, v%d, %%[lm]" % (PX + t, PX + t - 1))
+    elif role == "RING":
+        # the window in two halves: words 0..19 (the presets of steps 0..16) now, words 20..35 in front of step 17.  The first
+        # 16 bytes come from %[raddr], the rest from %[raddrb] (+ 16 q): where the 36 words straddle the ring's end the second
+        # address is the ring's start - 16 (round 3 mirrored the ring's first two blocks behind its end instead)
+        a.append("ds_read_b128 v[%d:%d], %%[raddr]" % (XW, XW + 3))
+        for q in range(1, 5):
+            a.append("ds_read_b128 v[%d:%d], %%[raddrb] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
+        a.append("s_waitcnt lgkmcnt(0)")
+        for t in range(17):
+            a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
     else:
         for q in range(9):
             a.append("ds_read_b128 v[%d:%d], %%[raddr] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
@@ -55,6 +90,8 @@ def block(wide, first):
     a.append("v_add_u32 v%d, %%[dgB], v%d" % (DGB, G))
     for t in range(32):
         prevB = "%[outvB]" if t == 0 else "v%d" % (OXB + t - 1)
+        if t == 17 and role == "RING":
+            a += ring_second_half()
         if t < 31:
             a.append("v_mov_b32_dpp v%d, v%d %s" % (Y + t + 1, Y + t, DPP))
         else:
@@ -78,6 +115,9 @@ def block(wide, first):
         if t % 4 == 3:
             a.append("ds_write_b128 %%[waddr], v[%d:%d] offset:%d" % (OXB + t - 3, OXB + t, 16 * (t // 4)))
         if t == 15:
+            # half of the block's hand-off values are in the ring: the half-block counter (lane 63's address is the counter,
+            # every other lane's its scrap slot; the LDS runs a wave's stores in order)
+            a.append("ds_write_b32 %[caddr], %[chalf]")
             a.append("v_mov_b32 %%[w0A], v%d" % ACCA)
             a.append("v_mov_b32 %%[w0B], v%d" % ACCB)
     a.append("v_mov_b32 %%[w1A], v%d" % ACCA)
@@ -96,8 +136,8 @@ def cstring(lines):
 
 out = ["/* GENERATED by tools/gen_cells_block.py -- do not edit.  See that file for the register map. */"]
 for wide in (0, 1):
-    for first in (0, 1):
-        out.append("#define CELLS_BLOCK_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", "FIRST" if first else "LDS", cstring(block(wide, first))))
+    for role in ("LDS", "FIRST", "RING"):
+        out.append("#define CELLS_BLOCK_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(block(wide, role))))
 regs = list(range(XW, XW + 36)) + list(range(OXB, OXB + 32)) + list(range(Y, Y + 32)) + [H, G, ACCA, ACCB, DGA, DGB, OXA, LFB]
 out.append("#define CELLS_BLOCK_CLOBBERS " + ", ".join('"v%d"' % r for r in regs) + ', "memory"')
 open(sys.argv[1], "w").write("\n".join(out) + "\n")
