@@ -62,6 +62,7 @@ def bits_cycles_per_64_cells(w):
 
 
 ALG_BYTES_PER_CELL = 0.25             # the 2-bit direction of every cell
+PREWARM_S = 1.0                       # untimed passes before the W warm-up steps of `value`: the device leaves its idle clocks (main())
 
 
 def pmc_summary(kernel):
@@ -538,6 +539,20 @@ def main():
         if torch is not None:
             torch.cuda.synchronize()
 
+    # The chip holds its clocks down after an idle period and takes a few hundred milliseconds of load to raise them
+    # (MI355X_MICROARCH.md, 'DVFS give-back': steady clocks want ~2 s of back-to-back launches; tools/r04/prewarm_probe.py,
+    # profiles/r04_prewarm_probe.txt: W = 5 warm-up passes are 4 ms -- 42.9-43.5 TCUPS from idle clocks, 46-47 after 0.5-2 s of
+    # load, 49.8 sustained over 1200 steps).  So: first the driver's W + K steps as they come, from idle clocks (reported as
+    # `from_idle_clocks`), then PREWARM_S seconds of untimed passes of the same batch, then the W warm-up and EXACTLY K timed steps
+    # of `value`.
+    elapsed_idle = cdist.timed_steps(group, batch.run, sync, args.steps, args.warmup)
+    t_pw = time.perf_counter()
+    prewarm_passes = 0
+    while time.perf_counter() - t_pw < PREWARM_S:
+        for _ in range(16):
+            batch.run()
+        sync()
+        prewarm_passes += 16
     elapsed = cdist.timed_steps(group, batch.run, sync, args.steps, args.warmup)
     tm_pipe = batch.timing()                     # HIP events of the launch that held the LAST timed pass
     # one FULL launch alone (nothing else in flight): the bit-parallel path merges up to
@@ -613,6 +628,12 @@ def main():
             "dtype": "u32 bit planes",
             "data": "synthetic", "verified": bool(ok),
             "per_gpu_gcups": round(value / args.gpus, 3),
+            "clocks": {"prewarm_s": PREWARM_S, "prewarm_passes": prewarm_passes,
+                       "from_idle_clocks": {"value": round(cells_step * args.steps / elapsed_idle / 1e9, 3), "ms_per_step": round(elapsed_idle * 1e3 / args.steps, 3),
+                                            "what": "the same W warm-up + K timed steps run FIRST, before any other load on the device"},
+                       "what": "`value` is timed after %.1f s of untimed passes of the same batch (then the W warm-up steps, then exactly K steps): the chip "
+                               "takes a few hundred ms of load to leave its idle clocks, W = 5 passes are 4 ms (MI355X_MICROARCH.md 'DVFS give-back'; "
+                               "profiles/r04_prewarm_probe.txt: 42.9-43.5 TCUPS from idle, 46-47 after 0.5-2 s of load, 49.8 sustained over 1200 steps)" % PREWARM_S},
             "config": {"workload": workload + "; linear-gap NW: pack + fill + traceback + row expansion on the device, "
                                               "bit-exact vs the reference",
                        "pairs_this_rank": len(tasks), "seq_len": "1000..200000" if args.workload == "config5" and args.mode == "strong" else args.length,

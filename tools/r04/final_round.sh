@@ -13,7 +13,7 @@ timeout -k 10 500 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "
 python3 - "$OUT/bench.json" <<'PY'
 import json, sys
 d = json.load(open(sys.argv[1]))
-print("value", d["value"], "ms/step", d["ms_per_step"], "verified", d.get("verified"), "frac", d["roofline"]["frac"], "alone", d["roofline"]["one_launch_alone"])
+print("value", d["value"], "ms/step", d["ms_per_step"], "verified", d.get("verified"), "frac", d["roofline"]["frac"], "from idle", d["clocks"]["from_idle_clocks"], "alone", d["roofline"]["one_launch_alone"]["avg_launch_us"])
 for k in ("records", "kernel_ms", "one_shot", "streaming", "real_sets", "config5", "unrelated_16k", "single_matrix", "profile_path"):
     print(k, json.dumps(d.get(k)))
 cb = d.get("cpu_baseline", {})
