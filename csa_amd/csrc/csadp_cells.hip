@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "csadp_config.h"
 #include "csadp_device.h"
 #include "csadp_kernels.h"
 
@@ -84,7 +85,10 @@ struct CellState {
  * loop body every wave waited for ALL its outstanding global accesses -- the direction stores it had just
  * issued -- once per 32-step block (s_waitcnt vmcnt(0) at the merge points). */
 enum { ROLE_FIRST = 0, ROLE_RING = 1, ROLE_CHUNK = 2 };
-constexpr int kGranuleAhead = 2;                 /* hand-off granules are requested this many blocks ahead (= unroll of the block loop);
+#ifndef CSADP_GRANULE_AHEAD
+#define CSADP_GRANULE_AHEAD 2
+#endif
+constexpr int kGranuleAhead = CSADP_GRANULE_AHEAD;                 /* hand-off granules are requested this many blocks ahead (= unroll of the block loop);
                                                   * 4 was measured: long matrices -3 %, many-strip matrices +5 % (more lag per chunk) */
 
 /* byte t of the eight words that hold a block's 32 letter offsets */
@@ -178,7 +182,7 @@ __device__ __forceinline__ bool cell_block_ramp(CellState &S, const uint32_t *xi
 struct RingHalf {
 	const uint32_t *window_b;     /* the window's words 4.. come from here + 16 q bytes (the ring's start - 16 bytes where the window straddles its end) */
 	const int *counter;           /* the producer's half-block counter */
-	int need2;                    /* its value from which the window's second half may be read */
+	int need1, need2;             /* its values from which the window's first / second half may be read */
 	uint32_t *cslot;              /* where THIS wave counts its own half blocks (lane 63: the counter; other lanes: scrap) */
 	int chalf;                    /* 2 b + 1 */
 };
@@ -203,7 +207,7 @@ __device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *wi
 	: [tabA] "v"(S.A.tabf), [tabB] "v"(S.B.tabf), [leftcA] "v"(S.A.leftc), [leftcB] "v"(S.B.leftc), [c2A] "v"(c2A),           \
 	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [l0] "s"(lw[0]),            \
 	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7]),  \
-	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need2] "s"(R.need2), [caddr] "v"(caddr), [chalf] "v"(chalf)                   \
+	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [caddr] "v"(caddr), [chalf] "v"(chalf)                   \
 	: CELLS_BLOCK_CLOBBERS, "scc"
 	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
 	else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
@@ -244,7 +248,119 @@ __device__ __forceinline__ void granule_reload(unsigned long long &dst, const un
 }
 /* vmcnt counts in order and EVERY block issues exactly one request after consuming one: when a request is due,
  * exactly one younger request is in flight (and possibly the two direction stores between them, a block old) */
-__device__ __forceinline__ void granule_wait(unsigned long long &dst) { asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory"); }
+__device__ __forceinline__ void granule_wait(unsigned long long &dst)
+{
+	if (kGranuleAhead == 2) asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory");
+	else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
+}
+
+#ifdef CSADP_CELL_TIMERS
+/* probe builds only (tools/build_variant.sh): per strip, at its middle block: 100 MHz time at entry, with the hand-off in hand, at the block's end; shader clock of the
+ * same three; the XCC the wave runs on */
+__device__ unsigned long long g_cell_times[8192 * 8];
+#endif
+
+/*
+ * The fetcher of a chunked job's workgroup (launches of few workgroups: one per compute unit, launch_fill_cells): a FIFTH wave that does
+ * nothing but bring the previous chunk's hand-off granules in.  It keeps FOUR requests for the block's 32 granules in flight, a quarter of a
+ * round trip apart, looks at each as it lands and asks again; the first sample in which all 32 carry this launch's epoch AND the block's number goes into ring 0 of
+ * the workgroup, the half-block counter behind it -- the chunk's first strip is then a strip like every other (ROLE_RING: LDS window in two
+ * halves, its poll inside the generated block) and sees a block of its producer one trip through memory after that was published.  Without
+ * it (ROLE_CHUNK below) the strip asks for its granules itself, a block or two ahead: it cannot ask while it computes, so it settles as far
+ * behind its producer as makes every request find its data (measured, tools/r04/cells_times.py: 8.1 us between workgroups where three
+ * blocks, 4.5 us, plus a trip are needed).
+ * One statement on fixed registers: the compiler must not move a register a load is still in flight to.  Bounded by a count of looks
+ * (about a second); `false` = ran out.
+ */
+__device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in, uint32_t *ring0, int *made0, const int *taken0, int nb,
+                                               uint32_t epoch, int lane)
+{
+	const uint32_t rlane = (uint32_t)(uintptr_t)(ring0 + (lane & (kCellBlock - 1)));     /* lanes 32..63 repeat lanes 0..31 */
+	const uint32_t faddr = (uint32_t)(uintptr_t)made0, taddr = (uint32_t)(uintptr_t)taken0;
+	const uint32_t epsh = epoch << 8;
+	uint32_t voff = (uint32_t)(lane & (kCellBlock - 1)) * 8u;
+	uint32_t tmo = 0, k, tag, scnt, st, sv;
+	unsigned long long sx;
+	/* v[100:107]: the four requests; v108: the block's 32 values; v109: scratch.  A request that lands after its block was delivered carries the
+	 * previous block's tag and is simply asked again at the new address -- nothing is ever drained before the last block */
+#define CSADP_FETCH_ASK(LO) "global_load_dwordx2 v[" #LO ":" #LO "+1], %[voff], %[base] sc1\n\t"
+#define CSADP_FETCH_LOOK(HI, FOUND)                                                                                            \
+	"s_waitcnt vmcnt(3)\n\t"                                                                                                   \
+	"v_cmp_ne_u32 vcc, %[tag], v" #HI "\n\t"                                                                                   \
+	"s_cbranch_vccz " #FOUND "f\n\t"
+	/* block k is in v<LO>: wait for its ring slots (they last held block k - kRing, which the strip has in registers once taken0 >= k - kRing),
+	 * store the values, then the counter 2 k + 2 from lane 0 alone (the LDS runs a wave's stores in order); next block */
+#define CSADP_FETCH_DELIVER(LO, L1, L2, BACK)                                                                                  \
+	"v_mov_b32 v108, v" #LO "\n\t"                                                                                             \
+	"s_sub_u32 %[st], %[k], %[ring]\n\t"                                                                                       \
+	"s_cmp_le_i32 %[st], 0\n\t"                                                                                                \
+	"s_cbranch_scc1 " #L2 "f\n\t"                                                                                              \
+	#L1 ":\n\t"                                                                                                                \
+	"ds_read_b32 v109, %[taddr]\n\t"                                                                                           \
+	"s_waitcnt lgkmcnt(0)\n\t"                                                                                                 \
+	"v_readfirstlane_b32 %[sv], v109\n\t"                                                                                      \
+	"s_cmp_ge_i32 %[sv], %[st]\n\t"                                                                                            \
+	"s_cbranch_scc1 " #L2 "f\n\t"                                                                                              \
+	"s_sleep 2\n\t"                                                                                                            \
+	"s_sub_u32 %[scnt], %[scnt], 1\n\t"                                                                                        \
+	"s_cmp_lg_u32 %[scnt], 0\n\t"                                                                                              \
+	"s_cbranch_scc1 " #L1 "b\n\t"                                                                                              \
+	"s_mov_b32 %[tmo], 1\n\t"                                                                                                  \
+	"s_branch 9f\n\t"                                                                                                          \
+	#L2 ":\n\t"                                                                                                                \
+	"s_and_b32 %[st], %[k], %[ringm]\n\t"                                                                                      \
+	"s_lshl_b32 %[st], %[st], 7\n\t"                                                                                           \
+	"v_add_u32 v109, %[st], %[rlane]\n\t"                                                                                      \
+	"ds_write_b32 v109, v108\n\t"                                                                                              \
+	"s_lshl_b32 %[st], %[k], 1\n\t"                                                                                            \
+	"s_add_u32 %[st], %[st], 2\n\t"                                                                                            \
+	"v_mov_b32 v109, %[st]\n\t"                                                                                                \
+	"s_mov_b64 %[sx], exec\n\t"                                                                                                \
+	"s_mov_b64 exec, 1\n\t"                                                                                                    \
+	"ds_write_b32 %[faddr], v109\n\t"                                                                                          \
+	"s_mov_b64 exec, %[sx]\n\t"                                                                                                \
+	"s_add_u32 %[k], %[k], 1\n\t"                                                                                              \
+	"s_cmp_ge_u32 %[k], %[nb]\n\t"                                                                                             \
+	"s_cbranch_scc1 9f\n\t"                                                                                                    \
+	"v_add_u32 %[voff], 0x100, %[voff]\n\t"                                                                                    \
+	"s_and_b32 %[st], %[k], 0xff\n\t"                                                                                          \
+	"s_or_b32 %[tag], %[epsh], %[st]\n\t"                                                                                      \
+	"s_mov_b32 %[scnt], 0x80000\n\t"                                                                                           \
+	"s_branch " #BACK "b\n\t"
+	asm volatile(
+	    "s_mov_b32 %[k], 0\n\t"
+	    "s_mov_b32 %[tag], %[epsh]\n\t"
+	    "s_mov_b32 %[scnt], 0x80000\n\t"
+	    CSADP_FETCH_ASK(100) "s_sleep 12\n\t" CSADP_FETCH_ASK(102) "s_sleep 12\n\t" CSADP_FETCH_ASK(104) "s_sleep 12\n\t" CSADP_FETCH_ASK(106)
+	    "1:\n\t"
+	    CSADP_FETCH_LOOK(101, 20)
+	    "21:\n\t" CSADP_FETCH_ASK(100)
+	    CSADP_FETCH_LOOK(103, 30)
+	    "31:\n\t" CSADP_FETCH_ASK(102)
+	    CSADP_FETCH_LOOK(105, 40)
+	    "41:\n\t" CSADP_FETCH_ASK(104)
+	    CSADP_FETCH_LOOK(107, 50)
+	    "51:\n\t" CSADP_FETCH_ASK(106)
+	    "s_sub_u32 %[scnt], %[scnt], 1\n\t"
+	    "s_cmp_lg_u32 %[scnt], 0\n\t"
+	    "s_cbranch_scc1 1b\n\t"
+	    "s_mov_b32 %[tmo], 1\n\t"
+	    "s_branch 9f\n\t"
+	    "20:\n\t" CSADP_FETCH_DELIVER(100, 22, 23, 21)
+	    "30:\n\t" CSADP_FETCH_DELIVER(102, 32, 33, 31)
+	    "40:\n\t" CSADP_FETCH_DELIVER(104, 42, 43, 41)
+	    "50:\n\t" CSADP_FETCH_DELIVER(106, 52, 53, 51)
+	    "9:\n\t"
+	    "s_waitcnt vmcnt(0)\n\t"                                /* requests still on their way to v100..v107 */
+	    : [tmo] "+s"(tmo), [voff] "+v"(voff), [k] "=&s"(k), [tag] "=&s"(tag), [scnt] "=&s"(scnt), [st] "=&s"(st), [sv] "=&s"(sv), [sx] "=&s"(sx)
+	    : [base] "s"(hand_in), [epsh] "s"(epsh), [nb] "s"(nb), [rlane] "v"(rlane), [faddr] "v"(faddr), [taddr] "v"(taddr), [ring] "n"(kRing),
+	      [ringm] "n"(kRing - 1)
+	    : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "vcc", "scc", "memory");
+#undef CSADP_FETCH_ASK
+#undef CSADP_FETCH_LOOK
+#undef CSADP_FETCH_DELIVER
+	return tmo == 0;
+}
 
 struct StripShared {
 	uint32_t *ring_mine;         /* ring[wv]       */
@@ -257,8 +373,9 @@ struct StripShared {
 template <bool WIDE, int ROLE>
 __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, CellState &S, uint32_t *dirs, size_t dirs_half,
                                           const StripShared &L, unsigned long long *hand_out, const unsigned long long *hand_in, int wv,
-                                          int lane, int nb, bool feeds, bool publishes, uint32_t epoch)
+                                          int lane, int nb, bool feeds, bool publishes, uint32_t epoch, int strip)
 {
+	(void)strip;                                             /* probe builds (CSADP_CELL_TIMERS) */
 	const int t = lane & 31;
 	/* the letter offsets of a block's 32 rows: eight uniform words (scalar loads), requested one block ahead;
 	 * the same for every strip -- lane 0 of each takes them from here, the others get them through DPP */
@@ -282,7 +399,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	const int last_granule = steps_pad - 1;                     /* requests past the end repeat this one; nobody looks at them */
 	if (ROLE == ROLE_CHUNK) {
 		granule_request(preA, hand_in + min(63 + t, last_granule));
-		granule_request(preB, hand_in + min(kCellBlock + 63 + t, last_granule));
+		if (kGranuleAhead == 2) granule_request(preB, hand_in + min(kCellBlock + 63 + t, last_granule));
 	}
 	/* Order of global accesses.  The compiler's wait before the first use of a loaded value is
 	 * s_waitcnt vmcnt(0): it also waits for every store issued since.  So a block first consumes what was
@@ -293,23 +410,32 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	uint32_t pubx = 0;
 	auto publish = [&](int b) {
 		if (lane < kCellBlock)
-			__hip_atomic_store(hand_out + b * kCellBlock + lane, (unsigned long long)pubx | ((unsigned long long)(epoch << 8) << 32),
+			__hip_atomic_store(hand_out + b * kCellBlock + lane, (unsigned long long)pubx | ((unsigned long long)((epoch << 8) | (b & 255)) << 32),
 			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	};
 	auto block = [&](int b, unsigned long long &pre) -> bool {
+#ifdef CSADP_CELL_TIMERS
+		const bool timed = b == nb / 2 && strip < 8192;
+		unsigned long long tr0 = 0, tc0 = 0, tr1 = 0, tc1 = 0;
+		if (timed) {
+			tr0 = __builtin_amdgcn_s_memrealtime();
+			tc0 = __builtin_amdgcn_s_memtime();
+		}
+#endif
 		uint32_t lw[kCellBlock / 4];
 #pragma unroll
 		for (int q = 0; q < kCellBlock / 4; ++q) lw[q] = nx[q];
 		const uint32_t *window = L.inject_mine;                 /* 16-byte aligned; X of step t at word 3 + t */
 		RingHalf R;
 		R.window_b = window;
-		R.counter = &L.made[wv > 0 ? wv - 1 : 0];
-		R.need2 = 0;
+		R.counter = &L.made[ROLE == ROLE_RING ? wv - 1 : 0];           /* [-1]: the fetcher's (nw_fill_cells) */
+		R.need1 = R.need2 = 0;
 		if (ROLE == ROLE_RING) {
 			/* `made` counts half blocks.  The hand-scheduled blocks (b >= 2) read their window in two halves: words 0..19 need the
 			 * producer's steps up to 32 b + 79 = the first half of its block b + 2; so do the ramp blocks (plain C++) */
 			const int need_all = std::min(2 * (b + 3), 2 * nb), need_half = std::min(2 * (b + 2) + 1, 2 * nb);
-			if (!wait_lds(&L.made[wv - 1], need_half)) return false;
+			if (b < 2 && !wait_lds(&L.made[wv - 1], need_half)) return false;      /* the ramp blocks; the others look themselves */
+			R.need1 = need_half;
 			R.need2 = need_all;
 			const int start = (b * kCellBlock + 60) % kRingSteps;      /* 36 words from here; at 252 they straddle the ring's end */
 			window = L.ring_prev + start;
@@ -330,6 +456,12 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			}
 			if (lane < kCellBlock) L.inject_mine[3 + lane] = (uint32_t)v;
 		}
+#ifdef CSADP_CELL_TIMERS
+		if (timed) {
+			tr1 = __builtin_amdgcn_s_memrealtime();
+			tc1 = __builtin_amdgcn_s_memtime();
+		}
+#endif
 		if (b > 0) {
 			uint32_t *d = dirs + (size_t)(b - 1) * (kCellBlock / 16) * kLanes;
 			d[0] = words[0][0];
@@ -378,11 +510,30 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			if (lane < kCellBlock) pubx = L.ring_mine[(b * kCellBlock) % kRingSteps + lane];
 			publish(b);
 		}
+#ifdef CSADP_CELL_TIMERS
+		if (timed && lane == 0) {
+			unsigned long long *g = g_cell_times + 8 * strip;
+			g[0] = tr0;
+			g[1] = tr1;
+			g[2] = __builtin_amdgcn_s_memrealtime();
+			g[3] = tc0;
+			g[4] = tc1;
+			g[5] = __builtin_amdgcn_s_memtime();
+			g[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   /* HW_REG_XCC_ID, bits 0..3 */
+		}
+		if (b == nb / 2 + 16 && strip < 8192 && lane == 0) g_cell_times[8 * strip + 7] = __builtin_amdgcn_s_memtime();   /* 16 periods after g[5] */
+#endif
 		return true;
 	};
-	for (int b = 0; b < nb; b += kGranuleAhead) {
-		if (!block(b, preA)) return false;
-		if (b + 1 < nb && !block(b + 1, preB)) return false;
+	if (kGranuleAhead == 2 && ROLE == ROLE_CHUNK) {           /* two requests in flight, each with its own register; the other roles: one copy of the block (a
+	                                                           * strip alone: 94 -> 85 cycles per step -- the loop fits the instruction cache better) */
+		for (int b = 0; b < nb; b += 2) {
+			if (!block(b, preA)) return false;
+			if (b + 1 < nb && !block(b + 1, preB)) return false;
+		}
+	} else {
+		for (int b = 0; b < nb; ++b)
+			if (!block(b, preA)) return false;
 	}
 	{
 		uint32_t *d = dirs + (size_t)(nb - 1) * (kCellBlock / 16) * kLanes;
@@ -396,31 +547,38 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 
 }  // namespace
 
-template <bool WIDE>
-__global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
+template <bool WIDE, bool FETCH>
+__global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
                                                                     const TileRef *__restrict__ work, uint32_t epoch,
                                                                     int *__restrict__ abort_word)
 {
 	/* four words in front of every ring: a window that straddles the ring's end is read from two addresses, the second of them
 	 * "ring start - 16 bytes" + 16 q (q >= 1) -- never below the array */
-	__shared__ __attribute__((aligned(16))) uint32_t ring[kCellWaves][4 + kRingWords];
+	/* ring[1 + wv]: strip wv's; ring[0]: what the fetcher brings in from the previous chunk (FETCH) */
+	__shared__ __attribute__((aligned(16))) uint32_t ring[kCellWaves + 1][4 + kRingWords];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kCellWaves][kInjectWords];
 	__shared__ __attribute__((aligned(16))) uint32_t scrap[kCellWaves][kScrapWords];
-	__shared__ int made[kCellWaves], taken[kCellWaves];
+	__shared__ int made[kCellWaves + 1], taken[kCellWaves];        /* made[1 + wv]: strip wv's half blocks; made[0]: the fetcher's */
 
 	const TileRef item = work[blockIdx.x];
 	const CellJob &J = jobs[item.job];
 	const int chunk = item.a;
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
 	const int s = chunk * kCellWaves + wv;                    /* this wave's strip */
-	if (threadIdx.x < kCellWaves) {
+	if (threadIdx.x <= kCellWaves) {
 		made[threadIdx.x] = 0;
-		taken[threadIdx.x] = 0;
+		if (threadIdx.x < kCellWaves) taken[threadIdx.x] = 0;
 	}
 	__syncthreads();
+	const int nb = J.steps_pad / kCellBlock;
+	if (FETCH && wv == kCellWaves) {
+		if (chunk == 0 || chunk * kCellWaves >= J.nstrips) return;
+		const unsigned long long *from = reinterpret_cast<const unsigned long long *>(arena + J.hand) + (size_t)(chunk - 1) * J.steps_pad;
+		if (!fetch_granules(from, ring[0] + 4, &made[0], &taken[0], nb, epoch, lane) && lane == 0) atomicExch(abort_word, 1);
+		return;
+	}
 	if (s >= J.nstrips) return;
 
-	const int nb = J.steps_pad / kCellBlock;
 	const int col = s * kCellStripCols + kCellCols * lane;     /* 0-based column A of this lane; B = col + 1 */
 	const uint32_t *coltab = reinterpret_cast<const uint32_t *>(arena + J.coltab);
 	const int32_t *leftcs = reinterpret_cast<const int32_t *>(arena + J.leftc);
@@ -447,11 +605,11 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 	S.B.outv = S.B.hup;
 	S.outs = 0;
 	StripShared L;
-	L.ring_mine = ring[wv] + 4;
-	L.ring_prev = ring[wv > 0 ? wv - 1 : 0] + 4;
+	L.ring_mine = ring[wv + 1] + 4;
+	L.ring_prev = ring[wv] + 4;
 	L.inject_mine = inject[wv];
 	L.scrap_mine = scrap[wv];
-	L.made = made;
+	L.made = made + 1;
 	L.taken = taken;
 	/* table of the hand-scheduled blocks: gain bytes reduced by leftc (8*sv + 2 - leftc = 8*sv + 4*(i - gaps) + 1 <= 12*i + 1:
 	 * the host takes the WIDE form from i = 22 on); WIDE keeps the counts and adds 2 - leftc in the step */
@@ -466,9 +624,9 @@ __global__ __launch_bounds__(kCellWaves *kLanes) void nw_fill_cells(uint8_t *__r
 		}
 	}
 	bool ok;
-	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
-	else if (wv > 0) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
-	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch);
+	if (s == 0) ok = run_strip<WIDE, ROLE_FIRST>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch, s);
+	else if (wv > 0 || FETCH) ok = run_strip<WIDE, ROLE_RING>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch, s);
+	else ok = run_strip<WIDE, ROLE_CHUNK>(J, rsh, S, dirs, dirs_half, L, hand_out, hand_in, wv, lane, nb, feeds, publishes, epoch, s);
 	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }
 
@@ -477,9 +635,22 @@ hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, con
 {
 	if (nwork <= 0) return hipSuccess;
 	epoch &= 0xffffffu;                                /* 24 bits travel in a granule */
-	if (wide) hipLaunchKernelGGL(nw_fill_cells<true>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, epoch, abort_word);
-	else hipLaunchKernelGGL(nw_fill_cells<false>, dim3(nwork), dim3(kCellWaves * kLanes), 0, st, arena, jobs, work, epoch, abort_word);
+	/* few workgroups (one per compute unit at most): every chain is alone on its units and the fill takes as long as its hand-offs do --
+	 * the layout with a fetcher wave (fetch_granules).  More: a compute unit holds two workgroups of four waves, but only one of five */
+	const bool fetch = nwork <= config().cells_fetch_wgs;
+	const dim3 threads((kCellWaves + (fetch ? 1 : 0)) * kLanes);
+	if (wide && fetch) hipLaunchKernelGGL((nw_fill_cells<true, true>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
+	else if (wide) hipLaunchKernelGGL((nw_fill_cells<true, false>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
+	else if (fetch) hipLaunchKernelGGL((nw_fill_cells<false, true>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
+	else hipLaunchKernelGGL((nw_fill_cells<false, false>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
 	return hipGetLastError();
 }
 
 }  // namespace csadp
+
+#ifdef CSADP_CELL_TIMERS
+extern "C" __attribute__((visibility("default"))) int csadp_debug_cell_times(unsigned long long *out, int nstrips)
+{
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(csadp::g_cell_times), sizeof(unsigned long long) * 8 * (size_t)nstrips);
+}
+#endif

@@ -153,6 +153,34 @@ def test_cells_kernel_strip_chunk_and_block_boundaries(length, profile_mode):
         assert g["score"] == st.last_score and g["fills"] == st.fills
 
 
+@pytest.mark.parametrize("layout", ["fetcher", "plain"])
+def test_cells_kernel_hand_off_between_workgroups_in_both_layouts(layout, monkeypatch):
+    """Chunked jobs of nw_fill_cells in both layouts of its workgroups (launch_fill_cells; CSADP_CELLS_FETCH = the most workgroups of a
+    launch that still get the fetcher wave): "fetcher" -- a fifth wave polls the previous chunk's granules into an LDS ring and the
+    chunk's first strip reads them like every other strip; "plain" -- that strip requests its granules itself.  Widths around the
+    chunk boundaries (512 columns per workgroup), one matrix of more than 256 hand-off blocks (the granules' block tag wraps) and
+    more rows than a ring holds, families and pairs in one batch, against the oracle string for string."""
+    monkeypatch.setenv("CSADP_BITS", "0")
+    monkeypatch.setenv("CSADP_CELLS_FETCH", "256" if layout == "fetcher" else "0")
+    r = rng(31337)
+    tasks = []
+    for length in (500, 513, 1025, 1600, 2049):
+        fam = random_family(r, 3, length, mut=0.1, indel=0.04)
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    for ncols, nrows in ((1500, 9000), (9000, 1500), (700, 40), (40, 700)):
+        base = bytes(r.choice(b"ACGT") for _ in range(max(ncols, nrows)))
+        a = base[:ncols]
+        b = bytes(c if r.random() > 0.1 else r.choice(b"ACGT") for c in base[:nrows])
+        tasks.append(([a, b], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    got = csa_amd.align_batch(tasks)
+    alone = csa_amd.align_batch(tasks[5:6])[0]                 # one matrix alone: 3 workgroups, every chain on its own units
+    for t, g in zip(tasks, got):
+        cons, strs, st = oracle_progressive(t[0], t[1])
+        assert g["status"] == 0 and g["consensus"] == cons
+        assert g["aligned"] == strs and g["score"] == st.last_score
+    assert alone["aligned"] == got[5]["aligned"] and alone["score"] == got[5]["score"]
+
+
 def test_cells_kernel_paths_that_leave_the_traceback_window(profile_mode):
     """Profiles whose optimal path drifts far from the diagonal (a 700-letter insertion in the middle of the
     row sequence): the walk leaves its LDS window and must reload it around the current cell; the band-parallel

@@ -27,27 +27,41 @@ def gain(wide, ysrc, col):
     return ["v_bfe_u32 v%d, %%[tab%s], v%d, 8" % (G, col, ysrc)]
 
 
-def ring_second_half():
-    """ROLE_RING: steps 17..31 need the producer's second half of its block two ahead.  Bounded poll of its half-block counter
-    (in LDS: %[paddr], the same address in every lane), then the rest of the window and its presets.  %[tmo] = 1: the poll ran out
-    (the caller raises the abort word; the values read are then garbage)."""
-    a = ["s_mov_b32 %[scnt], 0x400000",
-         "1:",
+def ring_poll(need, lo, hi, tag):
+    """ROLE_RING, the slow way to a half of the window: bounded poll of the producer's half-block counter (in LDS: %[paddr], the same address in
+    every lane), then the window's words again.  Only taken when the look that was asked for ahead of time (counter first, words behind it: the
+    LDS runs a wave's reads in order) found the counter short.  %[tmo] = 1: the poll ran out (the caller raises the abort word; the values
+    read are then garbage)."""
+    a = ["s_waitcnt lgkmcnt(0)",
+         "v_readfirstlane_b32 %[sval], %[vtmp]",
+         "s_cmp_ge_i32 %[sval], " + need,
+         "s_cbranch_scc1 %d2f" % tag,
+         "s_mov_b32 %[scnt], 0x400000",
+         "%d1:" % tag,
          "ds_read_b32 %[vtmp], %[paddr]",
          "s_waitcnt lgkmcnt(0)",
          "v_readfirstlane_b32 %[sval], %[vtmp]",
-         "s_cmp_ge_i32 %[sval], %[need2]",
-         "s_cbranch_scc1 2f",
+         "s_cmp_ge_i32 %[sval], " + need,
+         "s_cbranch_scc1 %d3f" % tag,
          "s_sub_u32 %[scnt], %[scnt], 1",
          "s_cmp_lg_u32 %[scnt], 0",
-         "s_cbranch_scc1 1b",
+         "s_cbranch_scc1 %d1b" % tag,
          "s_mov_b32 %[tmo], 1",
-         "2:"]
-    for q in range(5, 9):
-        a.append("ds_read_b128 v[%d:%d], %%[raddrb] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
-    a.append("s_waitcnt lgkmcnt(0)")
-    for t in range(17, 32):
-        a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
+         "%d3:" % tag]
+    a += ring_words(lo, hi)
+    a += ["s_waitcnt lgkmcnt(0)", "%d2:" % tag]
+    return a
+
+
+def ring_words(lo, hi):
+    """the window's 16-byte pieces lo..hi-1: the first comes from %[raddr], the rest from %[raddrb] (+ 16 q): where the 36 words straddle the
+    ring's end the second address is the ring's start - 16 (round 3 mirrored the ring's first two blocks behind its end instead)"""
+    a = []
+    for q in range(lo, hi):
+        if q == 0:
+            a.append("ds_read_b128 v[%d:%d], %%[raddr]" % (XW, XW + 3))
+        else:
+            a.append("ds_read_b128 v[%d:%d], %%[raddrb] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
     return a
 
 
@@ -61,21 +75,13 @@ def block(wide, role):
         for t in range(1, 32):
             a.append("v_add_u32 v%d, v%d, %%[lm]" % (PX + t, PX + t - 1))
     elif role == "RING":
-        # the window in two halves: words 0..19 (the presets of steps 0..16) now, words 20..35 in front of step 17.  The first
-        # 16 bytes come from %[raddr], the rest from %[raddrb] (+ 16 q): where the 36 words straddle the ring's end the second
-        # address is the ring's start - 16 (round 3 mirrored the ring's first two blocks behind its end instead)
-        a.append("ds_read_b128 v[%d:%d], %%[raddr]" % (XW, XW + 3))
-        for q in range(1, 5):
-            a.append("ds_read_b128 v[%d:%d], %%[raddrb] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
-        a.append("s_waitcnt lgkmcnt(0)")
-        for t in range(17):
-            a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
+        # the window in two halves: words 0..19 (the presets of steps 0..16) now, words 20..35 in front of step 17, each asked for together
+        # with the producer's half-block counter (counter first) and looked at only after work that does not need it
+        a.append("ds_read_b32 %[vtmp], %[paddr]")
+        a += ring_words(0, 5)
     else:
         for q in range(9):
             a.append("ds_read_b128 v[%d:%d], %%[raddr] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
-        a.append("s_waitcnt lgkmcnt(0)")
-        for t in range(32):
-            a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
     # lane-0 letter offsets of the block's 32 rows: the bytes of eight scalar registers
     for t in range(32):
         a.append("v_bfe_u32 v%d, %%[l%d], %d, 8" % (Y + t, t // 4, 8 * (t % 4)))
@@ -88,10 +94,25 @@ def block(wide, role):
     a.append("v_add_u32 v%d, %%[dgA], v%d" % (DGA, G))
     a += gain(wide, Y, "B")
     a.append("v_add_u32 v%d, %%[dgB], v%d" % (DGB, G))
+    # the window has had the time of the letter work to arrive
+    if role == "RING":
+        a += ring_poll("%[need1]", 0, 5, 1)
+        for t in range(17):
+            a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
+    elif not first:
+        a.append("s_waitcnt lgkmcnt(0)")
+        for t in range(32):
+            a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
     for t in range(32):
         prevB = "%[outvB]" if t == 0 else "v%d" % (OXB + t - 1)
+        if t == 12 and role == "RING":
+            # the second half is asked for five steps before it is needed (the counter in front of it)
+            a.append("ds_read_b32 %[vtmp], %[paddr]")
+            a += ring_words(5, 9)
         if t == 17 and role == "RING":
-            a += ring_second_half()
+            a += ring_poll("%[need2]", 5, 9, 2)
+            for u in range(17, 32):
+                a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + u, PX + u))
         if t < 31:
             a.append("v_mov_b32_dpp v%d, v%d %s" % (Y + t + 1, Y + t, DPP))
         else:
