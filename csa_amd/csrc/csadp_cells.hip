@@ -48,7 +48,6 @@ namespace {
 constexpr int kRing = 8;                          /* hand-off blocks buffered per strip boundary */
 constexpr int kRingSteps = kRing * kCellBlock;
 constexpr unsigned long long kSpinTicks = 50000000ull;    /* bound of every wait: 0.5 s of the 100 MHz s_memrealtime clock (round 2: an iteration count) */
-constexpr int DPP_WAVE_SHR1 = 0x138;
 
 /* Counters in LDS that order LDS data only: the LDS executes one wave's instructions in order and is
  * coherent inside the compute unit, so relaxed accesses suffice -- a workgroup-scope release/acquire
@@ -70,8 +69,7 @@ struct CellColumn {
 	uint32_t tabf;      /* the same for the hand-scheduled blocks: bytes reduced by leftc               */
 	int32_t leftc;      /* 4*(gaps - i) + 1                                                             */
 	int32_t hup;        /* X of the cell above (this column, previous row)                              */
-	int32_t diag;       /* X of the cell above-left (ramp blocks); the hand-scheduled blocks keep
-	                     * D = that value + leftc instead                                               */
+	int32_t diag;       /* D = X of the cell above-left + leftc                                         */
 	int32_t outv;       /* X of the column's cell in the current row, tag cleared                       */
 };
 struct CellState {
@@ -91,71 +89,8 @@ enum { ROLE_FIRST = 0, ROLE_RING = 1, ROLE_CHUNK = 2 };
 constexpr int kGranuleAhead = CSADP_GRANULE_AHEAD;                 /* hand-off granules are requested this many blocks ahead (= unroll of the block loop);
                                                   * 4 was measured: long matrices -3 %, many-strip matrices +5 % (more lag per chunk) */
 
-/* byte t of the eight words that hold a block's 32 letter offsets */
-__device__ __forceinline__ uint32_t letter_of(const uint32_t (&lw)[kCellBlock / 4], int t) { return (lw[t >> 2] >> (8 * (t & 3))) & 0xffu; }
-
 /*
- * The first two blocks of a strip (the ramp: a lane keeps its border values until its first row arrives),
- * plain C++.  xin[t] = hand-off value entering lane 0 at step t (ROLE_FIRST: computed from the border
- * column), lw = the block's letter offsets, lanebuf[t] = where this lane's value of step t goes (the ring
- * for lane 63, a scrap area for all others: no EXEC change).
- */
-template <bool WIDE>
-__device__ __forceinline__ int32_t cell_ramp(CellColumn &C, int32_t in, uint32_t sh, uint32_t &acc, bool live)
-{
-	int32_t dg;
-	if (WIDE) dg = C.diag + 2 + (int32_t)(__builtin_amdgcn_ubfe(C.tab, sh, 6) << 3);    /* 6-bit counts: gain = 8*sv + 2 */
-	else dg = C.diag + (int32_t)__builtin_amdgcn_ubfe(C.tab, sh, 8);                    /* pre-scaled byte 8*sv + 2      */
-	const int32_t lf = in + C.leftc;
-	int32_t h = max(max(dg, C.hup), lf);
-	acc = __builtin_amdgcn_alignbit((uint32_t)h, acc, 2);
-	h &= ~3;
-	/* rows above the matrix: the lane keeps its border values until its first row arrives */
-	C.diag = live ? in : C.diag;
-	C.hup = live ? h : C.hup;
-	C.outv = C.hup;
-	return C.outv;
-}
-
-template <bool WIDE, int ROLE>
-__device__ __forceinline__ bool cell_block_ramp(CellState &S, const uint32_t *xin, int32_t xfirst, int32_t leftmul,
-                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
-                                                int l0, int lane, const int *counter, int need2)
-{
-	uint32_t ioff = 0;
-	asm volatile("" : "+v"(ioff));                     /* keep the address in a VGPR: broadcast LDS reads */
-	uint32_t inx[kCellBlock];
-	/* ROLE_RING: the hand-off values of steps 0..16 now, the rest in front of step 17, when the producer's half-block counter says
-	 * so (as the hand-scheduled blocks do: a strip starts 80 steps behind its left neighbour, not 96) */
-	constexpr int kFirstHalf = ROLE == ROLE_RING ? 17 : kCellBlock;
-#pragma unroll
-	for (int t = 0; t < kFirstHalf; ++t) inx[t] = ROLE == ROLE_FIRST ? (uint32_t)(xfirst + leftmul * t) : xin[ioff + t];
-	uint32_t accA = 0, accB = 0;
-#pragma unroll
-	for (int t = 0; t < kCellBlock; ++t) {
-		if (ROLE == ROLE_RING && t == kFirstHalf) {
-			if (!wait_lds(counter, need2)) return false;
-#pragma unroll
-			for (int u = kFirstHalf; u < kCellBlock; ++u) inx[u] = xin[ioff + u];
-		}
-		/* column A's left neighbour is the left lane's column B of the same row; column B's is column A */
-		const int32_t in = __builtin_amdgcn_update_dpp((int)inx[t], S.B.outv, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp((int)letter_of(lw, t), (int)S.outs, DPP_WAVE_SHR1, 0xf, 0xf, false);
-		const bool live = l0 + t >= lane;
-		const int32_t a = cell_ramp<WIDE>(S.A, in, sh, accA, live);
-		const int32_t bval = cell_ramp<WIDE>(S.B, a, sh, accB, live);
-		S.outs = sh;
-		lanebuf[t] = (uint32_t)bval;
-		if ((t & 15) == 15) {
-			words[0][t >> 4] = accA;
-			words[1][t >> 4] = accB;
-		}
-	}
-	return true;
-}
-
-/*
- * The same 32 steps for all later blocks, hand-scheduled: ONE inline-assembly statement on fixed registers,
+ * A strip's 32-step block, hand-scheduled: ONE inline-assembly statement on fixed registers,
  * generated by tools/gen_cells_block.py (csadp_cells_block.inc).  Measured on a wave alone on its SIMD
  * (tools/cellstep_microbench.hip): a VALU instruction costs ~4.2 cycles whatever it is and whatever it depends
  * on, an LDS store 16-27 cycles of the WAVE's issue time (b32 16, 2 x b32 20, b128 27), an LDS load ~6.  So:
@@ -171,6 +106,11 @@ __device__ __forceinline__ bool cell_block_ramp(CellState &S, const uint32_t *xi
  *   - a lane works on two adjacent columns per step: B's left neighbour is A's fresh value (a plain v_add), so the
  *     cross-lane move, the letter move and every hand-off serve two cells.
  * 13 VALU per step (two cells) + 2 per step at the block's head (lane-0 presets of X and letter offset).
+ * A strip's first two blocks (the ramp: lane l's first row arrives at step l) are the same statement with a live mask that moves to the
+ * right with the letters and v_bfi_b32 in place of v_and_b32 (CELLS_RAMP_ASM_*: 14 VALU per step; the generator's header says why nothing
+ * else needs the mask).  Rounds 2-4 ran them as plain C++ at 1.5 x the time of a hand-scheduled block -- and a strip cannot start before its
+ * left neighbour is through two and a half blocks: every strip boundary of a matrix waited for that (tools/r04/cells_times.py: 4.65 us
+ * behind the neighbour at the start where 3.6 us are kept up later on).
  */
 #include "csadp_cells_block.inc"
 
@@ -187,10 +127,10 @@ struct RingHalf {
 	int chalf;                    /* 2 b + 1 */
 };
 
-template <bool WIDE, int ROLE>
+template <bool WIDE, int ROLE, bool RAMP>
 __device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *window, int32_t xfirst, int32_t leftmul,
                                                 const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
-                                                const RingHalf &R)
+                                                const RingHalf &R, uint32_t lm0)
 {
 	int32_t outvA = S.A.outv, outvB = S.B.outv, dgA = S.A.diag, dgB = S.B.diag;
 	uint32_t sh = S.outs, w0A, w1A, w0B, w1B;
@@ -207,14 +147,23 @@ __device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *wi
 	: [tabA] "v"(S.A.tabf), [tabB] "v"(S.B.tabf), [leftcA] "v"(S.A.leftc), [leftcB] "v"(S.B.leftc), [c2A] "v"(c2A),           \
 	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [l0] "s"(lw[0]),            \
 	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7]),  \
-	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [caddr] "v"(caddr), [chalf] "v"(chalf)                   \
+	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [lm0] "v"(lm0), [caddr] "v"(caddr), [chalf] "v"(chalf)                   \
 	: CELLS_BLOCK_CLOBBERS, "scc"
-	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
-	else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
-	else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
-	else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
-	else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
-	else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
+	if (RAMP) {
+		if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_RAMP_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
+		else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_RAMP_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
+		else if (WIDE) asm volatile(CELLS_RAMP_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
+		else if (ROLE == ROLE_FIRST) asm volatile(CELLS_RAMP_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
+		else if (ROLE == ROLE_RING) asm volatile(CELLS_RAMP_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
+		else asm volatile(CELLS_RAMP_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
+	} else {
+		if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
+		else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
+		else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
+		else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
+		else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
+		else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
+	}
 #undef CELLS_BLOCK_OPERANDS
 	S.A.outv = S.A.hup = outvA;
 	S.B.outv = S.B.hup = outvB;
@@ -257,7 +206,7 @@ __device__ __forceinline__ void granule_wait(unsigned long long &dst)
 #ifdef CSADP_CELL_TIMERS
 /* probe builds only (tools/build_variant.sh): per strip, at its middle block: 100 MHz time at entry, with the hand-off in hand, at the block's end; shader clock of the
  * same three; the XCC the wave runs on */
-__device__ unsigned long long g_cell_times[8192 * 8];
+__device__ unsigned long long g_cell_times[8192 * 12];   /* + [8] entry of block 0, [9] end of the last block, [10] end of block 2 (100 MHz) */
 #endif
 
 /*
@@ -416,6 +365,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	auto block = [&](int b, unsigned long long &pre) -> bool {
 #ifdef CSADP_CELL_TIMERS
 		const bool timed = b == nb / 2 && strip < 8192;
+		if (b == 0 && strip < 8192 && lane == 0) g_cell_times[12 * strip + 8] = __builtin_amdgcn_s_memrealtime();
 		unsigned long long tr0 = 0, tc0 = 0, tr1 = 0, tc1 = 0;
 		if (timed) {
 			tr0 = __builtin_amdgcn_s_memrealtime();
@@ -434,7 +384,6 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			/* `made` counts half blocks.  The hand-scheduled blocks (b >= 2) read their window in two halves: words 0..19 need the
 			 * producer's steps up to 32 b + 79 = the first half of its block b + 2; so do the ramp blocks (plain C++) */
 			const int need_all = std::min(2 * (b + 3), 2 * nb), need_half = std::min(2 * (b + 2) + 1, 2 * nb);
-			if (b < 2 && !wait_lds(&L.made[wv - 1], need_half)) return false;      /* the ramp blocks; the others look themselves */
 			R.need1 = need_half;
 			R.need2 = need_all;
 			const int start = (b * kCellBlock + 60) % kRingSteps;      /* 36 words from here; at 252 they straddle the ring's end */
@@ -487,14 +436,10 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		const int32_t xfirst = leftmul * (b * kCellBlock + 1);     /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
 		R.cslot = (feeds && lane == kLanes - 1) ? reinterpret_cast<uint32_t *>(&L.made[wv]) : L.scrap_mine + 4 * lane;
 		R.chalf = 2 * b + 1;
-		if (b < 2) {
-			if (!cell_block_ramp<WIDE, ROLE>(S, window + 3, xfirst, leftmul, lw, lanebuf, words, b * kCellBlock, lane, R.counter, R.need2)) return false;
-			if (b == 1) {                                       /* the hand-scheduled blocks keep D = diag + leftc */
-				S.A.diag += S.A.leftc;
-				S.B.diag += S.B.leftc;
-			}
+		if (b < 2) {                                            /* the ramp: lane l is live from step l on */
+			if (!cell_block_fast<WIDE, ROLE, true>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R, lane <= b * kCellBlock ? ~3u : 0u)) return false;
 		} else {
-			if (!cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R)) return false;   /* the poll inside ran out */
+			if (!cell_block_fast<WIDE, ROLE, false>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R, 0u)) return false;   /* the poll inside ran out */
 		}
 		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers */
 			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -512,7 +457,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		}
 #ifdef CSADP_CELL_TIMERS
 		if (timed && lane == 0) {
-			unsigned long long *g = g_cell_times + 8 * strip;
+			unsigned long long *g = g_cell_times + 12 * strip;
 			g[0] = tr0;
 			g[1] = tr1;
 			g[2] = __builtin_amdgcn_s_memrealtime();
@@ -521,7 +466,8 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			g[5] = __builtin_amdgcn_s_memtime();
 			g[6] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   /* HW_REG_XCC_ID, bits 0..3 */
 		}
-		if (b == nb / 2 + 16 && strip < 8192 && lane == 0) g_cell_times[8 * strip + 7] = __builtin_amdgcn_s_memtime();   /* 16 periods after g[5] */
+		if (b == nb / 2 + 16 && strip < 8192 && lane == 0) g_cell_times[12 * strip + 7] = __builtin_amdgcn_s_memtime();   /* 16 periods after g[5] */
+		if (strip < 8192 && lane == 0 && (b == nb - 1 || b == 2)) g_cell_times[12 * strip + (b == 2 ? 10 : 9)] = __builtin_amdgcn_s_memrealtime();
 #endif
 		return true;
 	};
@@ -598,9 +544,10 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fi
 	S.B.tab = coltab[col + 1];
 	S.A.leftc = leftcs[col];
 	S.B.leftc = leftcs[col + 1];
-	S.A.diag = top[col];
-	S.A.hup = S.B.diag = top[col + 1];
+	S.A.hup = top[col + 1];
 	S.B.hup = top[col + 2];
+	S.A.diag = top[col] + S.A.leftc;                          /* the blocks keep D = the cell above-left + leftc */
+	S.B.diag = top[col + 1] + S.B.leftc;
 	S.A.outv = S.A.hup;
 	S.B.outv = S.B.hup;
 	S.outs = 0;
@@ -651,6 +598,6 @@ hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, con
 #ifdef CSADP_CELL_TIMERS
 extern "C" __attribute__((visibility("default"))) int csadp_debug_cell_times(unsigned long long *out, int nstrips)
 {
-	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(csadp::g_cell_times), sizeof(unsigned long long) * 8 * (size_t)nstrips);
+	return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(csadp::g_cell_times), sizeof(unsigned long long) * 12 * (size_t)nstrips);
 }
 #endif

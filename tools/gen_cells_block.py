@@ -12,11 +12,16 @@ Register map (clobbered by the statement):
   v[168:199]  OXB  X of the lane's B cell after step t (what lane 63 hands to the next strip): 8 x ds_write_b128
   v[200:231]  Y    letter offset of step t (lane 0 preset from the row sequence, v_mov_b32_dpp for the others)
   v[236:243]  H, G, ACCA, ACCB, DGA, DGB, OXA, LFB
+  v244        LM   ramp variants (a strip's first two blocks): -4 in the lanes whose first row has arrived, 0 in the others; moves one
+                   lane to the right per step like the letters.  A lane that is not live yet runs the same instructions on its border
+                   values and keeps them: X is taken through v_bfi_b32 (LM ? h & -4 : old X) where the later blocks have v_and_b32;
+                   everything else such a lane computes is either unused or already what its first row needs (lf = the left lane's border
+                   value + leftc = its own D; the next step's dg from that and the letter that arrives with the row)
 """
 import sys
 
 XW, OXB, Y = 128, 168, 200
-H, G, ACCA, ACCB, DGA, DGB, OXA, LFB = 236, 237, 238, 239, 240, 241, 242, 243
+H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM = 236, 237, 238, 239, 240, 241, 242, 243, 244
 PX = XW + 3
 DPP = "wave_shr:1 row_mask:0xf bank_mask:0xf"
 
@@ -65,15 +70,17 @@ def ring_words(lo, hi):
     return a
 
 
-def block(wide, role):
+def block(wide, role, ramp=False):
     first = role == "FIRST"
     a = []
+    if ramp:
+        a.append("v_mov_b32 v%d, %%[lm0]" % LM)
     if first:
         # the job's first strip: hand-off value of row r = border column X[r][0] = leftmul * r (:967); %[x0] = that of
         # the block's first row + leftcA, every further one adds leftmul
         a.append("v_mov_b32 v%d, %%[x0]" % PX)
         for t in range(1, 32):
-            a.append("v_add_u32 v%d, v%d, %%[lm]" % (PX + t, PX + t - 1))
+            a.append("v_mad_i32_i24 v%d, %%[lm], %d, %%[x0]" % (PX + t, t))      # (a chain of 31 dependent adds before: +5 cycles per step)
     elif role == "RING":
         # the window in two halves: words 0..19 (the presets of steps 0..16) now, words 20..35 in front of step 17, each asked for together
         # with the producer's half-block counter (counter first) and looked at only after work that does not need it
@@ -123,7 +130,10 @@ def block(wide, role):
         if t < 31:
             a += gain(wide, Y + t + 1, "A")
             a.append("v_add_u32 v%d, v%d, v%d" % (DGA, PX + t, G))
-        a.append("v_and_b32 v%d, -4, v%d" % (OXA, H))
+        if ramp:
+            a.append("v_bfi_b32 v%d, v%d, v%d, v%d" % (OXA, LM, H, OXA))
+        else:
+            a.append("v_and_b32 v%d, -4, v%d" % (OXA, H))
         a.append("v_alignbit_b32 v%d, v%d, v%d, 2" % (ACCA, H, ACCA))
         # column B: left neighbour = A, just computed
         a.append("v_add_u32 v%d, v%d, %%[leftcB]" % (LFB, OXA))
@@ -131,7 +141,12 @@ def block(wide, role):
         if t < 31:
             a += gain(wide, Y + t + 1, "B")
             a.append("v_add_u32 v%d, v%d, v%d" % (DGB, LFB, G))
-        a.append("v_and_b32 v%d, -4, v%d" % (OXB + t, H))
+        if ramp:
+            a.append("v_bfi_b32 v%d, v%d, v%d, %s" % (OXB + t, LM, H, prevB))
+            if t < 31:
+                a.append("v_mov_b32_dpp v%d, v%d %s" % (LM, LM, DPP))
+        else:
+            a.append("v_and_b32 v%d, -4, v%d" % (OXB + t, H))
         a.append("v_alignbit_b32 v%d, v%d, v%d, 2" % (ACCB, H, ACCB))
         if t % 4 == 3:
             a.append("ds_write_b128 %%[waddr], v[%d:%d] offset:%d" % (OXB + t - 3, OXB + t, 16 * (t // 4)))
@@ -159,6 +174,7 @@ out = ["/* GENERATED by tools/gen_cells_block.py -- do not edit.  See that file 
 for wide in (0, 1):
     for role in ("LDS", "FIRST", "RING"):
         out.append("#define CELLS_BLOCK_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(block(wide, role))))
-regs = list(range(XW, XW + 36)) + list(range(OXB, OXB + 32)) + list(range(Y, Y + 32)) + [H, G, ACCA, ACCB, DGA, DGB, OXA, LFB]
+        out.append("#define CELLS_RAMP_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(block(wide, role, True))))
+regs = list(range(XW, XW + 36)) + list(range(OXB, OXB + 32)) + list(range(Y, Y + 32)) + [H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM]
 out.append("#define CELLS_BLOCK_CLOBBERS " + ", ".join('"v%d"' % r for r in regs) + ', "memory"')
 open(sys.argv[1], "w").write("\n".join(out) + "\n")

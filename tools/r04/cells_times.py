@@ -30,11 +30,11 @@ for nrows, ncols in [(16384, 16384), (16979, 20852), (5000, 6187)]:
         pb.sync()
     t = pb.timing()
     strips = (ncols + 127) // 128
-    buf = (ctypes.c_ulonglong * (8 * strips))()
+    buf = (ctypes.c_ulonglong * (12 * strips))()
     rc = lib.csadp_debug_cell_times(buf, strips)
     assert rc == 0, rc
     pb.close()
-    rows = [buf[8 * s:8 * s + 8] for s in range(strips)]
+    rows = [buf[12 * s:12 * s + 12] for s in range(strips)]
     inwg, cross, waits_in, waits_x, durs, xsame = [], [], [], [], [], []
     for s in range(1, strips):
         lag = (rows[s][1] - rows[s - 1][1]) * 10e-3        # us between "hand-off in hand" of neighbours at the same block
@@ -60,6 +60,15 @@ for nrows, ncols in [(16384, 16384), (16979, 20852), (5000, 6187)]:
     for k, ss in kinds.items():
         print("    %-18s period %.0f clocks per block, of them the block itself %d, the wait %d" % (k, per(ss), own(ss), wt(ss)))
     print("    lag behind the left strip in us, strip by strip: " + " ".join("%.1f" % ((rows[s][1] - rows[s - 1][1]) * 10e-3) for s in range(1, min(strips, 41))))
+    us = lambda a, b: (a - b) * 10e-3
+    t0 = rows[0][8]
+    last = strips - 1
+    print("    the whole fill %.1f us: the last strip enters %.1f us after the first, passes block 2 at +%.1f, runs %.1f us (the first strip %.1f us)"
+          % (us(rows[last][9], t0), us(rows[last][8], t0), us(rows[last][10], rows[last][8]), us(rows[last][9], rows[last][8]), us(rows[0][9], t0)))
+    print("    lag at block 2 (end), strip by strip: " + " ".join("%.1f" % us(rows[s][10], rows[s - 1][10]) for s in range(1, min(strips, 41))))
+    print("    lag at the last block's end:          " + " ".join("%.1f" % us(rows[s][9], rows[s - 1][9]) for s in range(1, min(strips, 41))))
+    durs_all = [us(rows[s][9], rows[s][10]) for s in range(strips)]
+    print("    blocks 3.. of a strip take (us): first %.1f, median %.1f, max %.1f at strip %d" % (durs_all[0], med(durs_all), max(durs_all), durs_all.index(max(durs_all))))
     same = [l for l, x in zip(cross, xsame) if x]
     diff = [l for l, x in zip(cross, xsame) if not x]
     if same and diff:
