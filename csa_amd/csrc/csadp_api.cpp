@@ -563,6 +563,7 @@ static int pairs_create_io(csadp_pairbatch *b, const csadp_task *tasks, int ntas
 		b->active.push_back(t);
 	}
 	if (b->active.empty()) return CSADP_OK;
+	if (config().bits && fb.lone_pairs_take_cells()) return kNoDeviceIo;   /* a few large pairs alone: the cell-per-lane path, host I/O */
 	int rc = fb.layout();
 	if (rc != CSADP_OK) return rc;
 	if (!fb.device_io()) return kNoDeviceIo;      /* the batch did not qualify for the bit-parallel kernels */

@@ -21,6 +21,7 @@ struct Config {
 	bool lone_shape = true;         /* CSADP_LONE_SHAPE: a pass flushed alone takes the spread shape (csadp_engine.h) */
 	int stream_rotate = -1;         /* CSADP_STREAM_ROTATE: batches of one engine start on different streams (default: by batch size) */
 	int cells_fetch_wgs = 256;      /* CSADP_CELLS_FETCH: cell-per-lane launches of at most this many workgroups carry a fetcher wave (0: none) */
+	bool lone_cells = true;         /* CSADP_LONE_CELLS: at most 8 large square-ish pairs alone take the cell-per-lane path (FillBatch::layout) */
 	int slots = 4;                  /* CSADP_SLOTS: result / scratch sets of a pipelined cell-per-lane batch */
 	/* band-parallel traceback of the profile steps */
 	int tb_band_min = 512;          /* CSADP_TB_BAND_MIN: rows from which a matrix' walk is cut into bands */

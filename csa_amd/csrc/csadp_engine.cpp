@@ -332,6 +332,22 @@ int FillBatch::add(int nrows, int ncols, int nprev, int left_i)
 	return (int)jobs_.size() - 1;
 }
 
+/* A few large pairs with the device to themselves: every chain of nw_fill_cells then has its own compute units (the fetcher layout,
+ * csadp_cells.hip) and a matrix takes (rows + 0.66 cols) x 41 ns there, its band-parallel walk a fifth of the bit-parallel path's serial
+ * one -- against 86 ns per row plus 17 for the walk (tools/single_probe.py: 16 384^2 1.23 ms on the device against 1.75, 100 000^2
+ * 7.5 against 10.2).  The bit-parallel kernels are built for batches; these are not one.  (A pair's columns are its shorter sequence.) */
+bool FillBatch::lone_pairs_take_cells() const
+{
+	const Config &cfg = config();
+	if (!cfg.lone_cells || jobs_.empty() || jobs_.size() > 8) return false;
+	long chunks = 0;
+	for (const FillJob &J : jobs_) {
+		if (J.nprev != 1 || J.leftmul != 0 || J.nrows < 4096 || J.ncols > 2L * J.nrows || J.ncols <= 0) return false;
+		chunks += (J.ncols + kCellStripCols * kCellWaves - 1) / (kCellStripCols * kCellWaves);
+	}
+	return chunks <= cfg.cells_fetch_wgs;
+}
+
 int FillBatch::layout()
 {
 	Engine &E = *E_;
@@ -348,6 +364,7 @@ int FillBatch::layout()
 		for (const FillJob &J : jobs_)
 			if (J.nprev != 1 || J.leftmul != 0 || J.nrows <= 0 || J.ncols <= 0) bits_ = false;
 	}
+	if (bits_ && lone_pairs_take_cells()) bits_ = false;
 	if (bits_) return layout_bits();
 	/* every other fill (profile steps, stale borders, pairs with the bit-parallel path switched off by CSADP_BITS=0 --
 	 * the 32-bit cross-check of the bit-parallel kernels): the persistent cell-per-lane wavefront */

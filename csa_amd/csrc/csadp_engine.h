@@ -127,6 +127,7 @@ public:
 	 * two bit planes of the column letters and two of the row letters. */
 	void allow_bits(bool on) { bits_allowed_ = on; }
 	bool bits() const { return bits_; }
+	bool lone_pairs_take_cells() const;                            /* before layout(): these jobs would leave the bit-parallel path */
 	uint32_t *bit_cols(int j);         /* [2][bit_nwords(j)] */
 	int bit_nwords(int j) const;
 	uint32_t *bit_rows(int j);         /* [2][bit_rowwords(j)] */

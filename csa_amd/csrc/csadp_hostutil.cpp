@@ -192,6 +192,7 @@ Config read_config()
 	c.lone_shape = env_int("CSADP_LONE_SHAPE", 1) != 0;
 	c.stream_rotate = env_int("CSADP_STREAM_ROTATE", -1);
 	c.cells_fetch_wgs = env_int("CSADP_CELLS_FETCH", 256);
+	c.lone_cells = env_int("CSADP_LONE_CELLS", 1) != 0;
 	c.slots = env_int("CSADP_SLOTS", 4);
 	c.tb_band_min = env_int("CSADP_TB_BAND_MIN", 512);
 	c.tb_band_forced = getenv("CSADP_TB_BAND_MIN") != nullptr;

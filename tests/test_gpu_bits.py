@@ -16,6 +16,12 @@ def device():
     yield
 
 
+@pytest.fixture(autouse=True)
+def bit_parallel_path_also_for_large_pairs_alone(monkeypatch):
+    """This module tests the bit-parallel kernels: a few large pairs alone would otherwise take the cell-per-lane path (FillBatch::layout)."""
+    monkeypatch.setenv("CSADP_LONE_CELLS", "0")
+
+
 # words of 32 columns per lane: the engine picks 1, 2 or 3 by the shape of the batch (layout_bits); every test below runs with
 # each of the three kernels
 @pytest.fixture(params=["1 word", "2 words", "3 words", "4 words"])

@@ -31,6 +31,8 @@ def device():
 # matrix, a one-row one included, take the scout / resolve / emit / gather kernels, "cells" none.
 @pytest.fixture(params=["bits", "bits-hostio", "cells", "cells-banded"])
 def fill_mode(request, monkeypatch):
+    if request.param.startswith("bits"):
+        monkeypatch.setenv("CSADP_LONE_CELLS", "0")             # also for large pairs alone (FillBatch::layout would pick the cell-per-lane path)
     if request.param == "bits-hostio":
         monkeypatch.setenv("CSADP_DEVICE_IO", "0")
     elif request.param != "bits":
@@ -357,6 +359,34 @@ def test_full_size_pair_vs_oracle(fill_mode):
     g = csa_amd.align_batch([([a, b], [ra, rb], None, None)])[0]
     cons, strs, st = oracle_progressive([a, b], [ra, rb])
     assert g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
+
+
+def test_large_pairs_alone_take_either_path_with_equal_results(monkeypatch):
+    """At most 8 large square-ish pairs with the device to themselves are routed to nw_fill_cells and its band-parallel walk
+    (FillBatch::layout, CSADP_LONE_CELLS); the bit-parallel path must give the same rows: one pair and three pairs, both routes,
+    against the oracle's score (two-row fill) and string for string against each other."""
+    pairs = [synth_pair(900 + i, length=n) for i, n in enumerate((5000, 9000, 6000))]
+    tasks = [([a, b], [ra, rb], None, None) for a, b, ra, rb in pairs]
+    routed = csa_amd.align_batch(tasks[:1]) + csa_amd.align_batch(tasks)
+    monkeypatch.setenv("CSADP_LONE_CELLS", "0")
+    plain = csa_amd.align_batch(tasks[:1]) + csa_amd.align_batch(tasks)
+    for g, h, t in zip(routed, plain, tasks[:1] + tasks):
+        assert g["status"] == 0 and h["status"] == 0
+        assert g["aligned"] == h["aligned"] and g["score"] == h["score"] and g["consensus"] == h["consensus"]
+        assert g["score"] == oracle_pair_score_linear(t[0], t[1])
+    pb = csa_amd.PairBatch(tasks[:1])
+    pb.run()
+    pb.sync()
+    assert pb.timing()["words_per_lane"] > 0                      # CSADP_LONE_CELLS=0: bit-parallel
+    pb.close()
+    monkeypatch.delenv("CSADP_LONE_CELLS")
+    pb = csa_amd.PairBatch(tasks[:1])
+    pb.run()
+    pb.sync()
+    assert pb.timing()["words_per_lane"] == 0                     # routed: the cell-per-lane kernels
+    got = pb.fetch()
+    pb.close()
+    assert got[0]["aligned"] == routed[0]["aligned"]
 
 
 def test_mixed_length_batch(fill_mode):
