@@ -403,11 +403,13 @@ def profile_path_leg(csa_amd):
 
 
 def single_matrix_leg(csa_amd):
-    """Latency of ONE matrix (BASELINE config 2: a 16 kbp pair; config 5's upper end: a 200 kbp pair): device fill and
-    traceback + row expansion of a one-job batch (its strips spread over compute units, one wave per SIMD), best of 3."""
+    """Latency of ONE matrix (BASELINE config 2: a 16 kbp pair; config 5's upper end: 100 and 200 kbp pairs): device fill and
+    traceback of a one-job batch, best of 3.  A large pair alone takes the cell-per-lane kernels (every chunk of the matrix on a
+    compute unit of its own, band-parallel walk; FillBatch::lone_pairs_take_cells) while its chunks number at most 256: `path`
+    says which kernels ran (200 kbp: 391 chunks, bit-parallel)."""
     from csa_amd.synth import synth_pair
     out = {}
-    for length in (16384, 200000):
+    for length in (16384, 100000, 200000):
         a, b, ra, rb = synth_pair(777, length=length)
         pb = csa_amd.PairBatch([([a, b], [ra, rb], None, None)])
         best = None
@@ -420,7 +422,8 @@ def single_matrix_leg(csa_amd):
         pb.fetch()
         pb.close()
         out[str(length)] = {"fill_ms": round(best["fill_ms"], 3), "traceback_expand_ms": round(best["traceback_ms"], 3),
-                            "gcups": round(len(a) * len(b) / best["total_ms"] / 1e6, 1)}
+                            "gcups": round(len(a) * len(b) / best["total_ms"] / 1e6, 1),
+                            "path": "cell-per-lane" if best["words_per_lane"] == 0 else "bit-parallel"}
     return out
 
 
