@@ -577,14 +577,11 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fi
 	if (!ok && lane == 0) atomicExch(abort_word, 1);
 }
 
-hipError_t launch_fill_cells(bool wide, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch, int *abort_word,
-                             hipStream_t st)
+hipError_t launch_fill_cells(bool wide, bool fetch, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch,
+                             int *abort_word, hipStream_t st)
 {
 	if (nwork <= 0) return hipSuccess;
 	epoch &= 0xffffffu;                                /* 24 bits travel in a granule */
-	/* few workgroups (one per compute unit at most): every chain is alone on its units and the fill takes as long as its hand-offs do --
-	 * the layout with a fetcher wave (fetch_granules).  More: a compute unit holds two workgroups of four waves, but only one of five */
-	const bool fetch = nwork <= config().cells_fetch_wgs;
 	const dim3 threads((kCellWaves + (fetch ? 1 : 0)) * kLanes);
 	if (wide && fetch) hipLaunchKernelGGL((nw_fill_cells<true, true>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
 	else if (wide) hipLaunchKernelGGL((nw_fill_cells<true, false>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);

@@ -345,7 +345,7 @@ bool FillBatch::lone_pairs_take_cells() const
 		if (J.nprev != 1 || J.leftmul != 0 || J.nrows < 4096 || J.ncols > 2L * J.nrows || J.ncols <= 0) return false;
 		chunks += (J.ncols + kCellStripCols * kCellWaves - 1) / (kCellStripCols * kCellWaves);
 	}
-	return chunks <= cfg.cells_fetch_wgs;
+	return chunks <= cfg.cells_fetch_wgs;      /* (run_slot_cells: when a launch takes the fetcher layout) */
 }
 
 int FillBatch::layout()
@@ -1214,11 +1214,16 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	 * and the hand regions are zeroed when a batch is laid out (epoch 0 is never used), so whatever an
 	 * earlier pass or an earlier owner of the arena left there is never mistaken for this pass' data */
 	const uint32_t epoch = E_->next_epoch();
+	/* Few workgroups (one per compute unit at most): every chain is alone on its units and the fill takes as long as its hand-offs do --
+	 * the layout with a fetcher wave (csadp_cells.hip, fetch_granules).  More: a compute unit holds two workgroups of four waves, but
+	 * only one of five.  (ONE matrix of 391 chunks in that layout, its later chunks starting as the first ones end: a 200 kbp pair fills in
+	 * 19.15 ms, as in the plain layout, and the bit-parallel path stays ahead host to host: 20.5 against 22.3 ms.) */
+	const bool fetch = (int)tiles_.size() <= config().cells_fetch_wgs;
 	if (!serial) {
-		HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st));
+		HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st));
 	} else {
 		for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
-			HIP_TRY(launch_fill_cells(wide_, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
+			HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],
 			                          (int)(chunk_first_[c + 1] - chunk_first_[c]), epoch, abort_word, st));
 	}
 	if (!serial && test_abort_)                           /* testing: pretend a bounded wait ran out, so that the repeat path runs */
