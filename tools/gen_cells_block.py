@@ -6,6 +6,11 @@ tuples for 16-byte LDS stores and nothing depends on the compiler's register all
 A lane owns TWO adjacent columns, A (even) and B (odd), and computes both cells of a row in one step: A takes its
 left neighbour (the left lane's B) through DPP, B takes A's fresh value from a register.
 
+Instruction placement: a step is 84 bytes (five 4-byte instructions), so every second step has its 8-byte instructions at 4 mod 8.  The
+bit-parallel block gains 15 % from keeping them at 0 mod 8 (tools/gen_bits_block.py); this one gains nothing (round 4: one 4-byte
+instruction per step in its VOP3 form behind a .p2align 3 -- a strip alone 90 against 91 cycles per step, a 16 384^2 fill 1.156 against
+1.153 ms) and stays as it is.
+
 Register map (clobbered by the statement):
   v[128:163]  XW   the 9 x ds_read_b128 window of hand-off values; word 3 + t = XP(t), the lane-0 preset of
                    step t (hand-off value + leftcA), which v_add_u32_dpp turns into lfA(t) for all other lanes
