@@ -124,19 +124,21 @@ struct RingHalf {
 	const int *counter;           /* the producer's half-block counter */
 	int need1, need2;             /* its values from which the window's first / second half may be read */
 	uint32_t *cslot;              /* where THIS wave counts its own half blocks (lane 63: the counter; other lanes: scrap) */
+	uint32_t *tslot;              /* ring strips: where lane 0 says which block of its producer's ring it has taken (other lanes: scrap) */
 	int chalf;                    /* 2 b + 1 */
 };
 
-template <bool WIDE, int ROLE, bool RAMP>
+template <bool WIDE, int ROLE>
 __device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *window, int32_t xfirst, int32_t leftmul,
                                                 const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
-                                                const RingHalf &R, uint32_t lm0)
+                                                const RingHalf &R, uint32_t lm0, int bidx)
 {
 	int32_t outvA = S.A.outv, outvB = S.B.outv, dgA = S.A.diag, dgB = S.B.diag;
 	uint32_t sh = S.outs, w0A, w1A, w0B, w1B;
 	const uint32_t waddr = (uint32_t)(uintptr_t)lanebuf;       /* LDS byte address = low half of the generic pointer */
 	const uint32_t raddr = (uint32_t)(uintptr_t)window;
-	const uint32_t raddrb = (uint32_t)(uintptr_t)R.window_b, paddr = (uint32_t)(uintptr_t)R.counter, caddr = (uint32_t)(uintptr_t)R.cslot;
+	const uint32_t raddrb = (uint32_t)(uintptr_t)R.window_b, paddr = (uint32_t)(uintptr_t)R.counter, caddr = (uint32_t)(uintptr_t)R.cslot,
+	               taddr = (uint32_t)(uintptr_t)R.tslot, tval = (uint32_t)(bidx + 1);
 	const uint32_t chalf = (uint32_t)R.chalf;
 	uint32_t tmo = 0, scnt, sval, vtmp;
 	const int32_t c2A = 2 - S.A.leftc, c2B = 2 - S.B.leftc;
@@ -147,23 +149,14 @@ __device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *wi
 	: [tabA] "v"(S.A.tabf), [tabB] "v"(S.B.tabf), [leftcA] "v"(S.A.leftc), [leftcB] "v"(S.B.leftc), [c2A] "v"(c2A),           \
 	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [l0] "s"(lw[0]),            \
 	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7]),  \
-	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [lm0] "v"(lm0), [caddr] "v"(caddr), [chalf] "v"(chalf)                   \
+	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [lm0] "v"(lm0), [caddr] "v"(caddr), [chalf] "v"(chalf), [taddr] "v"(taddr), [tval] "v"(tval), [bidx] "s"(bidx) \
 	: CELLS_BLOCK_CLOBBERS, "scc"
-	if (RAMP) {
-		if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_RAMP_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
-		else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_RAMP_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
-		else if (WIDE) asm volatile(CELLS_RAMP_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
-		else if (ROLE == ROLE_FIRST) asm volatile(CELLS_RAMP_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
-		else if (ROLE == ROLE_RING) asm volatile(CELLS_RAMP_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
-		else asm volatile(CELLS_RAMP_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
-	} else {
-		if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
-		else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
-		else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
-		else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
-		else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
-		else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
-	}
+	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
+	else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
+	else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
+	else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
+	else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
+	else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
 #undef CELLS_BLOCK_OPERANDS
 	S.A.outv = S.A.hup = outvA;
 	S.B.outv = S.B.hup = outvB;
@@ -436,18 +429,17 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		const int32_t xfirst = leftmul * (b * kCellBlock + 1);     /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
 		R.cslot = (feeds && lane == kLanes - 1) ? reinterpret_cast<uint32_t *>(&L.made[wv]) : L.scrap_mine + 4 * lane;
 		R.chalf = 2 * b + 1;
-		if (b < 2) {                                            /* the ramp: lane l is live from step l on */
-			if (!cell_block_fast<WIDE, ROLE, true>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R, lane <= b * kCellBlock ? ~3u : 0u)) return false;
-		} else {
-			if (!cell_block_fast<WIDE, ROLE, false>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R, 0u)) return false;   /* the poll inside ran out */
-		}
-		if (ROLE == ROLE_RING && lane == 0)                     /* this block's ring words are in registers */
-			__hip_atomic_store(&L.taken[wv], b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		if (feeds) {
-			/* no wait: the LDS executes this wave's stores in the order they were issued, so whoever sees the
-			 * counter sees the block's ring words */
-			if (lane == kLanes - 1) __hip_atomic_store(&L.made[wv], 2 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-		}
+		R.tslot = (ROLE == ROLE_RING && lane == 0) ? reinterpret_cast<uint32_t *>(&L.taken[wv]) : L.scrap_mine + 4 * lane + 1;
+#ifdef CSADP_CELL_TIMERS
+		const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
+#endif
+		/* blocks 0 and 1 are the ramp (lane l is live from step l on: `lm0`), the statement branches on b */
+		if (!cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R, lane <= b * kCellBlock ? ~3u : 0u, b)) return false;   /* a poll inside ran out */
+#ifdef CSADP_CELL_TIMERS
+		if (timed && lane == 0) g_cell_times[12 * strip + 11] = __builtin_amdgcn_s_memtime() - ta0;     /* the statement alone */
+#endif
+		/* (`taken` = b + 1 and `made` = 2 b + 2 are stored by the statement itself, behind the block's last ring words: the LDS runs a
+		 * wave's stores in order, so whoever sees the counter sees the words) */
 		/* the block's 32 values for the next chunk: read back from the ring (in order behind the block's
 		 * stores) and sent at once -- the next chunk's first strip is waiting on them, and the LDS round trip
 		 * costs less than a block's delay does downstream (16384^2: 1.42 -> 1.40 ms) */

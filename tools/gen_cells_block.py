@@ -77,6 +77,7 @@ def ring_words(lo, hi):
 
 def block(wide, role, ramp=False):
     first = role == "FIRST"
+    tag = 3 if ramp else 1                 # numeric labels of the polls: the two bodies of a statement keep theirs apart
     a = []
     if ramp:
         a.append("v_mov_b32 v%d, %%[lm0]" % LM)
@@ -108,7 +109,7 @@ def block(wide, role, ramp=False):
     a.append("v_add_u32 v%d, %%[dgB], v%d" % (DGB, G))
     # the window has had the time of the letter work to arrive
     if role == "RING":
-        a += ring_poll("%[need1]", 0, 5, 1)
+        a += ring_poll("%[need1]", 0, 5, tag)
         for t in range(17):
             a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
     elif not first:
@@ -122,7 +123,7 @@ def block(wide, role, ramp=False):
             a.append("ds_read_b32 %[vtmp], %[paddr]")
             a += ring_words(5, 9)
         if t == 17 and role == "RING":
-            a += ring_poll("%[need2]", 5, 9, 2)
+            a += ring_poll("%[need2]", 5, 9, tag + 1)
             for u in range(17, 32):
                 a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + u, PX + u))
         if t < 31:
@@ -161,6 +162,13 @@ def block(wide, role, ramp=False):
             a.append("ds_write_b32 %[caddr], %[chalf]")
             a.append("v_mov_b32 %%[w0A], v%d" % ACCA)
             a.append("v_mov_b32 %%[w0B], v%d" % ACCB)
+    # the block's hand-off values are in the ring: the counter 2 b + 2 (lane 63 of a strip that feeds one; scrap elsewhere), and for a ring
+    # strip "block b of my producer's ring is in my registers" (lane 0; the producer may overwrite those slots) -- inside the statement:
+    # they leave a hundred cycles earlier than behind the compiler's wait for the statement's LDS traffic, and without an EXEC dance each
+    a.append("v_add_u32 %[vtmp], 1, %[chalf]")
+    a.append("ds_write_b32 %[caddr], %[vtmp]")
+    if role == "RING":
+        a.append("ds_write_b32 %[taddr], %[tval]")
     a.append("v_mov_b32 %%[w1A], v%d" % ACCA)
     a.append("v_mov_b32 %%[w1B], v%d" % ACCB)
     a.append("v_mov_b32 %%[dgA], v%d" % (PX + 31))         # D of column A for the next block: lfA of the last step
@@ -176,10 +184,16 @@ def cstring(lines):
 
 
 out = ["/* GENERATED by tools/gen_cells_block.py -- do not edit.  See that file for the register map. */"]
+def statement(wide, role):
+    """one statement per (width, role): the first two blocks of a strip take the ramp body, all later ones the plain one -- ONE statement
+    in the strip's loop, so that the lane state it carries from block to block stays in the same registers (two statements: a dozen copies
+    per block at the loop's merge points)"""
+    return ["s_cmp_gt_u32 %[bidx], 1", "s_cbranch_scc0 70f"] + block(wide, role) + ["s_branch 80f", "70:"] + block(wide, role, True) + ["80:"]
+
+
 for wide in (0, 1):
     for role in ("LDS", "FIRST", "RING"):
-        out.append("#define CELLS_BLOCK_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(block(wide, role))))
-        out.append("#define CELLS_RAMP_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(block(wide, role, True))))
+        out.append("#define CELLS_BLOCK_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(statement(wide, role))))
 regs = list(range(XW, XW + 36)) + list(range(OXB, OXB + 32)) + list(range(Y, Y + 32)) + [H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM]
 out.append("#define CELLS_BLOCK_CLOBBERS " + ", ".join('"v%d"' % r for r in regs) + ', "memory"')
 open(sys.argv[1], "w").write("\n".join(out) + "\n")

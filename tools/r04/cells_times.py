@@ -57,8 +57,9 @@ for nrows, ncols in [(16384, 16384), (16979, 20852), (5000, 6187)]:
     own = lambda ss: med([rows[s][5] - rows[s][4] for s in ss])
     wt = lambda ss: med([rows[s][4] - rows[s][3] for s in ss])
     kinds = {"first strip": [0], "first of a chunk": list(range(4, strips, 4)), "inside (ring)": [s for s in range(1, strips) if s % 4]}
+    stmt = lambda ss: med([rows[s][11] for s in ss])
     for k, ss in kinds.items():
-        print("    %-18s period %.0f clocks per block, of them the block itself %d, the wait %d" % (k, per(ss), own(ss), wt(ss)))
+        print("    %-18s period %.0f clocks per block, of them the block itself %d (the assembly statement %d), the wait %d" % (k, per(ss), own(ss), stmt(ss), wt(ss)))
     print("    lag behind the left strip in us, strip by strip: " + " ".join("%.1f" % ((rows[s][1] - rows[s - 1][1]) * 10e-3) for s in range(1, min(strips, 41))))
     us = lambda a, b: (a - b) * 10e-3
     t0 = rows[0][8]
