@@ -128,47 +128,19 @@ struct RingHalf {
 	int chalf;                    /* 2 b + 1 */
 };
 
-template <bool WIDE, int ROLE>
-__device__ __forceinline__ bool cell_block_fast(CellState &S, const uint32_t *window, int32_t xfirst, int32_t leftmul,
-                                                const uint32_t (&lw)[kCellBlock / 4], uint32_t *lanebuf, uint32_t (&words)[2][kCellBlock / 16],
-                                                const RingHalf &R, uint32_t lm0, int bidx)
-{
-	int32_t outvA = S.A.outv, outvB = S.B.outv, dgA = S.A.diag, dgB = S.B.diag;
-	uint32_t sh = S.outs, w0A, w1A, w0B, w1B;
-	const uint32_t waddr = (uint32_t)(uintptr_t)lanebuf;       /* LDS byte address = low half of the generic pointer */
-	const uint32_t raddr = (uint32_t)(uintptr_t)window;
-	const uint32_t raddrb = (uint32_t)(uintptr_t)R.window_b, paddr = (uint32_t)(uintptr_t)R.counter, caddr = (uint32_t)(uintptr_t)R.cslot,
-	               taddr = (uint32_t)(uintptr_t)R.tslot, tval = (uint32_t)(bidx + 1);
-	const uint32_t chalf = (uint32_t)R.chalf;
-	uint32_t tmo = 0, scnt, sval, vtmp;
-	const int32_t c2A = 2 - S.A.leftc, c2B = 2 - S.B.leftc;
+/* The statement's operands.  The lane state (outvA .. sh) goes in and comes out in the same registers; the block's letters are eight FIXED
+ * vector registers with the same content in every lane (v[246:253], register variables of run_strip: the statement asks for the next
+ * block's itself). */
 #define CELLS_BLOCK_OPERANDS                                                                                                   \
 	: [outvA] "+v"(outvA), [outvB] "+v"(outvB), [dgA] "+v"(dgA), [dgB] "+v"(dgB), [sh] "+v"(sh), [w0A] "=&v"(w0A),             \
 	  [w1A] "=&v"(w1A), [w0B] "=&v"(w0B), [w1B] "=&v"(w1B), [tmo] "+s"(tmo), [scnt] "=&s"(scnt), [sval] "=&s"(sval),           \
-	  [vtmp] "=&v"(vtmp)                                                                                                       \
+	  [vtmp] "=&v"(vtmp), [l0] "+v"(lt0), [l1] "+v"(lt1), [l2] "+v"(lt2), [l3] "+v"(lt3), [l4] "+v"(lt4), [l5] "+v"(lt5),      \
+	  [l6] "+v"(lt6), [l7] "+v"(lt7)                                                                                           \
 	: [tabA] "v"(S.A.tabf), [tabB] "v"(S.B.tabf), [leftcA] "v"(S.A.leftc), [leftcB] "v"(S.B.leftc), [c2A] "v"(c2A),           \
-	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [l0] "s"(lw[0]),            \
-	  [l1] "s"(lw[1]), [l2] "s"(lw[2]), [l3] "s"(lw[3]), [l4] "s"(lw[4]), [l5] "s"(lw[5]), [l6] "s"(lw[6]), [l7] "s"(lw[7]),  \
-	  [raddrb] "v"(raddrb), [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [lm0] "v"(lm0), [caddr] "v"(caddr), [chalf] "v"(chalf), [taddr] "v"(taddr), [tval] "v"(tval), [bidx] "s"(bidx) \
+	  [c2B] "v"(c2B), [waddr] "v"(waddr), [raddr] "v"(raddr), [x0] "v"(xfirst), [lm] "v"(leftmul), [raddrb] "v"(raddrb),       \
+	  [paddr] "v"(paddr), [need1] "s"(R.need1), [need2] "s"(R.need2), [lm0] "v"(lm0), [caddr] "v"(caddr), [chalf] "v"(chalf),  \
+	  [taddr] "v"(taddr), [tval] "v"(tval), [bidx] "s"(bidx), [lbase] "s"(lbase), [lvoff] "v"(loff), [young] "s"(young)                             \
 	: CELLS_BLOCK_CLOBBERS, "scc"
-	if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
-	else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
-	else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
-	else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
-	else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
-	else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
-#undef CELLS_BLOCK_OPERANDS
-	S.A.outv = S.A.hup = outvA;
-	S.B.outv = S.B.hup = outvB;
-	S.A.diag = dgA;
-	S.B.diag = dgB;
-	S.outs = sh;
-	words[0][0] = w0A;
-	words[0][1] = w1A;
-	words[1][0] = w0B;
-	words[1][1] = w1B;
-	return tmo == 0;
-}
 
 constexpr int kRingWords = kRingSteps;                     /* (round 3: + a mirror of the first two blocks; the window is read from two addresses now) */
 constexpr int kInjectWords = 40;                           /* X of step t at word 3 + t: the same 9 x 16-byte window as the ring's */
@@ -325,9 +297,16 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	 * apart from the vector memory accesses) */
 	typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
 	ConstWords rw = (ConstWords)(uintptr_t)rsh;
-	uint32_t nx[kCellBlock / 4];
-#pragma unroll
-	for (int q = 0; q < kCellBlock / 4; ++q) nx[q] = rw[q];
+	/* the block's 32 letter offsets: eight registers the statement names itself (it loads the next block's into them) */
+	register uint32_t lt0 asm("v246") = rw[0];
+	register uint32_t lt1 asm("v247") = rw[1];
+	register uint32_t lt2 asm("v248") = rw[2];
+	register uint32_t lt3 asm("v249") = rw[3];
+	register uint32_t lt4 asm("v250") = rw[4];
+	register uint32_t lt5 asm("v251") = rw[5];
+	register uint32_t lt6 asm("v252") = rw[6];
+	register uint32_t lt7 asm("v253") = rw[7];
+	const unsigned long long lbase = (unsigned long long)(uintptr_t)rsh;
 	/* ROLE_CHUNK: 8-byte granules {X, epoch << 8}, each written by ONE write-through store and valid exactly
 	 * when it carries this launch's epoch -- no counter, no fence, one memory round trip, and that one is
 	 * hidden: the granules of block b + 2 are requested while block b is computed and only re-read (bounded)
@@ -365,9 +344,6 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			tc0 = __builtin_amdgcn_s_memtime();
 		}
 #endif
-		uint32_t lw[kCellBlock / 4];
-#pragma unroll
-		for (int q = 0; q < kCellBlock / 4; ++q) lw[q] = nx[q];
 		const uint32_t *window = L.inject_mine;                 /* 16-byte aligned; X of step t at word 3 + t */
 		RingHalf R;
 		R.window_b = window;
@@ -411,8 +387,6 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			d[dirs_half] = words[1][0];
 			d[dirs_half + kLanes] = words[1][1];
 		}
-#pragma unroll
-		for (int q = 0; q < kCellBlock / 4; ++q) nx[q] = rw[(b + 1) * (kCellBlock / 4) + q];   /* rowshift is padded */
 		if (ROLE == ROLE_CHUNK) {
 			pre = 0;
 			granule_request(pre, hand_in + min((b + kGranuleAhead) * kCellBlock + 63 + t, last_granule));
@@ -426,7 +400,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
 			known_taken = __hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 		}
-		const int32_t xfirst = leftmul * (b * kCellBlock + 1);     /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
+		const int32_t xfirst0 = leftmul * (b * kCellBlock + 1);    /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
 		R.cslot = (feeds && lane == kLanes - 1) ? reinterpret_cast<uint32_t *>(&L.made[wv]) : L.scrap_mine + 4 * lane;
 		R.chalf = 2 * b + 1;
 		R.tslot = (ROLE == ROLE_RING && lane == 0) ? reinterpret_cast<uint32_t *>(&L.taken[wv]) : L.scrap_mine + 4 * lane + 1;
@@ -434,7 +408,37 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		const unsigned long long ta0 = __builtin_amdgcn_s_memtime();
 #endif
 		/* blocks 0 and 1 are the ramp (lane l is live from step l on: `lm0`), the statement branches on b */
-		if (!cell_block_fast<WIDE, ROLE>(S, window, xfirst + S.A.leftc, leftmul, lw, lanebuf, words, R, lane <= b * kCellBlock ? ~3u : 0u, b)) return false;   /* a poll inside ran out */
+		{
+			int32_t outvA = S.A.outv, outvB = S.B.outv, dgA = S.A.diag, dgB = S.B.diag;
+			uint32_t sh = S.outs, w0A, w1A, w0B, w1B;
+			const uint32_t waddr = (uint32_t)(uintptr_t)lanebuf;       /* LDS byte address = low half of the generic pointer */
+			const uint32_t raddr = (uint32_t)(uintptr_t)window;
+			const uint32_t raddrb = (uint32_t)(uintptr_t)R.window_b, paddr = (uint32_t)(uintptr_t)R.counter, caddr = (uint32_t)(uintptr_t)R.cslot,
+			               taddr = (uint32_t)(uintptr_t)R.tslot, tval = (uint32_t)(b + 1), chalf = (uint32_t)R.chalf;
+			const uint32_t lm0 = lane <= b * kCellBlock ? ~3u : 0u;
+			const uint32_t loff = (uint32_t)(b + 1) * kCellBlock;      /* bytes: the next block's letters (the row table is padded) */
+			const int bidx = b;
+			const int young = __builtin_amdgcn_readfirstlane(4 + (publishes ? 1 : 0) + (ROLE == ROLE_CHUNK ? 1 : 0));   /* vector memory instructions between two statements */
+			const int32_t xfirst = xfirst0 + S.A.leftc;
+			uint32_t tmo = 0, scnt, sval, vtmp;
+			const int32_t c2A = 2 - S.A.leftc, c2B = 2 - S.B.leftc;
+			if (WIDE && ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_WIDE_FIRST CELLS_BLOCK_OPERANDS);
+			else if (WIDE && ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_WIDE_RING CELLS_BLOCK_OPERANDS);
+			else if (WIDE) asm volatile(CELLS_BLOCK_ASM_WIDE_LDS CELLS_BLOCK_OPERANDS);
+			else if (ROLE == ROLE_FIRST) asm volatile(CELLS_BLOCK_ASM_BYTE_FIRST CELLS_BLOCK_OPERANDS);
+			else if (ROLE == ROLE_RING) asm volatile(CELLS_BLOCK_ASM_BYTE_RING CELLS_BLOCK_OPERANDS);
+			else asm volatile(CELLS_BLOCK_ASM_BYTE_LDS CELLS_BLOCK_OPERANDS);
+			S.A.outv = S.A.hup = outvA;
+			S.B.outv = S.B.hup = outvB;
+			S.A.diag = dgA;
+			S.B.diag = dgB;
+			S.outs = sh;
+			words[0][0] = w0A;
+			words[0][1] = w1A;
+			words[1][0] = w0B;
+			words[1][1] = w1B;
+			if (tmo != 0) return false;                             /* a poll inside ran out */
+		}
 #ifdef CSADP_CELL_TIMERS
 		if (timed && lane == 0) g_cell_times[12 * strip + 11] = __builtin_amdgcn_s_memtime() - ta0;     /* the statement alone */
 #endif

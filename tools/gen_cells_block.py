@@ -27,6 +27,7 @@ import sys
 
 XW, OXB, Y = 128, 168, 200
 H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM = 236, 237, 238, 239, 240, 241, 242, 243, 244
+LT = 246        # v[246:253] (tuples start at even registers): the block's 32 letter offsets, the same in every lane (operands of the statement, pinned by register variables)
 PX = XW + 3
 DPP = "wave_shr:1 row_mask:0xf bank_mask:0xf"
 
@@ -97,7 +98,7 @@ def block(wide, role, ramp=False):
             a.append("ds_read_b128 v[%d:%d], %%[raddr] offset:%d" % (XW + 4 * q, XW + 4 * q + 3, 16 * q))
     # lane-0 letter offsets of the block's 32 rows: the bytes of eight scalar registers
     for t in range(32):
-        a.append("v_bfe_u32 v%d, %%[l%d], %d, 8" % (Y + t, t // 4, 8 * (t % 4)))
+        a.append("v_bfe_u32 v%d, v%d, %d, 8" % (Y + t, LT + t // 4, 8 * (t % 4)))
     a.append("v_mov_b32 v%d, 0" % ACCA)
     a.append("v_mov_b32 v%d, 0" % ACCB)
     a.append("v_mov_b32 v%d, %%[outvA]" % OXA)
@@ -122,6 +123,13 @@ def block(wide, role, ramp=False):
             # the second half is asked for five steps before it is needed (the counter in front of it)
             a.append("ds_read_b32 %[vtmp], %[paddr]")
             a += ring_words(5, 9)
+        if t == 18:
+            # the next block's letters: asked for here (what the load overwrites was last read at the head of the block), waited for at the
+            # head of the next statement -- every lane loads the same 32 bytes.  (Scalar loads share their counter with the LDS and return
+            # out of order: the compiler waited lgkmcnt(0) three times per block for them; as loop-carried scalar operands of the
+            # statement they do not compile -- the loop has divergent exits)
+            a.append("global_load_dwordx4 v[%d:%d], %%[lvoff], %%[lbase]" % (LT, LT + 3))
+            a.append("global_load_dwordx4 v[%d:%d], %%[lvoff], %%[lbase] offset:16" % (LT + 4, LT + 7))
         if t == 17 and role == "RING":
             a += ring_poll("%[need2]", 5, 9, tag + 1)
             for u in range(17, 32):
@@ -188,7 +196,10 @@ def statement(wide, role):
     """one statement per (width, role): the first two blocks of a strip take the ramp body, all later ones the plain one -- ONE statement
     in the strip's loop, so that the lane state it carries from block to block stays in the same registers (two statements: a dozen copies
     per block at the loop's merge points)"""
-    return ["s_cmp_gt_u32 %[bidx], 1", "s_cbranch_scc0 70f"] + block(wide, role) + ["s_branch 80f", "70:"] + block(wide, role, True) + ["80:"]
+    # the letters were asked for at step 18 of the previous block; since then this wave has issued %[young] = 4 (direction words) or 5 (+ a
+    # hand-off granule store or request) vector memory instructions, which need not have finished
+    head = ["s_cmp_eq_u32 %[young], 5", "s_cbranch_scc1 85f", "s_waitcnt vmcnt(4)", "s_branch 86f", "85:", "s_waitcnt vmcnt(5)", "86:"]
+    return head + ["s_cmp_gt_u32 %[bidx], 1", "s_cbranch_scc0 70f"] + block(wide, role) + ["s_branch 80f", "70:"] + block(wide, role, True) + ["80:"]
 
 
 for wide in (0, 1):
