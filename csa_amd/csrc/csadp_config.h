@@ -26,7 +26,8 @@ struct Config {
 	/* band-parallel traceback of the profile steps */
 	int tb_band_min = 512;          /* CSADP_TB_BAND_MIN: rows from which a matrix' walk is cut into bands */
 	bool tb_band_forced = false;    /* ... was set explicitly (then also for matrices more than twice as wide as high) */
-	int tb_corridor = 3;            /* CSADP_TB_CORRIDOR: groups of 1024 start columns scouted per band */
+	int tb_corridor = 3;            /* CSADP_TB_CORRIDOR: groups of 1024 start columns scouted per band (at least; more while the scouts fit the chip) */
+	bool tb_corridor_forced = false; /* ... was set explicitly: exactly that many */
 	bool pull_uploads = true;       /* CSADP_PULL_UPLOADS: a round's tables are pulled from pinned memory by a kernel */
 	/* host */
 	int round_groups = 2;           /* CSADP_ROUND_GROUPS: task groups whose lock-step rounds run side by side */

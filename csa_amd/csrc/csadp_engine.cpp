@@ -390,6 +390,7 @@ int FillBatch::layout_cells()
 	const bool band_forced = cfg.tb_band_forced;
 	const int tb_corridor = cfg.tb_corridor;                      /* groups of 1024 start columns scouted per band */
 	tb_max_bands_ = tb_max_groups_ = 0;
+	long banded_bands = 0;                                        /* bands of all banded jobs: the scouts' workgroups per corridor group */
 	cjobs_.assign((size_t)nj, CellJob());
 	tiles_.clear();
 	diag_off_.assign(2, 0);                       /* "one launch" for timing() */
@@ -417,17 +418,28 @@ int FillBatch::layout_cells()
 		 * them would be walked twice -- one serial walk then, unless the tests ask for bands) */
 		C.banded = (J.nrows >= band_min && (band_forced || J.ncols <= 2 * J.nrows)) ? 1 : 0;
 		if (C.banded) {
-			const int ngroups = (J.ncols / kBandStride + 1 + kScoutStarts - 1) / kScoutStarts;
-			/* at most as many groups as let one band's table row fit the resolve kernel's LDS table (64 KiB of u16) */
-			C.tb_groups = std::min(std::min(ngroups, std::max(1, tb_corridor)), 64 * 1024 / 2 / kScoutStarts);
-			C.tb_pitch = C.tb_groups * kScoutStarts;
 			tb_max_bands_ = std::max(tb_max_bands_, C.nbands);
-			tb_max_groups_ = std::max(tb_max_groups_, C.tb_groups);
+			banded_bands += C.nbands;
 		}
 		extra_[(size_t)j].ncols_pad = C.nstrips * kCellStripCols;
 		cells_ += (long long)J.nrows * J.ncols;
 		dir_bytes_ += (long long)C.nstrips * kCellCols * (C.steps_pad / 16) * kLanes * 4;
 		border_bytes_ += (long long)std::max(C.nchunks - 1, 0) * C.steps_pad * 8 * 2;      /* written once, read once */
+	}
+	/* The corridor of start columns the scouts cover per band (groups of 1024 columns around the straight line between the matrix' corners):
+	 * `tb_corridor` groups, and more while the scouts of the whole batch still fit ONE workgroup per compute unit -- a wider corridor then
+	 * costs no time, and a path that leaves the corridor costs a serial walk of every band from there on (one round of Mammals: 0.40 ms in
+	 * nw_tb_resolve with three groups of seven scouted).  CSADP_TB_CORRIDOR set explicitly is taken as it is. */
+	for (int j = 0; j < nj; ++j) {
+		CellJob &C = cjobs_[(size_t)j];
+		if (!C.banded) continue;
+		const int ngroups = (C.ncols / kBandStride + 1 + kScoutStarts - 1) / kScoutStarts;
+		int want = std::max(1, tb_corridor);
+		if (!cfg.tb_corridor_forced) want = std::max(want, (int)(256 / std::max(1L, banded_bands)));
+		/* at most as many groups as let one band's table row fit the resolve kernel's LDS table (64 KiB of u16) */
+		C.tb_groups = std::min(std::min(ngroups, want), 64 * 1024 / 2 / kScoutStarts);
+		C.tb_pitch = C.tb_groups * kScoutStarts;
+		tb_max_groups_ = std::max(tb_max_groups_, C.tb_groups);
 	}
 	{
 		std::vector<int> order((size_t)nj);

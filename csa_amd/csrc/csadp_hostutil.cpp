@@ -197,6 +197,7 @@ Config read_config()
 	c.tb_band_min = env_int("CSADP_TB_BAND_MIN", 512);
 	c.tb_band_forced = getenv("CSADP_TB_BAND_MIN") != nullptr;
 	c.tb_corridor = env_int("CSADP_TB_CORRIDOR", 3);
+	c.tb_corridor_forced = getenv("CSADP_TB_CORRIDOR") != nullptr;
 	c.pull_uploads = env_int("CSADP_PULL_UPLOADS", 1) != 0;
 	c.round_groups = env_int("CSADP_ROUND_GROUPS", 2);
 	c.refine_speculate = env_int("CSADP_REFINE_SPECULATE", 0);
