@@ -189,10 +189,12 @@ __device__ unsigned long long g_cell_times[8192 * 12];   /* + [8] entry of block
 __device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in, uint32_t *ring0, int *made0, const int *taken0, int nb,
                                                uint32_t epoch, int lane)
 {
-	const uint32_t rlane = (uint32_t)(uintptr_t)(ring0 + (lane & (kCellBlock - 1)));     /* lanes 32..63 repeat lanes 0..31 */
+	constexpr int kHalf = kCellBlock / 2;                     /* the unit of a hand-off through memory: the 16 granules of HALF a block (publish_halves) */
+	const uint32_t rlane = (uint32_t)(uintptr_t)(ring0 + (lane & (kHalf - 1)));         /* lanes 16..63 repeat lanes 0..15 */
 	const uint32_t faddr = (uint32_t)(uintptr_t)made0, taddr = (uint32_t)(uintptr_t)taken0;
 	const uint32_t epsh = epoch << 8;
-	uint32_t voff = (uint32_t)(lane & (kCellBlock - 1)) * 8u;
+	uint32_t voff = (uint32_t)(lane & (kHalf - 1)) * 8u;
+	const int nhalves = 2 * nb;
 	uint32_t tmo = 0, k, tag, scnt, st, sv;
 	unsigned long long sx;
 	/* v[100:107]: the four requests; v108: the block's 32 values; v109: scratch.  A request that lands after its block was delivered carries the
@@ -202,11 +204,12 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in
 	"s_waitcnt vmcnt(3)\n\t"                                                                                                   \
 	"v_cmp_ne_u32 vcc, %[tag], v" #HI "\n\t"                                                                                   \
 	"s_cbranch_vccz " #FOUND "f\n\t"
-	/* block k is in v<LO>: wait for its ring slots (they last held block k - kRing, which the strip has in registers once taken0 >= k - kRing),
-	 * store the values, then the counter 2 k + 2 from lane 0 alone (the LDS runs a wave's stores in order); next block */
+	/* half block k (block k >> 1) is in v<LO>: wait for its ring slots (they last held block (k >> 1) - kRing, which the strip has in registers
+	 * once taken0 >= (k >> 1) - kRing), store the values, then the counter k + 1 from lane 0 alone (the LDS runs a wave's stores in order); next */
 #define CSADP_FETCH_DELIVER(LO, L1, L2, BACK)                                                                                  \
 	"v_mov_b32 v108, v" #LO "\n\t"                                                                                             \
-	"s_sub_u32 %[st], %[k], %[ring]\n\t"                                                                                       \
+	"s_lshr_b32 %[st], %[k], 1\n\t"                                                                                            \
+	"s_sub_u32 %[st], %[st], %[ring]\n\t"                                                                                      \
 	"s_cmp_le_i32 %[st], 0\n\t"                                                                                                \
 	"s_cbranch_scc1 " #L2 "f\n\t"                                                                                              \
 	#L1 ":\n\t"                                                                                                                \
@@ -223,11 +226,10 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in
 	"s_branch 9f\n\t"                                                                                                          \
 	#L2 ":\n\t"                                                                                                                \
 	"s_and_b32 %[st], %[k], %[ringm]\n\t"                                                                                      \
-	"s_lshl_b32 %[st], %[st], 7\n\t"                                                                                           \
+	"s_lshl_b32 %[st], %[st], 6\n\t"                                                                                           \
 	"v_add_u32 v109, %[st], %[rlane]\n\t"                                                                                      \
 	"ds_write_b32 v109, v108\n\t"                                                                                              \
-	"s_lshl_b32 %[st], %[k], 1\n\t"                                                                                            \
-	"s_add_u32 %[st], %[st], 2\n\t"                                                                                            \
+"s_add_u32 %[st], %[k], 1\n\t"                                                                                             \
 	"v_mov_b32 v109, %[st]\n\t"                                                                                                \
 	"s_mov_b64 %[sx], exec\n\t"                                                                                                \
 	"s_mov_b64 exec, 1\n\t"                                                                                                    \
@@ -236,7 +238,7 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in
 	"s_add_u32 %[k], %[k], 1\n\t"                                                                                              \
 	"s_cmp_ge_u32 %[k], %[nb]\n\t"                                                                                             \
 	"s_cbranch_scc1 9f\n\t"                                                                                                    \
-	"v_add_u32 %[voff], 0x100, %[voff]\n\t"                                                                                    \
+	"v_add_u32 %[voff], 0x80, %[voff]\n\t"                                                                                     \
 	"s_and_b32 %[st], %[k], 0xff\n\t"                                                                                          \
 	"s_or_b32 %[tag], %[epsh], %[st]\n\t"                                                                                      \
 	"s_mov_b32 %[scnt], 0x80000\n\t"                                                                                           \
@@ -267,13 +269,44 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in
 	    "9:\n\t"
 	    "s_waitcnt vmcnt(0)\n\t"                                /* requests still on their way to v100..v107 */
 	    : [tmo] "+s"(tmo), [voff] "+v"(voff), [k] "=&s"(k), [tag] "=&s"(tag), [scnt] "=&s"(scnt), [st] "=&s"(st), [sv] "=&s"(sv), [sx] "=&s"(sx)
-	    : [base] "s"(hand_in), [epsh] "s"(epsh), [nb] "s"(nb), [rlane] "v"(rlane), [faddr] "v"(faddr), [taddr] "v"(taddr), [ring] "n"(kRing),
-	      [ringm] "n"(kRing - 1)
+	    : [base] "s"(hand_in), [epsh] "s"(epsh), [nb] "s"(nhalves), [rlane] "v"(rlane), [faddr] "v"(faddr), [taddr] "v"(taddr), [ring] "n"(kRing),
+	      [ringm] "n"(2 * kRing - 1)
 	    : "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "vcc", "scc", "memory");
 #undef CSADP_FETCH_ASK
 #undef CSADP_FETCH_LOOK
 #undef CSADP_FETCH_DELIVER
 	return tmo == 0;
+}
+
+/*
+ * The publisher of a chunked job's workgroup (the same launches): a SIXTH wave that sends the last strip's hand-off values to the next chunk,
+ * HALF a block at a time -- it follows that strip's half-block counter like a fifth strip would and tells it through `taken` which blocks
+ * of its ring are out.  The strip itself then publishes nothing (in the plain layout it reads its ring back and stores 32 granules behind
+ * every block), and the next chunk's fetcher sees the first half of a block half a block earlier: two and a half blocks plus a trip
+ * between workgroups, as inside one.  Granule = {X, epoch << 8 | half-block number & 255}.  It sleeps between looks (it shares a SIMD
+ * with a strip: a look is two vector instructions).
+ */
+__device__ __forceinline__ bool publish_halves(unsigned long long *hand_out, const uint32_t *ring_last, const int *made_last, int *taken_pub, int nb,
+                                               uint32_t epoch, int lane)
+{
+	constexpr int kHalf = kCellBlock / 2;
+	for (int h = 0; h < 2 * nb; ++h) {
+		if (__hip_atomic_load(made_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < h + 1) {
+			const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+			int spins = 0;
+			while (__hip_atomic_load(made_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < h + 1) {
+				__builtin_amdgcn_s_sleep(3);
+				if ((++spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
+			}
+		}
+		const uint32_t x = ring_last[(h * kHalf) % kRingSteps + (lane & (kHalf - 1))];
+		if (lane < kHalf)
+			__hip_atomic_store(hand_out + h * kHalf + lane, (unsigned long long)x | ((unsigned long long)((epoch << 8) | (uint32_t)(h & 255)) << 32),
+			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		/* (the store has the values in registers: the strip may overwrite the block's ring slots) */
+		if ((h & 1) && lane == 0) __hip_atomic_store(taken_pub, (h >> 1) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+	}
+	return true;
 }
 
 struct StripShared {
@@ -490,7 +523,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 }  // namespace
 
 template <bool WIDE, bool FETCH>
-__global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
+__global__ __launch_bounds__((kCellWaves + (FETCH ? 2 : 0)) * kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
                                                                     const TileRef *__restrict__ work, uint32_t epoch,
                                                                     int *__restrict__ abort_word)
 {
@@ -500,7 +533,8 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fi
 	__shared__ __attribute__((aligned(16))) uint32_t ring[kCellWaves + 1][4 + kRingWords];
 	__shared__ __attribute__((aligned(16))) uint32_t inject[kCellWaves][kInjectWords];
 	__shared__ __attribute__((aligned(16))) uint32_t scrap[kCellWaves][kScrapWords];
-	__shared__ int made[kCellWaves + 1], taken[kCellWaves];        /* made[1 + wv]: strip wv's half blocks; made[0]: the fetcher's */
+	__shared__ int made[kCellWaves + 1], taken[kCellWaves + 1];    /* made[1 + wv]: strip wv's half blocks, made[0]: the fetcher's; taken[wv]: blocks strip wv has
+	                                                                * taken from its producer's ring, taken[kCellWaves]: the publisher's from the last strip's */
 
 	const TileRef item = work[blockIdx.x];
 	const CellJob &J = jobs[item.job];
@@ -509,7 +543,7 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fi
 	const int s = chunk * kCellWaves + wv;                    /* this wave's strip */
 	if (threadIdx.x <= kCellWaves) {
 		made[threadIdx.x] = 0;
-		if (threadIdx.x < kCellWaves) taken[threadIdx.x] = 0;
+		taken[threadIdx.x] = 0;
 	}
 	__syncthreads();
 	const int nb = J.steps_pad / kCellBlock;
@@ -517,6 +551,12 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fi
 		if (chunk == 0 || chunk * kCellWaves >= J.nstrips) return;
 		const unsigned long long *from = reinterpret_cast<const unsigned long long *>(arena + J.hand) + (size_t)(chunk - 1) * J.steps_pad;
 		if (!fetch_granules(from, ring[0] + 4, &made[0], &taken[0], nb, epoch, lane) && lane == 0) atomicExch(abort_word, 1);
+		return;
+	}
+	if (FETCH && wv == kCellWaves + 1) {                      /* the publisher: the chunk's last strip hands on to a next chunk */
+		if ((chunk + 1) * kCellWaves >= J.nstrips) return;
+		unsigned long long *to = reinterpret_cast<unsigned long long *>(arena + J.hand) + (size_t)chunk * J.steps_pad;
+		if (!publish_halves(to, ring[kCellWaves] + 4, &made[kCellWaves], &taken[kCellWaves], nb, epoch, lane) && lane == 0) atomicExch(abort_word, 1);
 		return;
 	}
 	if (s >= J.nstrips) return;
@@ -532,8 +572,9 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 1 : 0)) * kLanes) void nw_fi
 	unsigned long long *hand_out = reinterpret_cast<unsigned long long *>(arena + J.hand) + (size_t)chunk * J.steps_pad;
 	const unsigned long long *hand_in =
 	    reinterpret_cast<const unsigned long long *>(arena + J.hand) + (size_t)(chunk > 0 ? chunk - 1 : 0) * J.steps_pad;
-	const bool feeds = wv + 1 < kCellWaves && s + 1 < J.nstrips;        /* a wave of this workgroup reads my ring */
-	const bool publishes = wv + 1 == kCellWaves && s + 1 < J.nstrips;   /* the next chunk reads my hand-off words  */
+	/* a wave of this workgroup reads my ring: the next strip, or (FETCH) the publisher behind the last strip */
+	const bool feeds = s + 1 < J.nstrips && (wv + 1 < kCellWaves || FETCH);
+	const bool publishes = !FETCH && wv + 1 == kCellWaves && s + 1 < J.nstrips;   /* plain layout: the last strip sends its hand-off words itself */
 
 	CellState S;
 	S.A.tab = coltab[col];
@@ -578,7 +619,7 @@ hipError_t launch_fill_cells(bool wide, bool fetch, uint8_t *arena, const CellJo
 {
 	if (nwork <= 0) return hipSuccess;
 	epoch &= 0xffffffu;                                /* 24 bits travel in a granule */
-	const dim3 threads((kCellWaves + (fetch ? 1 : 0)) * kLanes);
+	const dim3 threads((kCellWaves + (fetch ? 2 : 0)) * kLanes);
 	if (wide && fetch) hipLaunchKernelGGL((nw_fill_cells<true, true>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
 	else if (wide) hipLaunchKernelGGL((nw_fill_cells<true, false>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
 	else if (fetch) hipLaunchKernelGGL((nw_fill_cells<false, true>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
