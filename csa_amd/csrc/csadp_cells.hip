@@ -176,8 +176,8 @@ __device__ unsigned long long g_cell_times[8192 * 12];   /* + [8] entry of block
 
 /*
  * The fetcher of a chunked job's workgroup (launches of few workgroups: one per compute unit, launch_fill_cells): a FIFTH wave that does
- * nothing but bring the previous chunk's hand-off granules in.  It keeps FOUR requests for the block's 32 granules in flight, a quarter of a
- * round trip apart, looks at each as it lands and asks again; the first sample in which all 32 carry this launch's epoch AND the block's number goes into ring 0 of
+ * nothing but bring the previous chunk's hand-off granules in, half a block (16 granules: publish_halves below) at a time.  It keeps FOUR requests for them in flight, a quarter of a
+ * round trip apart, looks at each as it lands and asks again; the first sample in which all 16 carry this launch's epoch AND the half block's number goes into ring 0 of
  * the workgroup, the half-block counter behind it -- the chunk's first strip is then a strip like every other (ROLE_RING: LDS window in two
  * halves, its poll inside the generated block) and sees a block of its producer one trip through memory after that was published.  Without
  * it (ROLE_CHUNK below) the strip asks for its granules itself, a block or two ahead: it cannot ask while it computes, so it settles as far

@@ -1227,8 +1227,8 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	 * earlier pass or an earlier owner of the arena left there is never mistaken for this pass' data */
 	const uint32_t epoch = E_->next_epoch();
 	/* Few workgroups (one per compute unit at most): every chain is alone on its units and the fill takes as long as its hand-offs do --
-	 * the layout with a fetcher wave (csadp_cells.hip, fetch_granules).  More: a compute unit holds two workgroups of four waves, but
-	 * only one of five.  (ONE matrix of 391 chunks in that layout, its later chunks starting as the first ones end: a 200 kbp pair fills in
+	 * the layout with a fetcher and a publisher wave (csadp_cells.hip, fetch_granules, publish_halves).  More: a compute unit holds two
+	 * workgroups of four waves, but only one of six.  (ONE matrix of 391 chunks in that layout, its later chunks starting as the first ones end: a 200 kbp pair fills in
 	 * 19.15 ms, as in the plain layout, and the bit-parallel path stays ahead host to host: 20.5 against 22.3 ms.) */
 	const bool fetch = (int)tiles_.size() <= config().cells_fetch_wgs;
 	if (!serial) {
