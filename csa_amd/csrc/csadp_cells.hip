@@ -3,7 +3,8 @@
  * stale borders included) as a persistent cell-per-lane wavefront, and its direction walk
  * (dynamicprogramming.c:1037-1047).  gfx950, wave64.
  *
- *   nw_fill_cells<WIDE>    K1c: a lane owns two adjacent columns, a wave 128, a workgroup kCellWaves strips
+ *   nw_fill_cells<WIDE, FETCH>   K1c: a lane owns two adjacent columns, a wave 128, a workgroup kCellWaves strips
+ *                                (FETCH: + two helper waves for the hand-off between workgroups, launches of few workgroups)
  *   (the direction walk over K1c's tags: csadp_cells_tb.hip)
  *
  * Why this shape.  The reference's own use of the DP (mode N) is a handful of wide gaps, each a chain
@@ -11,7 +12,7 @@
  * critical path is its nrows + ncols anti-diagonals.  The tiled kernel (csadp_kernels.hip) gives a
  * lane 16 columns x 2 rows per step -- ~200 instructions -- and needs nrows/2 + ncols/16 such steps
  * and a launch per tile anti-diagonal; here a step is ONE row of the lane's two columns (13 VALU
- * instructions in the hand-scheduled blocks, see cell_block_fast) and a matrix takes nrows + ncols / 2 of
+ * instructions in the generated statement, csadp_cells_block.inc) and a matrix takes nrows + ncols / 2 of
  * them, on one wave per SIMD so that nothing else competes for the issue slot.
  * Gain form and tie-break as in csadp_device.h: X = 4*H + 4*i*r, candidates tagged U 0 / L 1 / D 2,
  * one v_max3_i32 yields the reference's H and the reference's direction (D >= L >= U, :1014-1025).
@@ -23,8 +24,11 @@
  * the previous strip's lane 63 left in the LDS ring 63 steps earlier (same workgroup; counted in HALF blocks
  * since round 4: a strip follows its neighbour at 80 steps, not 96 -- RingHalf below), or from `hand`
  * in HBM (previous chunk: 8-byte granules tagged with the launch's epoch, written through by one store
- * each and requested two blocks ahead by the consumer -- no counter, no fence); the LETTER offsets of a
- * block's rows it reads from the row table itself (scalar loads), whatever the strip.  Directions:
+ * each -- no counter, no fence.  FETCH layout: a publisher wave sends them half a block at a time and a
+ * fetcher wave of the next workgroup polls them into an LDS ring the chunk's first strip reads like any
+ * other; plain layout: the last strip stores them itself and the next chunk's first strip requests them two
+ * blocks ahead); the LETTER offsets of a block's rows every strip takes from the row table itself (eight
+ * vector registers, reloaded by the statement).  Directions:
  * 16 steps of 2-bit tags per word and lane, one coalesced 256-byte store per wave every 16 steps =
  * 0.25 B/cell, the algorithmic figure of SURVEY 8(d).
  *
