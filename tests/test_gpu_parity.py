@@ -169,18 +169,20 @@ def test_cells_kernel_hand_off_between_workgroups_in_both_layouts(layout, monkey
     for length in (500, 513, 1025, 1600, 2049):
         fam = random_family(r, 3, length, mut=0.1, indel=0.04)
         tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    wide = random_family(r, 24, 1100, mut=0.05, indel=0.02)    # steps 22 and 23 take the 6-bit-count statement (WIDE) over three chunks
+    tasks.append((wide, [r.randrange(len(f)) for f in wide], None, None))
     for ncols, nrows in ((1500, 9000), (9000, 1500), (700, 40), (40, 700)):
         base = bytes(r.choice(b"ACGT") for _ in range(max(ncols, nrows)))
         a = base[:ncols]
         b = bytes(c if r.random() > 0.1 else r.choice(b"ACGT") for c in base[:nrows])
         tasks.append(([a, b], [r.randrange(len(a)), r.randrange(len(b))], None, None))
     got = csa_amd.align_batch(tasks)
-    alone = csa_amd.align_batch(tasks[5:6])[0]                 # one matrix alone: 3 workgroups, every chain on its own units
+    alone = csa_amd.align_batch(tasks[6:7])[0]                 # one matrix alone: 3 workgroups, every chain on its own units
     for t, g in zip(tasks, got):
         cons, strs, st = oracle_progressive(t[0], t[1])
         assert g["status"] == 0 and g["consensus"] == cons
         assert g["aligned"] == strs and g["score"] == st.last_score
-    assert alone["aligned"] == got[5]["aligned"] and alone["score"] == got[5]["score"]
+    assert alone["aligned"] == got[6]["aligned"] and alone["score"] == got[6]["score"]
 
 
 def test_cells_kernel_paths_that_leave_the_traceback_window(profile_mode):
