@@ -303,6 +303,7 @@ __device__ __forceinline__ bool publish_halves(unsigned long long *hand_out, con
 				if ((++spins & 255) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > kSpinTicks) return false;
 			}
 		}
+		asm volatile("" ::: "memory");                          /* the compiler must not read the ring before the counter (the LDS itself runs a wave's reads in order) */
 		const uint32_t x = ring_last[(h * kHalf) % kRingSteps + (lane & (kHalf - 1))];
 		if (lane < kHalf)
 			__hip_atomic_store(hand_out + h * kHalf + lane, (unsigned long long)x | ((unsigned long long)((epoch << 8) | (uint32_t)(h & 255)) << 32),
