@@ -175,12 +175,7 @@ def cpu_baseline(tasks, gpu_results, seconds_budget=25.0):
     the compiled reference (oracle/_ref, kind 'reference') when its prebuilt library
     travelled with the repo, else the oracle port.  Also cross-checks the GPU strings."""
     from helpers import have_ref, oracle_progressive, ref_progressive
-    try:  # keep freed matrix pages in the heap between calls (glibc would unmap and re-fault 1.4 GB per pair)
-        libc = ctypes.CDLL("libc.so.6")
-        libc.mallopt(-1, 1 << 30)   # M_TRIM_THRESHOLD
-        libc.mallopt(-3, 1 << 25)   # M_MMAP_THRESHOLD (32 MiB is the glibc maximum)
-    except Exception:
-        pass
+    keep_heap()   # freed matrix pages stay in the heap between calls (glibc would unmap and re-fault 1.4 GB per pair)
     kind = "reference" if have_ref() else "port"
     run = ref_progressive if kind == "reference" else (lambda t, r: oracle_progressive(t, r))
     cells = 0
@@ -377,17 +372,33 @@ def unrelated_leg(csa_amd, steps=20, warmup=5):
             "what": "64 unrelated random 16384-letter pairs (tests/test_gpu_parity.py holds their scores to the oracle's optimum)"}
 
 
+def keep_heap():
+    """glibc maps and unmaps every vector of more than 128 KB: the host stages of mode N (suffix automata of a few MB per sequence) and the
+    CPU baseline (1.4 GB of matrices per pair) re-fault their pages at every call.  A program that calls them in a loop keeps the heap
+    (INTEGRATION.md, section 2); the library itself leaves the process' malloc settings alone."""
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-1, 1 << 30)   # M_TRIM_THRESHOLD
+        libc.mallopt(-3, 1 << 25)   # M_MMAP_THRESHOLD (32 MiB is the glibc maximum)
+        return True
+    except Exception:
+        return False
+
+
 def profile_path_leg(csa_amd):
     """The reference's OWN use of ProgressiveDP (mode N): sequence-vs-profile fills (i up to 18) of the
-    example sets through csadp_msa -- one device batch per set, lock-step rounds.  Best of 3 warm calls."""
+    example sets through csadp_msa -- one device batch per set, lock-step rounds.  Best of 3 warm calls (by DP time; `total_ms_best` = the
+    shortest whole call of the three)."""
     from helpers import GOLDEN, read_fasta
     out = {}
+    kept = keep_heap()
     for name in ("Primates", "Mammals", "Set3"):
         path = os.path.join(GOLDEN, "data", name + ".txt")
         if not os.path.exists(path):
             continue
         _, seqs = read_fasta(path)
         best = None
+        walls = []
         for _ in range(3):
             t0 = time.perf_counter()
             rc, rot, rows, st = csa_amd.msa(seqs)
@@ -395,10 +406,14 @@ def profile_path_leg(csa_amd):
             if rc != 0:
                 best = None
                 break
+            walls.append(wall)
             if best is None or st["dp_ms"] < best["dp_ms"]:
                 best = {"dp_ms": round(st["dp_ms"], 2), "total_ms": round(wall * 1e3, 1), "fills": st["fills"],
                         "gaps": st["dp_gaps"], "cells": st["cells"], "gcups": round(st["cells"] / st["dp_ms"] / 1e6, 1)}
+        if best is not None:
+            best["total_ms_best"] = round(min(walls) * 1e3, 1)
         out[name] = best
+    out["host_heap"] = "kept (mallopt M_TRIM_THRESHOLD 1 GiB, M_MMAP_THRESHOLD 32 MiB in this process)" if kept else "glibc defaults"
     return out
 
 
