@@ -252,18 +252,30 @@ int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Bor
 		int first0;
 	};
 	std::vector<Group> groups;
-	for (size_t i = 0; i < credits.size();) {
-		size_t j = i;
-		int seen = 0, prev = -1;
-		while (j < credits.size() && credits[j].key == credits[i].key) {
-			if (credits[j].seq != prev) {
-				++seen;
-				prev = credits[j].seq;
+	{
+		/* runs of equal keys, slices of the sorted credits over the pool: a slice starts at the first run that begins inside it */
+		const size_t nc = credits.size();
+		const int T = (int)std::max<size_t>(1, std::min<size_t>(32, nc / 4096));
+		std::vector<std::vector<Group>> part((size_t)T);
+		host_parallel_for(T, [&](int t) {
+			size_t i = nc * (size_t)t / (size_t)T;
+			const size_t stop = nc * (size_t)(t + 1) / (size_t)T;
+			while (i > 0 && i < nc && credits[i].key == credits[i - 1].key) ++i;      /* the run that straddles the slice's start is the left slice's */
+			while (i < stop) {
+				size_t j = i;
+				int seen = 0, prev = -1;
+				while (j < nc && credits[j].key == credits[i].key) {
+					if (credits[j].seq != prev) {
+						++seen;
+						prev = credits[j].seq;
+					}
+					++j;
+				}
+				if (seen == N) part[(size_t)t].push_back({i, j, credits[i].pos});     /* morenodeslinkedlists.c:325-328 */
+				i = j;
 			}
-			++j;
-		}
-		if (seen == N) groups.push_back({i, j, credits[i].pos});     /* morenodeslinkedlists.c:325-328 */
-		i = j;
+		}, T);
+		for (const std::vector<Group> &v : part) groups.insert(groups.end(), v.begin(), v.end());
 	}
 	std::sort(groups.begin(), groups.end(), [](const Group &a, const Group &b) { return a.first0 < b.first0; });
 
@@ -274,6 +286,11 @@ int collect_border_nodes(const std::vector<std::vector<unsigned char>> &rev, Bor
 	B.head.assign(nodes * N, 0);
 	B.tail.assign(nodes * N, 0);
 	B.pool.clear();
+	{
+		size_t total = (size_t)N;
+		for (const Group &g : groups) total += g.to - g.from;
+		B.pool.reserve(total);
+	}
 	for (int s = 0; s < N; ++s) {                   /* node 0: the sentinel, position -1 everywhere */
 		B.head[(size_t)s] = (int)B.pool.size();
 		B.pool.push_back(-1);

@@ -214,24 +214,34 @@ int csadp_find_rotations(int nseq, const char *const *texts, const int *sizes, i
 
 	lap("automata + matching statistics");
 	/* ---- blocks ---------------------------------------------------------------------------- */
+	/* every position is looked at on its own (suffix-link walks in nseq automata): slices of positions over the pool, joined in order */
 	std::vector<Block> blocks;
-	for (int p = 0; p < n0; ++p) {
-		const int d = M[(size_t)p];
-		if (d < 1) continue;
-		if (M[(size_t)((p + n0 - 1) % n0)] > d) continue;     /* suffix of the longer common string one to the left */
-		Block b;
-		b.depth = d;
-		b.p0 = p;
-		b.pos.assign((size_t)nseq, 0);
-		bool unique = true;
-		const int e = p + d - 1;                              /* end in the doubled query, < 2*n0 */
-		for (int s = 0; s < nseq && unique; ++s) {
-			const Sam &A = sam[(size_t)s];
-			const int v = A.shrink(state_at[(size_t)s][(size_t)e], d);
-			if (A.st[(size_t)v].cnt != 1) { unique = false; break; }
-			b.pos[(size_t)s] = ((A.st[(size_t)v].maxend - d + 1) % sizes[s] + sizes[s]) % sizes[s];
-		}
-		if (unique) blocks.push_back(b);
+	{
+		const int T = std::max(1, std::min(32, n0 / 256));
+		std::vector<std::vector<Block>> part((size_t)T);
+		host_parallel_for(T, [&](int t) {
+			std::vector<Block> &mine = part[(size_t)t];
+			for (int p = (int)((long long)n0 * t / T), pe = (int)((long long)n0 * (t + 1) / T); p < pe; ++p) {
+				const int d = M[(size_t)p];
+				if (d < 1) continue;
+				if (M[(size_t)((p + n0 - 1) % n0)] > d) continue;     /* suffix of the longer common string one to the left */
+				Block b;
+				b.depth = d;
+				b.p0 = p;
+				b.pos.assign((size_t)nseq, 0);
+				bool unique = true;
+				const int e = p + d - 1;                              /* end in the doubled query, < 2*n0 */
+				for (int s = 0; s < nseq && unique; ++s) {
+					const Sam &A = sam[(size_t)s];
+					const int v = A.shrink(state_at[(size_t)s][(size_t)e], d);
+					if (A.st[(size_t)v].cnt != 1) { unique = false; break; }
+					b.pos[(size_t)s] = ((A.st[(size_t)v].maxend - d + 1) % sizes[s] + sizes[s]) % sizes[s];
+				}
+				if (unique) mine.push_back(std::move(b));
+			}
+		});
+		for (std::vector<Block> &v : part)
+			for (Block &b : v) blocks.push_back(std::move(b));
 	}
 	if (blocks.empty()) return CSADP_ERR_RANGE;               /* reference: "No unique subsequences found" */
 
