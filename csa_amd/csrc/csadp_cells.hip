@@ -389,7 +389,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		R.need1 = R.need2 = 0;
 		if (ROLE == ROLE_RING) {
 			/* `made` counts half blocks.  The hand-scheduled blocks (b >= 2) read their window in two halves: words 0..19 need the
-			 * producer's steps up to 32 b + 79 = the first half of its block b + 2; so do the ramp blocks (plain C++) */
+			 * producer's steps up to 32 b + 79 = the first half of its block b + 2; so do the ramp blocks */
 			const int need_all = std::min(2 * (b + 3), 2 * nb), need_half = std::min(2 * (b + 2) + 1, 2 * nb);
 			R.need1 = need_half;
 			R.need2 = need_all;
