@@ -165,11 +165,13 @@ __device__ __forceinline__ void granule_reload(unsigned long long &dst, const un
 	asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "+v"(dst) : "v"(p) : "memory");
 }
 /* vmcnt counts in order and EVERY block issues exactly one request after consuming one: when a request is due,
- * exactly one younger request is in flight (and possibly the two direction stores between them, a block old) */
+ * exactly one younger request is in flight (the direction stores between them are a block old), and behind it the letters of this
+ * block, asked for by the last statement */
 __device__ __forceinline__ void granule_wait(unsigned long long &dst)
 {
-	if (kGranuleAhead == 2) asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory");
-	else asm volatile("s_waitcnt vmcnt(0)" : "+v"(dst) : : "memory");
+	/* younger than the request that is due: the next request (two blocks ahead) and the letters the last statement asked for */
+	if (kGranuleAhead == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(dst) : : "memory");
+	else asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory");
 }
 
 #ifdef CSADP_CELL_TIMERS
