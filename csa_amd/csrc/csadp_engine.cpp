@@ -430,6 +430,15 @@ int FillBatch::layout_cells()
 	 * `tb_corridor` groups, and more while the scouts of the whole batch still fit ONE workgroup per compute unit -- a wider corridor then
 	 * costs no time, and a path that leaves the corridor costs a serial walk of every band from there on (one round of Mammals: 0.40 ms in
 	 * nw_tb_resolve with three groups of seven scouted).  CSADP_TB_CORRIDOR set explicitly is taken as it is. */
+	/* The band-parallel walk buys latency with work: a scout workgroup per band and corridor group, most of whose walks are never used.  A
+	 * batch of MANY banded matrices has its parallelism in the jobs: past ~5 000 scout workgroups one serial walk per job is shorter
+	 * (tools/r04/fetch_threshold_probe.py, matrices of 5 000 x 6 187: the walk of 48 of them 0.50 ms either way, of 96 0.77 banded and
+	 * 0.53 serial; of 8 0.25 against 0.49).  Not when the tests ask for bands (CSADP_TB_BAND_MIN set). */
+	if (!band_forced && banded_bands * std::max(1, tb_corridor) > 5000) {
+		for (CellJob &C : cjobs_) C.banded = 0;
+		tb_max_bands_ = 0;
+		banded_bands = 0;
+	}
 	for (int j = 0; j < nj; ++j) {
 		CellJob &C = cjobs_[(size_t)j];
 		if (!C.banded) continue;
