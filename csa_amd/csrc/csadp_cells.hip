@@ -438,7 +438,7 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 			 * blocks b - kRing - 2 and b - kRing - 1; the consumer's progress is only looked up when the last
 			 * value seen does not cover this block */
 			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
-			known_taken = __hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+			known_taken = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));   /* a scalar: the look-ups in between are a compare */
 		}
 		const int32_t xfirst0 = leftmul * (b * kCellBlock + 1);    /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
 		R.cslot = (feeds && lane == kLanes - 1) ? reinterpret_cast<uint32_t *>(&L.made[wv]) : L.scrap_mine + 4 * lane;
