@@ -242,6 +242,86 @@ def cpu_many_cores(tasks, per_proc=2, o3=False):
             "sample": "%d processes x %d pairs, %.1f s wall" % (procs, per_proc, wall)}
 
 
+def dropin_leg(sets=("Primates", "Mammals", "Set3")):
+    """The boundary north_star names, timed: the reference PROGRAM (mode N) as it is (oracle/_ref/CSA_ref_timed: the unmodified
+    sources with a clock around ProgressiveDP, dynamicprogramming.c:906) and relinked with the csadp drop-in in its two modes
+    (CSA_csadp: one one-task batch per call, RunAlignment's own pattern alignment.c:179-206; CSA_csadp_deferred: one more link
+    flag, all gaps as ONE batch in front of SaveAlignment).  Fresh child processes, started BEFORE this process touches a device.
+    The three reference runs go side by side on three host cores (Set3's is 36 fills of up to 17 k x 21 k cells on one core);
+    the csadp programs run one at a time with the GPU to themselves, best of two by seconds inside the DP."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    from helpers import GOLDEN, load_golden
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    bins = {"reference": "CSA_ref_timed", "synchronous": "CSA_csadp", "deferred": "CSA_csadp_deferred"}
+    if not all(os.path.exists(os.path.join(refdir, b)) for b in bins.values()):
+        return None
+    gold = load_golden("pipeline.json")
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="csadp_dropin_")
+
+    def start(kind, name):
+        d = os.path.join(tmp, "%s_%s_%d" % (kind, name, len(os.listdir(tmp))))
+        os.makedirs(d)
+        shutil.copy(os.path.join(GOLDEN, "data", name + ".txt"), d)
+        env = dict(os.environ)
+        env["CSADP_DROPIN_STATS"] = os.path.join(d, "stats.json")
+        devnull = open(os.devnull)
+        p = subprocess.Popen([os.path.join(refdir, bins[kind]), name + ".txt"], cwd=d, stdin=devnull, stdout=subprocess.DEVNULL,
+                             stderr=subprocess.DEVNULL, env=env)
+        return p, d, time.perf_counter(), devnull
+
+    def finish(h, name):
+        p, d, t0, devnull = h
+        rc = p.wait()
+        wall = time.perf_counter() - t0
+        devnull.close()
+        try:
+            with open(os.path.join(d, "stats.json")) as f:
+                st = json.loads(f.read().splitlines()[-1])
+            with open(os.path.join(d, name + "-Aligned.fasta"), "rb") as f:
+                same = hashlib.md5(f.read()).hexdigest() == gold[name]["aligned_md5"]
+        except Exception:
+            return None
+        return {"wall_s": round(wall, 3), "dp_s": round(st["dp_s"], 4), "calls": st["calls"], "batches": st["batches"],
+                "init_wait_s": round(st["init_s"], 4), "init_thread_s": round(st.get("early_thread_s", 0.0), 3), "first_call_s": round(st["first_call_s"], 4),
+                "aligned_md5_equals_reference": bool(same and rc == 0)}
+
+    try:
+        refs = {name: start("reference", name) for name in sets if name in gold}
+        for name in refs:
+            out[name] = {}
+        for name in refs:                                   # the GPU programs meanwhile: one at a time
+            if name == "Set3":
+                continue
+            out[name]["reference"] = finish(refs[name], name)
+        for name in refs:
+            for kind in ("synchronous", "deferred"):
+                best = None
+                for _ in range(2):
+                    cur = finish(start(kind, name), name)
+                    if cur is not None and (best is None or cur["dp_s"] < best["dp_s"]):
+                        best = cur
+                out[name][kind] = best
+        if "Set3" in refs:
+            out["Set3"]["reference"] = finish(refs["Set3"], "Set3")
+        for name in refs:
+            r, sy, de = out[name].get("reference"), out[name].get("synchronous"), out[name].get("deferred")
+            if r and sy and de:
+                out[name]["dp_speedup_vs_reference"] = {"synchronous": round(r["dp_s"] / sy["dp_s"], 1), "deferred": round(r["dp_s"] / de["dp_s"], 1)}
+                out[name]["wall_speedup_vs_reference"] = {"synchronous": round(r["wall_s"] / sy["wall_s"], 2), "deferred": round(r["wall_s"] / de["wall_s"], 2)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["what"] = ("mode N of the reference program on its example sets: `reference` = unmodified sources (1 host core), `synchronous` / `deferred` = "
+                   "the same program with dynamicprogramming.c replaced by csadp_dropin.c (+ -Wl,--wrap=SaveAlignment for deferred).  dp_s = seconds "
+                   "inside ProgressiveDP calls (+ the one batch of the deferred mode); init_thread_s = csadp_init + csadp_warmup (HIP start-up, code objects, arenas) on the "
+                   "adapter's helper thread, started when the program starts, under the program's own suffix-tree stage; init_wait_s = what "
+                   "the first gap still waits for it; neither is in dp_s; wall_s = the whole process, the reference's own single-threaded suffix tree and anchor stages included")
+    return out
+
+
 def streaming_leg(csa_amd, tasks, batches, depth=3):
     """What a caller of the C-ABI gets from host buffers to host strings, PCIe included: `batches`
     pair batches, `depth` in flight (create + run + flush of batch n+depth-1 before fetch of batch n).
@@ -471,7 +551,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    many_cores = many_cores_o3 = many_cores_c3 = None
+    many_cores = many_cores_o3 = many_cores_c3 = dropin = None
+    if args.gpus == 1 and not args.no_cpu_baseline and not args.no_extra_legs:
+        dropin = dropin_leg()
     if args.gpus == 1 and not args.no_cpu_baseline:
         from csa_amd.synth import config4_tasks as _tasks      # numpy only: no device is initialised here
         many_cores = cpu_many_cores(_tasks(0, min(args.pairs, 64), args.length))
@@ -716,6 +798,14 @@ def main():
             line["one_shot"] = one_shot_leg(csa_amd, tasks)
             line["one_shot"]["vs_value"] = round(line["one_shot"]["gcups_device"] / (value / args.gpus), 3)
             line["profile_path"] = profile_path_leg(csa_amd)
+            if dropin:
+                # the same sets through csadp_msa (the library's own caller: all gaps of a set in one batch) beside the drop-in's modes
+                for name, rec in dropin.items():
+                    pp = line["profile_path"].get(name) if isinstance(rec, dict) else None
+                    if pp and rec.get("deferred"):
+                        rec["csadp_msa_dp_ms"] = pp["dp_ms"]
+                        rec["deferred_dp_vs_csadp_msa_dp"] = round(rec["deferred"]["dp_s"] * 1e3 / pp["dp_ms"], 2)
+                line["dropin"] = dropin
             line["single_matrix"] = single_matrix_leg(csa_amd)
             # SURVEY 8(d)'s unit of work counts H2D of the sequences and D2H of the results inside the wall time: that rate,
             # first class beside `value` (which starts and ends in HBM, as the bench contract asks)

@@ -76,7 +76,7 @@ class Timing(ctypes.Structure):
 
 # symbols declared in include/csadp.h and include/csadp_debug.h
 EXPORTS = [
-    "csadp_init", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
+    "csadp_init", "csadp_warmup", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
     "csadp_align_batch", "csadp_free_result", "csadp_free_results", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
     "csadp_align_batch_multi", "csadp_pairs_create_on",
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_flush", "csadp_pairs_sync", "csadp_pairs_fetch",
@@ -133,6 +133,10 @@ def _check(code, what=""):
 def init(device=-1, tile_rows=0, verbose=0):
     cfg = Config(device, tile_rows, verbose)
     _check(lib().csadp_init(ctypes.byref(cfg)), "csadp_init")
+
+
+def warmup():
+    _check(lib().csadp_warmup(), "csadp_warmup")
 
 
 def shutdown():

@@ -149,6 +149,31 @@ int Engine::init(int dev, const csadp_config *cfg)
 	return CSADP_OK;
 }
 
+int Engine::warm_copy_paths()
+{
+	{ const int brc = bind(); if (brc != CSADP_OK) return brc; }
+	constexpr size_t kBytes = (size_t)8 << 20;
+	uint8_t *dev = nullptr, *pin = nullptr;
+	HIP_TRY(hipMalloc((void **)&dev, kBytes));
+	if (hipHostMalloc((void **)&pin, kBytes, hipHostMallocDefault) != hipSuccess) { (void)hipFree(dev); return CSADP_ERR_HIP; }
+	memset(pin, 0, kBytes);
+	std::vector<hipStream_t> all(streams_, streams_ + nstreams_);
+	all.push_back(copy_stream_);
+	all.push_back(upload_stream_);
+	int rc = CSADP_OK;
+	for (hipStream_t st : all)
+		for (size_t bytes : {(size_t)4096, (size_t)256 << 10, kBytes}) {
+			if (hipMemsetAsync(dev, 0, bytes, st) != hipSuccess || hipMemcpyAsync(dev, pin, bytes, hipMemcpyHostToDevice, st) != hipSuccess ||
+			    hipMemcpyAsync(pin, dev, bytes, hipMemcpyDeviceToHost, st) != hipSuccess)
+				rc = CSADP_ERR_HIP;
+		}
+	for (hipStream_t st : all)
+		if (hipStreamSynchronize(st) != hipSuccess) rc = CSADP_ERR_HIP;
+	(void)hipHostFree(pin);
+	(void)hipFree(dev);
+	return rc;
+}
+
 /* Pools of released HBM arenas and pinned staging buffers: consecutive batches of similar size
  * (bench steps, the drop-in's ~50 calls, a streaming caller with several pair batches in flight) skip
  * hipMalloc / hipHostMalloc, which cost 0.1 .. 1 ms each.  Best fit; a full pool drops its smallest entry. */
@@ -970,6 +995,19 @@ int FillBatch::alloc_buffers()
 		}
 	}
 	return CSADP_OK;
+}
+
+int FillBatch::reserve(size_t arena_bytes, size_t in_bytes, size_t res_bytes)
+{
+	const size_t t = total_bytes_, i = in_bytes_, r = res_bytes_;
+	total_bytes_ = std::max(t, arena_bytes);
+	in_bytes_ = std::max(i, in_bytes);
+	res_bytes_ = std::max(r, res_bytes);
+	const int rc = alloc_buffers();
+	total_bytes_ = t;
+	in_bytes_ = i;
+	res_bytes_ = r;
+	return rc;
 }
 
 /* buffers, zeroed inputs, events */

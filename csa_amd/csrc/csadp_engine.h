@@ -62,6 +62,9 @@ public:
 	void give_pinned(uint8_t *ptr, size_t bytes);
 	uint8_t *take_pinned(size_t need, size_t *got);
 	void drop_arena_cache();
+	/* csadp_warmup: the first memset / copy of either direction and of either size class (blit kernel, copy engine) on every
+	 * stream of the engine, paid now (profiles/r05_dropin_hiptrace: 3-9 ms each inside a process' first batch) */
+	int warm_copy_paths();
 
 	/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) per device alive
 	 * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per input set) */
@@ -118,6 +121,9 @@ public:
 	int njobs() const { return (int)jobs_.size(); }
 	/* compute the arena layout and the tile schedule, (re)allocate HBM and pinned staging */
 	int layout();
+	/* grow the (grow-only) arena and the two pinned staging buffers to at least these sizes now, so that the layouts of a
+	 * first real batch find them (csadp_warmup) */
+	int reserve(size_t arena_bytes, size_t in_bytes, size_t res_bytes);
 	/* host staging pointers for the inputs of job j (valid after layout) */
 	uint32_t *coltab(int j);
 	int32_t *leftc(int j);

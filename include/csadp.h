@@ -50,6 +50,13 @@ typedef struct csadp_config {
  * it up; idempotent, NULL = defaults.  Every entry point makes its device current on the calling
  * thread (hipSetDevice is a per-thread setting), so calls may come from any host thread. */
 CSADP_API int csadp_init(const csadp_config *cfg);
+/* Optional.  Pays now what a process' first batch would otherwise pay on top of its work: the kernels' code objects (loaded
+ * at the first launch out of each), the host pool's threads, the arenas and pinned staging of csadp_align_batch (1.25 GB of
+ * HBM reserved).  Runs a small synthetic batch through every kernel family.  Thread-safe like every entry point; a caller
+ * with host work in front of its first batch runs it on a helper thread meanwhile (csadp_dropin.c does: the reference program
+ * builds its suffix tree first).  Measured on the reference program relinked with the drop-in: first batch 60-70 -> 12-15 ms
+ * (profiles/r05_dropin_*.json). */
+CSADP_API int csadp_warmup(void);
 CSADP_API void csadp_shutdown(void);
 CSADP_API int csadp_version(void);
 CSADP_API const char *csadp_strerror(int code);

@@ -20,6 +20,13 @@ Outputs (all data, no reference source text):
 
   config4_pairs.json   (--config4) the first 32 pairs of the benchmark workload (SURVEY 8d config 4,
                        csa_amd/synth.py) through the compiled reference: length, SP score, FNV-1a
+  config4_all.json     (--config4-all) ALL 1024 pairs of config 4 through the compiled reference (8 processes):
+                       parallel arrays consensus / sp / fnv1a indexed by pair number
+  config5_pairs.json   (--config5) every pair of config 5 (csa_amd/synth.py:config5_lengths, pair i =
+                       synth_pair(20000 + i, length=la[i])) whose longer side is <= 40 000 letters -- what the
+                       reference's 5 B/cell matrices allow here -- index, lengths, consensus, sp, fnv1a
+  unrelated_pairs.json (--unrelated) the 64 UNRELATED 16 kbp pairs of config 4's second variant
+                       (synth_pair(70000 + p, unrelated=True)): consensus, sp, fnv1a
   anchors.json         (--anchors) the anchor stage of the compiled reference (ref_shim.c:
                        csa_ref_alignment_map): small families with their rotations, border-node
                        count, final alignment map and the rows SaveAlignment wrote; and the
@@ -139,6 +146,56 @@ def config4_pairs(n=32):
         out.append({"pair": p, "consensus": cons, "sp": sp_score(strs), "fnv1a": "%08x" % fnv1a(strs)})
         print("config4 pair", p, cons, out[-1]["sp"], out[-1]["fnv1a"], "%.1fs" % sec, flush=True)
     return out
+
+
+def _ref_digest(job):
+    """(key, texts, rots) -> (key, consensus, sp, fnv1a, seconds); runs in a worker process (the reference is all globals)."""
+    key, kind = job
+    from csa_amd.synth import config5_lengths, synth_pair
+    if kind == "config4":
+        a, b, ra, rb = synth_pair(key)
+    elif kind == "unrelated":
+        a, b, ra, rb = synth_pair(70000 + key, unrelated=True)
+    else:
+        la, _ = config5_lengths(256)
+        a, b, ra, rb = synth_pair(20000 + key, length=int(la[key]))
+    cons, strs, sec = ref_progressive([a, b], [ra, rb])
+    return key, len(a), len(b), cons, sp_score(strs), "%08x" % fnv1a(strs), sec
+
+
+def _run_pool(jobs, workers, label):
+    """The compiled reference keeps 5 bytes per cell (dynamicprogramming.c:964-981): `workers` bounds the memory in use."""
+    import multiprocessing as mp
+    out = {}
+    with mp.get_context("fork").Pool(workers, maxtasksperchild=4) as pool:
+        for key, la, lb, cons, sp, dig, sec in pool.imap_unordered(_ref_digest, jobs):
+            out[key] = (la, lb, cons, sp, dig)
+            print(label, key, la, lb, cons, sp, dig, "%.1fs" % sec, "(%d/%d)" % (len(out), len(jobs)), flush=True)
+    return out
+
+
+def config4_all(n=1024, workers=8):
+    got = _run_pool([(p, "config4") for p in range(n)], workers, "config4")
+    return {"pairs": n, "consensus": [got[p][2] for p in range(n)], "sp": [got[p][3] for p in range(n)],
+            "fnv1a": [got[p][4] for p in range(n)]}
+
+
+def unrelated_pairs(n=64, workers=8):
+    got = _run_pool([(p, "unrelated") for p in range(n)], workers, "unrelated")
+    return [{"pair": p, "consensus": got[p][2], "sp": got[p][3], "fnv1a": got[p][4]} for p in range(n)]
+
+
+def config5_pairs(limit=40000):
+    from csa_amd.synth import config5_lengths
+    la, _ = config5_lengths(256)
+    # the partner is within a few per cent of la: 1.06 la bounds it
+    small = [i for i in range(256) if la[i] * 1.06 <= 20000]
+    large = [i for i in range(256) if 20000 < la[i] * 1.06 and la[i] * 1.06 <= limit * 1.06]
+    got = _run_pool([(i, "config5") for i in small], 8, "config5")
+    got.update(_run_pool([(i, "config5") for i in sorted(large, key=lambda i: -la[i])], 3, "config5"))   # up to 8.5 GB each
+    keep = sorted(i for i in got if max(got[i][0], got[i][1]) <= limit)
+    return [{"index": i, "len_a": got[i][0], "len_b": got[i][1], "consensus": got[i][2], "sp": got[i][3], "fnv1a": got[i][4]}
+            for i in keep]
 
 
 REF_BIN = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "CSA_ref")
@@ -280,6 +337,12 @@ def main():
         with open(os.path.join(HERE, "sp_stats.json"), "w") as f:
             json.dump(sp_stats(), f, indent=0)
         return
+    for flag, name, fn in (("--config4-all", "config4_all.json", config4_all), ("--config5", "config5_pairs.json", config5_pairs),
+                           ("--unrelated", "unrelated_pairs.json", unrelated_pairs)):
+        if flag in sys.argv:
+            with open(os.path.join(HERE, name), "w") as f:
+                json.dump(fn(), f, indent=0)
+            return
     if "--config4" in sys.argv:
         with open(os.path.join(HERE, "config4_pairs.json"), "w") as f:
             json.dump(config4_pairs(), f, indent=1)

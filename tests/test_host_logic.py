@@ -51,6 +51,28 @@ def test_no_cpu_fallback_without_device():
         csa_amd.PairBatch([([b"ACGT", b"ACGT"], None, None, None)])
 
 
+def test_dropin_adapter_without_device_exits_2_and_computes_nothing(tmp_path):
+    """The drop-in adapter's error policy (include/csa_dropin.h): no CPU fallback -- without a device the first gap prints the
+    reason and the process exits with 2, in both modes; a program that never reaches a gap (the reference's mode R) is not
+    disturbed by the adapter's early start-up thread."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from helpers import ROOT
+    exe = str(tmp_path / "dropin_driver")
+    subprocess.check_call(["gcc", "-O1", "-fcommon", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "dropin_driver.c"),
+                           os.path.join(ROOT, "csa_amd", "csadp_dropin.o"), "-o", exe, "-L", os.path.join(ROOT, "csa_amd"), "-lcsadp",
+                           "-Wl,-rpath," + os.path.join(ROOT, "csa_amd"), "-lpthread"])
+    for deferred in ("0", "1"):
+        out = subprocess.run([exe, deferred, "2", "1", "ACGTACGT", "ACGTTCGT"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert out.returncode == 2
+        assert b"no usable gfx950 HIP device" in out.stderr and b"0 0 " not in out.stdout
+    # no gap at all (ngaps = 0): nothing to compute, the failed start-up is never mentioned
+    out = subprocess.run([exe, "0", "2", "0", "ACGT", "ACGT"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert out.returncode == 0 and b"drop-in" not in out.stderr
+
+
 # DeleteGappedColumns runs either as the reference's plain pass or with its candidate scores speculated first (what the
 # round driver does over all tasks and threads); CSADP_REFINE_SPECULATE=1 makes the one-task entry points speculate too.
 @pytest.fixture(params=["plain", "speculated", "speculated-threads"])
