@@ -253,6 +253,7 @@ def dropin_leg(sets=("Primates", "Mammals", "Set3")):
     import shutil
     import subprocess
     import tempfile
+    import threading
     from helpers import GOLDEN, load_golden
     refdir = os.path.join(ROOT, "oracle", "_ref")
     bins = {"reference": "CSA_ref_timed", "synchronous": "CSA_csadp", "deferred": "CSA_csadp_deferred"}
@@ -269,14 +270,19 @@ def dropin_leg(sets=("Primates", "Mammals", "Set3")):
         env = dict(os.environ)
         env["CSADP_DROPIN_STATS"] = os.path.join(d, "stats.json")
         devnull = open(os.devnull)
+        t0 = time.perf_counter()
         p = subprocess.Popen([os.path.join(refdir, bins[kind]), name + ".txt"], cwd=d, stdin=devnull, stdout=subprocess.DEVNULL,
                              stderr=subprocess.DEVNULL, env=env)
-        return p, d, time.perf_counter(), devnull
+        ended = []
+        w = threading.Thread(target=lambda: ended.append((p.wait(), time.perf_counter())))     # the process' own end, whenever we look
+        w.start()
+        return p, d, t0, devnull, w, ended
 
     def finish(h, name):
-        p, d, t0, devnull = h
-        rc = p.wait()
-        wall = time.perf_counter() - t0
+        p, d, t0, devnull, w, ended = h
+        w.join()
+        rc, t1 = ended[0]
+        wall = t1 - t0
         devnull.close()
         try:
             with open(os.path.join(d, "stats.json")) as f:
@@ -428,9 +434,14 @@ def config5_leg(csa_amd, steps=3, warmup=1):
     for t, r in zip(tasks, res):
         ok = ok and r["status"] == 0 and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
         ok = ok and sp_score(r["aligned"]) == r["score"]
+    # every pair the reference's 5 B/cell matrices can hold here (both sides <= 40 000 letters: 171 of the 256) against the compiled reference
+    from helpers import load_golden
+    gold = load_golden("config5_pairs.json")
+    same = sum(1 for g in gold if (res[g["index"]]["score"], res[g["index"]]["consensus"], csa_amd.fnv1a(res[g["index"]]["aligned"])) ==
+               (g["sp"], g["consensus"], int(g["fnv1a"], 16)))
     return {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
             "ms_per_step": round(dt * 1e3 / steps, 2), "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"],
-            "properties_hold_for_all": bool(ok),
+            "properties_hold_for_all": bool(ok), "reference_digests": len(gold), "equal_to_reference_digests": same,
             "what": "256 synthetic pairs of 1-200 kbp in one batch (jobs of up to 33 strips run as chains of workgroups)"}
 
 
@@ -447,9 +458,30 @@ def unrelated_leg(csa_amd, steps=20, warmup=5):
     for t, r in zip(tasks, res):
         ok = ok and r["status"] == 0 and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1])
         ok = ok and sp_score(r["aligned"]) == r["score"]
+    from helpers import load_golden
+    gold = load_golden("unrelated_pairs.json")
+    same = sum(1 for g in gold if (res[g["pair"]]["score"], res[g["pair"]]["consensus"], csa_amd.fnv1a(res[g["pair"]]["aligned"])) ==
+               (g["sp"], g["consensus"], int(g["fnv1a"], 16)))
     return {"pairs": len(tasks), "gcups": round(tm["cells"] * steps / dt / 1e9, 1), "ms_per_step": round(dt * 1e3 / steps, 3),
             "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"], "properties_hold_for_all": bool(ok),
-            "what": "64 unrelated random 16384-letter pairs (tests/test_gpu_parity.py holds their scores to the oracle's optimum)"}
+            "equal_to_reference_digests": same,
+            "what": "64 unrelated random 16384-letter pairs, every record against the compiled reference's (tests/golden/unrelated_pairs.json)"}
+
+
+def config4_all_leg(csa_amd, first_tasks, steps=4, warmup=1):
+    """BASELINE config 4 whole: all 1024 synthetic pairs on this one GPU as ONE device-resident batch (what the 8 ranks of the
+    scaling run share out 128 apiece), every record against the compiled reference's (tests/golden/config4_all.json)."""
+    from csa_amd.synth import config4_tasks
+    from helpers import load_golden
+    tasks = list(first_tasks) + config4_tasks(len(first_tasks), 1024 - len(first_tasks))
+    dt, tm, res = timed_pair_batch(csa_amd, tasks, steps, warmup)
+    gold = load_golden("config4_all.json")
+    same = sum(1 for p, r in enumerate(res) if r["status"] == 0 and
+               (r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])) == (gold["sp"][p], gold["consensus"][p], int(gold["fnv1a"][p], 16)))
+    return {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
+            "ms_per_step": round(dt * 1e3 / steps, 3), "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"],
+            "equal_to_reference_digests": same,
+            "what": "all 1024 pairs of config 4 in one batch on one GPU; every (score, consensus, FNV-1a of the rows) equal to the compiled reference's"}
 
 
 def keep_heap():
@@ -698,9 +730,10 @@ def main():
                 ok = ok and by_id[t] == (g["sp"], g["consensus"], int(g["fnv1a"], 16))
                 checked += 1
         if args.workload == "config4" and args.length == 16384:
-            for g in load_golden("config4_pairs.json"):
-                if g["pair"] in by_id:
-                    ok = ok and by_id[g["pair"]] == (g["sp"], g["consensus"], int(g["fnv1a"], 16))
+            g4 = load_golden("config4_all.json")             # all 1024 pairs through the compiled reference
+            for p in by_id:
+                if p < g4["pairs"]:
+                    ok = ok and by_id[p] == (g4["sp"][p], g4["consensus"][p], int(g4["fnv1a"][p], 16))
                     checked += 1
         lp = max(tm["launch_passes"], 1)                        # passes carried by the launch timed alone
         impl_bytes = tm["dir_bytes"] + tm["border_bytes"]      # what the fill writes per pass (checkpoints + marks, or planes)
@@ -817,8 +850,12 @@ def main():
                 line["real_sets"] = real_sets_leg(csa_amd)
                 line["config5"] = config5_leg(csa_amd)
                 line["unrelated_16k"] = unrelated_leg(csa_amd)
+                if args.pairs <= 1024 and args.length == 16384:
+                    line["config4_all"] = config4_all_leg(csa_amd, tasks)
                 line["records"]["checked_against_reference_digests_in_all_legs"] = (
-                    checked + line["real_sets"]["Mammals"]["equal_to_reference_digests"] + line["real_sets"]["Primates"]["equal_to_reference_digests"])
+                    (line["config4_all"]["equal_to_reference_digests"] if "config4_all" in line else checked) +
+                    line["real_sets"]["Mammals"]["equal_to_reference_digests"] + line["real_sets"]["Primates"]["equal_to_reference_digests"] +
+                    line["config5"]["equal_to_reference_digests"] + line["unrelated_16k"]["equal_to_reference_digests"])
         if args.gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tasks, results)
             line["cpu_baseline"]["many_cores"] = many_cores

@@ -113,6 +113,43 @@ def test_oracle_reproduces_benchmark_pair_digests():
         assert st.last_score == g["sp"]
 
 
+def test_oracle_reproduces_a_sample_of_the_wide_reference_fixtures():
+    """Round 5's reference-held records -- all 1024 pairs of config 4, the 64 unrelated 16 kbp pairs, the 171 pairs of config 5 the
+    reference's matrices can hold (tests/golden/make_golden.py --config4-all / --unrelated / --config5) -- pin the ORACLE too: a sample
+    of each, string digests included; the linear-space score on a wider sample."""
+    from helpers import oracle_pair_score_linear, oracle_progressive, sp_score, synth_pair
+    from csa_amd.synth import config5_lengths
+    g4 = load_golden("config4_all.json")
+    assert g4["pairs"] == 1024 and len(g4["fnv1a"]) == len(g4["sp"]) == len(g4["consensus"]) == 1024
+    for g in load_golden("config4_pairs.json"):                    # the round-2 fixture is a prefix of the new one
+        assert (g4["consensus"][g["pair"]], g4["sp"][g["pair"]], g4["fnv1a"][g["pair"]]) == (g["consensus"], g["sp"], g["fnv1a"])
+    for p in (517, 1023):
+        a, b, ra, rb = synth_pair(p)
+        cons, strs, st = oracle_progressive([a, b], [ra, rb])
+        assert (cons, sp_score(strs), "%08x" % fnv1a(strs)) == (g4["consensus"][p], g4["sp"][p], g4["fnv1a"][p])
+    for p in (100, 333, 640, 900):
+        a, b, ra, rb = synth_pair(p)
+        assert oracle_pair_score_linear([a, b], [ra, rb]) == g4["sp"][p]
+    gu = load_golden("unrelated_pairs.json")
+    assert len(gu) == 64
+    for g in (gu[5], gu[63]):
+        a, b, ra, rb = synth_pair(70000 + g["pair"], unrelated=True)
+        cons, strs, st = oracle_progressive([a, b], [ra, rb])
+        assert (cons, sp_score(strs), "%08x" % fnv1a(strs)) == (g["consensus"], g["sp"], g["fnv1a"])
+    g5 = load_golden("config5_pairs.json")
+    la, _ = config5_lengths(256)
+    assert len(g5) == sum(1 for x in la if x <= 40000) >= 170
+    small = sorted(g5, key=lambda g: g["len_a"])
+    for g in small[:6] + small[len(small) // 2:len(small) // 2 + 3]:           # 1 k .. 7 k letters: full strings
+        a, b, ra, rb = synth_pair(20000 + g["index"], length=int(la[g["index"]]))
+        assert (len(a), len(b)) == (g["len_a"], g["len_b"])
+        cons, strs, st = oracle_progressive([a, b], [ra, rb])
+        assert (cons, sp_score(strs), "%08x" % fnv1a(strs)) == (g["consensus"], g["sp"], g["fnv1a"])
+    for g in small[-2:]:                                                        # the two longest (38 k letters): the score
+        a, b, ra, rb = synth_pair(20000 + g["index"], length=int(la[g["index"]]))
+        assert oracle_pair_score_linear([a, b], [ra, rb]) == g["sp"]
+
+
 def test_linear_space_score_equals_the_full_matrix():
     """odp_pair_score_linear (two rows, no directions) == dpmatrix[nrows][ncols] of the full
     restatement on fuzzed pairs (sub-regions, rotations, empty sides) ..."""
