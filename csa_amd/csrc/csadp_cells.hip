@@ -293,10 +293,13 @@ __device__ __forceinline__ bool fetch_granules(const unsigned long long *hand_in
  * with a strip: a look is two vector instructions).
  */
 __device__ __forceinline__ bool publish_halves(unsigned long long *hand_out, const uint32_t *ring_last, const int *made_last, int *taken_pub, int nb,
-                                               uint32_t epoch, int lane)
+                                               uint32_t epoch, int lane, int test_slow)
 {
 	constexpr int kHalf = kCellBlock / 2;
 	for (int h = 0; h < 2 * nb; ++h) {
+		/* test seam (CSADP_TEST_SLOW_PUBLISHER): a publisher that falls blocks behind its strip -- what a shared or preempted device does to
+		 * it -- so that the strip's wait for ring space is what keeps the result right (tests/test_gpu_parity.py) */
+		for (int z = 0; z < test_slow; ++z) __builtin_amdgcn_s_sleep(127);
 		if (__hip_atomic_load(made_last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < h + 1) {
 			const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
 			int spins = 0;
@@ -433,11 +436,14 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 		}
 		const bool ringer = lane == kLanes - 1 && (feeds || publishes);
 		uint32_t *lanebuf = ringer ? L.ring_mine + (b * kCellBlock) % kRingSteps : L.scrap_mine + 4 * lane;
-		if (feeds && b - kRing > known_taken) {
-			/* the ring slots of this block last held block b - kRing, which the consumer reads during its
-			 * blocks b - kRing - 2 and b - kRing - 1; the consumer's progress is only looked up when the last
-			 * value seen does not cover this block */
-			if (!wait_lds(&L.taken[wv + 1], b - kRing)) return false;
+		/* the ring slots of this block last held block b - kRing.  A STRIP reads it during its blocks b - kRing - 2 and b - kRing - 1 and
+		 * stores taken = c + 1 behind its block c: taken >= b - kRing covers it.  The PUBLISHER (the consumer of a chunk's last strip in
+		 * the helper-wave layout) stores taken = B + 1 when both halves of block B are out: it takes taken >= b - kRing + 1 (round-4
+		 * ADVICE: with the strips' threshold a publisher seven blocks behind had its slots overwritten under it, and at b == kRing there
+		 * was no wait at all).  The consumer's progress is only looked up when the last value seen does not cover this block. */
+		const int need_taken = b - kRing + ((feeds && wv + 1 == kCellWaves) ? 1 : 0);
+		if (feeds && need_taken > known_taken) {
+			if (!wait_lds(&L.taken[wv + 1], need_taken)) return false;
 			known_taken = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&L.taken[wv + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));   /* a scalar: the look-ups in between are a compare */
 		}
 		const int32_t xfirst0 = leftmul * (b * kCellBlock + 1);    /* border column: X[r][0] = leftmul * r (:967); other strips: unused */
@@ -531,9 +537,11 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 
 template <bool WIDE, bool FETCH>
 __global__ __launch_bounds__((kCellWaves + (FETCH ? 2 : 0)) * kLanes) void nw_fill_cells(uint8_t *__restrict__ arena, const CellJob *__restrict__ jobs,
-                                                                    const TileRef *__restrict__ work, uint32_t epoch,
+                                                                    const TileRef *__restrict__ work, uint32_t epoch_and_seam,
                                                                     int *__restrict__ abort_word)
 {
+	const uint32_t epoch = epoch_and_seam & 0xffffffu;        /* 24 bits travel in a granule; the top byte: the slow-publisher test seam */
+	const int test_slow = (int)(epoch_and_seam >> 24);
 	/* four words in front of every ring: a window that straddles the ring's end is read from two addresses, the second of them
 	 * "ring start - 16 bytes" + 16 q (q >= 1) -- never below the array */
 	/* ring[1 + wv]: strip wv's; ring[0]: what the fetcher brings in from the previous chunk (FETCH) */
@@ -563,7 +571,7 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 2 : 0)) * kLanes) void nw_fi
 	if (FETCH && wv == kCellWaves + 1) {                      /* the publisher: the chunk's last strip hands on to a next chunk */
 		if ((chunk + 1) * kCellWaves >= J.nstrips) return;
 		unsigned long long *to = reinterpret_cast<unsigned long long *>(arena + J.hand) + (size_t)chunk * J.steps_pad;
-		if (!publish_halves(to, ring[kCellWaves] + 4, &made[kCellWaves], &taken[kCellWaves], nb, epoch, lane) && lane == 0) atomicExch(abort_word, 1);
+		if (!publish_halves(to, ring[kCellWaves] + 4, &made[kCellWaves], &taken[kCellWaves], nb, epoch, lane, test_slow) && lane == 0) atomicExch(abort_word, 1);
 		return;
 	}
 	if (s >= J.nstrips) return;
@@ -622,10 +630,10 @@ __global__ __launch_bounds__((kCellWaves + (FETCH ? 2 : 0)) * kLanes) void nw_fi
 }
 
 hipError_t launch_fill_cells(bool wide, bool fetch, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch,
-                             int *abort_word, hipStream_t st)
+                             int *abort_word, hipStream_t st, int test_slow_publisher)
 {
 	if (nwork <= 0) return hipSuccess;
-	epoch &= 0xffffffu;                                /* 24 bits travel in a granule */
+	epoch = (epoch & 0xffffffu) | ((uint32_t)(test_slow_publisher & 255) << 24);     /* 24 bits travel in a granule */
 	const dim3 threads((kCellWaves + (fetch ? 2 : 0)) * kLanes);
 	if (wide && fetch) hipLaunchKernelGGL((nw_fill_cells<true, true>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);
 	else if (wide) hipLaunchKernelGGL((nw_fill_cells<true, false>), dim3(nwork), threads, 0, st, arena, jobs, work, epoch, abort_word);

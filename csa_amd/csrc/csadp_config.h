@@ -38,6 +38,7 @@ struct Config {
 	bool share_device = false;      /* CSADP_SHARE_DEVICE: several ordinals may name one device (rehearsals) */
 	int local_rank = 0;             /* LOCAL_RANK: default device ordinal */
 	/* testing */
+	int test_slow_publisher = 0;    /* CSADP_TEST_SLOW_PUBLISHER: the publisher wave of nw_fill_cells sleeps this many x 127 x 64 cycles per half block (tests) */
 	bool test_force_abort = false;  /* CSADP_TEST_FORCE_ABORT: pretend a bounded wait of a chunked fill ran out */
 };
 

@@ -1279,7 +1279,8 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	 * 19.15 ms, as in the plain layout, and the bit-parallel path stays ahead host to host: 20.5 against 22.3 ms.) */
 	const bool fetch = (int)tiles_.size() <= config().cells_fetch_wgs;
 	if (!serial) {
-		HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st));
+		HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st,
+		                          config().test_slow_publisher));
 	} else {
 		for (size_t c = 0; c + 1 < chunk_first_.size(); ++c)
 			HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + serial_off_) + chunk_first_[c],

@@ -206,6 +206,7 @@ Config read_config()
 	c.share_device = env_int("CSADP_SHARE_DEVICE", 0) != 0;
 	c.local_rank = env_int("LOCAL_RANK", 0);
 	c.test_force_abort = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;
+	c.test_slow_publisher = std::max(0, std::min(255, env_int("CSADP_TEST_SLOW_PUBLISHER", 0)));
 	return c;
 }
 std::mutex g_config_mutex;

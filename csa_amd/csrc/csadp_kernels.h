@@ -25,8 +25,9 @@ hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, 
 /* csadp_cells.hip: any fill as a persistent cell-per-lane wavefront; work = (job, chunk) items */
 /* epoch: a value no earlier launch on this memory has used (24 bits): it tags the hand-off granules between chunks */
 /* fetch: the workgroups carry a fetcher wave (few workgroups: every chain on compute units of its own; csadp_cells.hip) */
+/* test_slow_publisher: test seam, units of ~0.1 ms the publisher wave sleeps per half block (0 in production) */
 hipError_t launch_fill_cells(bool wide, bool fetch, uint8_t *arena, const CellJob *jobs, const TileRef *work, int nwork, uint32_t epoch,
-                             int *abort_word, hipStream_t st);
+                             int *abort_word, hipStream_t st, int test_slow_publisher = 0);
 /* csadp_cells_tb.hip: the direction walk.  max_bands = 0: every matrix by one serial walk (CellJob::banded all 0);
  * else the most bands / scout groups of any banded job of the batch (scout, resolve, emit, gather) */
 hipError_t configure_traceback_cells();

@@ -391,3 +391,27 @@ def test_abort_word_triggers_the_chunk_by_chunk_repeat(monkeypatch, capfd):
     assert "repeating the pass chunk by chunk" in err
     for g, (cons, strs, st) in zip(got, want):
         assert g["status"] == 0 and g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
+
+
+@pytest.mark.parametrize("slow", [1, 4])
+def test_publisher_wave_that_falls_behind_its_strip(slow, monkeypatch):
+    """Helper-wave layout of nw_fill_cells (launches of at most 256 workgroups): a chunk's last strip hands its values to the
+    publisher wave through an 8-block LDS ring and may only overwrite a block's slots once the publisher has sent BOTH halves of
+    it (`taken` >= block + 1; csadp_cells.hip, run_strip).  Round-4 ADVICE: the strip waited for one block less, and not at
+    all at block 8, so a publisher seven blocks behind -- a preempted or shared device -- sent overwritten values under a valid
+    tag: a wrong alignment, silently.  CSADP_TEST_SLOW_PUBLISHER makes the publisher sleep `slow` x 8 000 cycles per half block
+    (a strip's block takes ~3 000): it falls behind at once, and only the strip's wait keeps the hand-off right.  Matrices of
+    several chunks and far more than 8 blocks: a 3-sequence family (profile step) and a pair on the cell-per-lane path."""
+    r = rng(909 + slow)
+    fam = [related(r, 2600, None)[1] for _ in range(3)]
+    a, b = related(r, 5000, None)
+    tasks = [(fam, [5, 0, 9], None, None)]
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    wantp = oracle_progressive([a, b], [3, 1])
+    monkeypatch.setenv("CSADP_TEST_SLOW_PUBLISHER", str(slow))
+    got = csa_amd.align_batch(tasks)
+    for g, (cons, strs, st) in zip(got, want):
+        assert g["status"] == 0 and g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
+    monkeypatch.setenv("CSADP_BITS", "0")                     # the pair's first fill on nw_fill_cells too
+    g = csa_amd.align_batch([([a, b], [3, 1], None, None)])[0]
+    assert g["status"] == 0 and g["aligned"] == wantp[1] and g["score"] == wantp[2].last_score
