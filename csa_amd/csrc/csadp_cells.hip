@@ -164,14 +164,18 @@ __device__ __forceinline__ void granule_reload(unsigned long long &dst, const un
 {
 	asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "+v"(dst) : "v"(p) : "memory");
 }
-/* vmcnt counts in order and EVERY block issues exactly one request after consuming one: when a request is due,
- * exactly one younger request is in flight (the direction stores between them are a block old), and behind it the letters of this
- * block, asked for by the last statement */
+/* vmcnt counts in order.  When the request for block b is due (head of block b), the wave has issued behind it, oldest first: the four
+ * direction stores of block b - 1 (a block old: long done), the request for block b + 1 (kGranuleAhead == 2: issued in block b - 1), and the
+ * two letter loads the last statement asked for at its step 18.  Everything YOUNGER than the due request that should stay in flight: the
+ * next request and the two letter loads = 3 (2 when requests go one block ahead).  Round 4 waited for vmcnt(2) / (1), i.e. also for the
+ * request issued one block earlier -- less than a trip through memory: the latency the two-ahead request was meant to hide was partly
+ * paid (round-4 ADVICE; A/B of the plain layout: profiles/r05_granule_wait_ab.txt). */
+#ifndef CSADP_GRANULE_KEEP
+#define CSADP_GRANULE_KEEP (kGranuleAhead == 2 ? 3 : 2)
+#endif
 __device__ __forceinline__ void granule_wait(unsigned long long &dst)
 {
-	/* younger than the request that is due: the next request (two blocks ahead) and the letters the last statement asked for */
-	if (kGranuleAhead == 2) asm volatile("s_waitcnt vmcnt(2)" : "+v"(dst) : : "memory");
-	else asm volatile("s_waitcnt vmcnt(1)" : "+v"(dst) : : "memory");
+	asm volatile("s_waitcnt vmcnt(%1)" : "+v"(dst) : "n"(CSADP_GRANULE_KEEP) : "memory");
 }
 
 #ifdef CSADP_CELL_TIMERS

@@ -20,6 +20,7 @@ struct Config {
 	int bits_lds_pad = -1;          /* CSADP_BITS_LDS_PAD: KiB of dynamic LDS a fill workgroup reserves */
 	bool lone_shape = true;         /* CSADP_LONE_SHAPE: a pass flushed alone takes the spread shape (csadp_engine.h) */
 	int stream_rotate = -1;         /* CSADP_STREAM_ROTATE: batches of one engine start on different streams (default: by batch size) */
+	bool cells_fetch_forced = false; /* CSADP_CELLS_FETCH was set: taken as it is; else min(256, the device's compute units) */
 	int cells_fetch_wgs = 256;      /* CSADP_CELLS_FETCH: cell-per-lane launches of at most this many workgroups carry a fetcher wave (0: none) */
 	bool lone_cells = true;         /* CSADP_LONE_CELLS: at most 8 large square-ish pairs alone take the cell-per-lane path (FillBatch::layout) */
 	int slots = 4;                  /* CSADP_SLOTS: result / scratch sets of a pipelined cell-per-lane batch */
@@ -39,6 +40,8 @@ struct Config {
 	int local_rank = 0;             /* LOCAL_RANK: default device ordinal */
 	/* testing */
 	int test_slow_publisher = 0;    /* CSADP_TEST_SLOW_PUBLISHER: the publisher wave of nw_fill_cells sleeps this many x 127 x 64 cycles per half block (tests) */
+	int test_range_log2 = 31;       /* CSADP_TEST_RANGE_LOG2: the gain form's score range as a power of two (31; tests lower it to reach CSADP_ERR_RANGE) */
+	int test_hbm_limit_mb = 0;      /* CSADP_TEST_HBM_LIMIT_MB: pretend the device has only this much free memory (0: ask the device) */
 	bool test_force_abort = false;  /* CSADP_TEST_FORCE_ABORT: pretend a bounded wait of a chunked fill ran out */
 };
 

@@ -140,6 +140,7 @@ int Engine::init(int dev, const csadp_config *cfg)
 	if (slots_ < 1 || slots_ > kMaxSlots) return CSADP_ERR_ARG;
 	nstreams_ = 2 * main_streams();
 	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipStreamCreateWithFlags(&streams_[i], hipStreamNonBlocking));
+	for (int i = 0; i < nstreams_; ++i) HIP_TRY(hipEventCreateWithFlags(&busy_ev_[i], hipEventDisableTiming));
 	HIP_TRY(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
 	HIP_TRY(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
 	HIP_TRY(configure_kernels());                     /* per-device function attributes (csadp_bits.hip) */
@@ -147,6 +148,22 @@ int Engine::init(int dev, const csadp_config *cfg)
 	verbose_ = cfg && cfg->verbose;
 	ready_ = true;
 	return CSADP_OK;
+}
+
+int Engine::mark_busy(int stream_index, hipStream_t st)
+{
+	if (stream_index < 0 || stream_index >= nstreams_) return CSADP_ERR_ARG;
+	HIP_TRY(hipEventRecord(busy_ev_[stream_index], st));
+	busy_mask_.fetch_or(1ull << stream_index);
+	return CSADP_OK;
+}
+
+bool Engine::device_idle()
+{
+	const unsigned long long m = busy_mask_.load();
+	for (int i = 0; i < nstreams_; ++i)
+		if (((m >> i) & 1ull) && hipEventQuery(busy_ev_[i]) != hipSuccess) return false;
+	return true;
 }
 
 int Engine::warm_copy_paths()
@@ -262,7 +279,10 @@ void Engine::shutdown()
 		(void)hipStreamSynchronize(streams_[i]);
 		(void)hipStreamDestroy(streams_[i]);
 		streams_[i] = nullptr;
+		if (busy_ev_[i]) (void)hipEventDestroy(busy_ev_[i]);
+		busy_ev_[i] = nullptr;
 	}
+	busy_mask_.store(0);
 	if (copy_stream_) {
 		(void)hipStreamSynchronize(copy_stream_);
 		(void)hipStreamDestroy(copy_stream_);
@@ -361,6 +381,15 @@ int FillBatch::add(int nrows, int ncols, int nprev, int left_i)
  * csadp_cells.hip) and a matrix takes (rows + 0.66 cols) x 41 ns there, its band-parallel walk a fifth of the bit-parallel path's serial
  * one -- against 86 ns per row plus 17 for the walk (tools/single_probe.py: 16 384^2 1.23 ms on the device against 1.75, 100 000^2
  * 7.5 against 10.2).  The bit-parallel kernels are built for batches; these are not one.  (A pair's columns are its shorter sequence.) */
+/* The helper-wave layout of nw_fill_cells wants one workgroup per compute unit (every chain alone on its units): the limit follows the
+ * device's compute units -- a partitioned or smaller part has fewer than the 256 of a whole MI355X (round-4 ADVICE) -- unless
+ * CSADP_CELLS_FETCH was set explicitly. */
+int cells_fetch_limit(const Engine &E)
+{
+	const Config &cfg = config();
+	return cfg.cells_fetch_forced ? cfg.cells_fetch_wgs : std::min(cfg.cells_fetch_wgs, E.compute_units());
+}
+
 bool FillBatch::lone_pairs_take_cells() const
 {
 	const Config &cfg = config();
@@ -370,7 +399,7 @@ bool FillBatch::lone_pairs_take_cells() const
 		if (J.nprev != 1 || J.leftmul != 0 || J.nrows < 4096 || J.ncols > 2L * J.nrows || J.ncols <= 0) return false;
 		chunks += (J.ncols + kCellStripCols * kCellWaves - 1) / (kCellStripCols * kCellWaves);
 	}
-	return chunks <= cfg.cells_fetch_wgs;      /* (run_slot_cells: when a launch takes the fetcher layout) */
+	return chunks <= cells_fetch_limit(*E_);   /* (run_slot_cells: when a launch takes the fetcher layout) */
 }
 
 int FillBatch::layout()
@@ -424,7 +453,7 @@ int FillBatch::layout_cells()
 		if (J.nrows <= 0 || J.ncols <= 0) return CSADP_ERR_ARG;
 		const long long nprev = J.nprev;
 		if (nprev < 1 || nprev > 63) return CSADP_ERR_ARG;
-		if (nprev * (2LL * J.nrows + J.ncols) * 4 + 64 >= (1LL << 31)) return CSADP_ERR_RANGE;
+		if (nprev * (2LL * J.nrows + J.ncols) * 4 + 64 >= (1LL << config().test_range_log2)) return CSADP_ERR_RANGE;
 		if (nprev > 21) wide_ = true;                  /* nw_fill_cells folds leftc into the gain bytes: 12 * nprev + 1 <= 255 */
 		CellJob &C = cjobs_[(size_t)j];
 		memset(&C, 0, sizeof(C));
@@ -459,7 +488,8 @@ int FillBatch::layout_cells()
 	 * batch of MANY banded matrices has its parallelism in the jobs: past ~5 000 scout workgroups one serial walk per job is shorter
 	 * (tools/r04/fetch_threshold_probe.py, matrices of 5 000 x 6 187: the walk of 48 of them 0.50 ms either way, of 96 0.77 banded and
 	 * 0.53 serial; of 8 0.25 against 0.49).  Not when the tests ask for bands (CSADP_TB_BAND_MIN set). */
-	if (!band_forced && banded_bands * std::max(1, tb_corridor) > 5000) {
+	const long cus = std::max(1, E.compute_units());
+	if (!band_forced && banded_bands * std::max(1, tb_corridor) > 5000 * cus / 256) {
 		for (CellJob &C : cjobs_) C.banded = 0;
 		tb_max_bands_ = 0;
 		banded_bands = 0;
@@ -469,7 +499,7 @@ int FillBatch::layout_cells()
 		if (!C.banded) continue;
 		const int ngroups = (C.ncols / kBandStride + 1 + kScoutStarts - 1) / kScoutStarts;
 		int want = std::max(1, tb_corridor);
-		if (!cfg.tb_corridor_forced) want = std::max(want, (int)(256 / std::max(1L, banded_bands)));
+		if (!cfg.tb_corridor_forced) want = std::max(want, (int)(cus / std::max(1L, banded_bands)));
 		/* at most as many groups as let one band's table row fit the resolve kernel's LDS table (64 KiB of u16) */
 		C.tb_groups = std::min(std::min(ngroups, want), 64 * 1024 / 2 / kScoutStarts);
 		C.tb_pitch = C.tb_groups * kScoutStarts;
@@ -960,10 +990,13 @@ int FillBatch::alloc_buffers()
 	}
 	if (total_bytes_ > arena_cap_) {
 		size_t free_b = 0, total_b = 0;
+		const size_t pretend = (size_t)config().test_hbm_limit_mb << 20;       /* test seam: a device with little memory left */
 		HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+		if (pretend) free_b = std::min(free_b, pretend);
 		if (total_bytes_ + (256u << 20) > free_b) {
 			E.drop_arena_cache();
 			HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+			if (pretend) free_b = std::min(free_b, pretend);
 		}
 		if (total_bytes_ + (256u << 20) > free_b) {
 			fprintf(stderr, "csadp: batch needs %.1f GiB of HBM, %.1f GiB free\n",
@@ -1126,9 +1159,10 @@ int FillBatch::flush_bits(int k)
 {
 	Engine &E = *E_;
 	const int mainN = E.main_streams();
-	if (k == 1 && lone_.on && idle_now()) {
+	if (k == 1 && lone_.on && idle_now() && E.device_idle()) {
 		const int q = base_stream_ % mainN;
-		const int rc = launch_bits_pass(lone_.slot, 1, E.stream(q), E.stream(mainN + q), false, true);
+		int rc = launch_bits_pass(lone_.slot, 1, E.stream(q), E.stream(mainN + q), false, true);
+		if (rc == CSADP_OK) rc = E.mark_busy(mainN + q, E.stream(mainN + q));
 		if (rc != CSADP_OK) return rc;
 		last_stream_ = mainN + q;
 		last_first_ = last_slot_ = lone_.slot;
@@ -1143,7 +1177,8 @@ int FillBatch::flush_bits(int k)
 		const int qs = piped ? mainN + q : q;                           /* its side stream */
 		const int first = (qi * 2 + parity) * bits_group_;
 		const int g = std::min(k, bits_group_);
-		const int rc = launch_bits_pass(first, g, E.stream(q), E.stream(qs), false);
+		int rc = launch_bits_pass(first, g, E.stream(q), E.stream(qs), false);
+		if (rc == CSADP_OK) rc = E.mark_busy(qs, E.stream(qs));
 		last_stream_ = qs;
 		if (rc != CSADP_OK) return rc;
 		last_first_ = first;
@@ -1277,7 +1312,7 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	 * the layout with a fetcher and a publisher wave (csadp_cells.hip, fetch_granules, publish_halves).  More: a compute unit holds two
 	 * workgroups of four waves, but only one of six.  (ONE matrix of 391 chunks in that layout, its later chunks starting as the first ones end: a 200 kbp pair fills in
 	 * 19.15 ms, as in the plain layout, and the bit-parallel path stays ahead host to host: 20.5 against 22.3 ms.) */
-	const bool fetch = (int)tiles_.size() <= config().cells_fetch_wgs;
+	const bool fetch = (int)tiles_.size() <= cells_fetch_limit(*E_);
 	if (!serial) {
 		HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st,
 		                          config().test_slow_publisher));

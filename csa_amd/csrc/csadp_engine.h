@@ -65,6 +65,11 @@ public:
 	/* csadp_warmup: the first memset / copy of either direction and of either size class (blit kernel, copy engine) on every
 	 * stream of the engine, paid now (profiles/r05_dropin_hiptrace: 3-9 ms each inside a process' first batch) */
 	int warm_copy_paths();
+	/* Engine-wide idleness for the launch shaping of pair batches: every pass of EVERY batch records the end of its work here (one event
+	 * per stream, re-recorded by each launch on it); device_idle() is true when all of them have been reached.  A batch's own events say
+	 * nothing about the device: a streaming caller's batches are each "idle" by themselves (round-4 ADVICE). */
+	int mark_busy(int stream_index, hipStream_t st);
+	bool device_idle();
 
 	/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) per device alive
 	 * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per input set) */
@@ -84,6 +89,8 @@ private:
 	hipStream_t streams_[2 * kMaxSlots] = {};
 	hipStream_t copy_stream_ = nullptr;
 	hipStream_t upload_stream_ = nullptr;
+	hipEvent_t busy_ev_[2 * kMaxSlots] = {};
+	std::atomic<unsigned long long> busy_mask_{0};       /* streams whose busy event has ever been recorded */
 	std::atomic<int> stream_rr_{0};
 	std::mutex pool_mutex_;
 	std::vector<std::pair<uint8_t *, size_t>> arena_pool_, pinned_pool_;

@@ -192,6 +192,7 @@ Config read_config()
 	c.lone_shape = env_int("CSADP_LONE_SHAPE", 1) != 0;
 	c.stream_rotate = env_int("CSADP_STREAM_ROTATE", -1);
 	c.cells_fetch_wgs = env_int("CSADP_CELLS_FETCH", 256);
+	c.cells_fetch_forced = getenv("CSADP_CELLS_FETCH") != nullptr;
 	c.lone_cells = env_int("CSADP_LONE_CELLS", 1) != 0;
 	c.slots = env_int("CSADP_SLOTS", 4);
 	c.tb_band_min = env_int("CSADP_TB_BAND_MIN", 512);
@@ -206,6 +207,8 @@ Config read_config()
 	c.share_device = env_int("CSADP_SHARE_DEVICE", 0) != 0;
 	c.local_rank = env_int("LOCAL_RANK", 0);
 	c.test_force_abort = env_int("CSADP_TEST_FORCE_ABORT", 0) != 0;
+	c.test_range_log2 = std::max(8, std::min(31, env_int("CSADP_TEST_RANGE_LOG2", 31)));
+	c.test_hbm_limit_mb = std::max(0, env_int("CSADP_TEST_HBM_LIMIT_MB", 0));
 	c.test_slow_publisher = std::max(0, std::min(255, env_int("CSADP_TEST_SLOW_PUBLISHER", 0)));
 	return c;
 }

@@ -671,3 +671,50 @@ def test_batches_in_flight_are_independent():
                 assert sp_score(g["aligned"]) == g["score"]
         for pb in batches:
             pb.close()
+
+
+def test_score_range_limit_of_the_gain_form(monkeypatch):
+    """csadp_engine.cpp, layout_cells: the 32-bit kernel keeps X = 4 H + 4 i r with two tag bits, so a fill needs
+    i (2 nrows + ncols) 4 + 64 < 2^31, else CSADP_ERR_RANGE for the batch (the reference's counterpart is an int that would
+    overflow silently, dynamicprogramming.c:996-1012).  A real fill at that bound is 180 M letters against one sequence or 2.8 M
+    against 63: the test lowers the bound (CSADP_TEST_RANGE_LOG2) until the LAST step of a 5-sequence family crosses it --
+    the steps before it run, the call reports the range error, and the same task passes again at the real bound."""
+    r = rng(4711)
+    fam = random_family(r, 5, 3000, mut=0.1, indel=0.03)
+    small = random_family(r, 3, 300)
+    cons, strs, st = oracle_progressive(fam, None)
+    need = [i * (2 * len(sorted(fam, key=len)[i]) + cons) * 4 + 64 for i in range(1, 5)]      # roughly: consensus grows from step to step
+    bits = max(need).bit_length() - 1                     # 2^bits <= the largest step's need
+    assert (1 << bits) > need[1]                          # ... and the early steps fit
+    monkeypatch.setenv("CSADP_TEST_RANGE_LOG2", str(bits))
+    with pytest.raises(csa_amd.CsadpError) as e:
+        csa_amd.align_batch([(fam, None, None, None), (small, None, None, None)])
+    assert e.value.code == csa_amd.ERR_RANGE
+    got = csa_amd.align_batch([(small, None, None, None)])            # the library is in order after the error
+    assert got[0]["status"] == 0 and got[0]["aligned"] == oracle_progressive(small, None)[1]
+    monkeypatch.delenv("CSADP_TEST_RANGE_LOG2")
+    got = csa_amd.align_batch([(fam, None, None, None)])
+    assert got[0]["status"] == 0 and got[0]["aligned"] == strs and got[0]["score"] == st.last_score
+
+
+def test_batch_that_does_not_fit_the_device_memory(monkeypatch, capfd):
+    """csadp_engine.cpp, alloc_buffers: a batch whose arena does not fit the device's free memory (less 256 MB) is refused with
+    CSADP_ERR_RANGE and a line on stderr -- the reference's counterpart is an unchecked malloc per matrix row
+    (dynamicprogramming.c:964-981).  CSADP_TEST_HBM_LIMIT_MB pretends a device with 264 MB free (8 MB usable): a 3-sequence family of 12 000
+    letters needs 36 MB of direction words and more per step, a family of 400 fits."""
+    r = rng(1812)
+    big = random_family(r, 3, 12000, mut=0.1, indel=0.02)
+    small = random_family(r, 3, 400)
+    csa_amd.shutdown()                                    # drop the cached arenas of earlier tests: the batch must ask for memory
+    csa_amd.init(device=0)
+    monkeypatch.setenv("CSADP_TEST_HBM_LIMIT_MB", "264")
+    got = csa_amd.align_batch([(small, None, None, None)])
+    assert got[0]["status"] == 0 and got[0]["aligned"] == oracle_progressive(small, None)[1]
+    with pytest.raises(csa_amd.CsadpError) as e:
+        csa_amd.align_batch([(big, None, None, None)])
+    assert e.value.code == csa_amd.ERR_RANGE
+    assert "GiB of HBM" in capfd.readouterr().err
+    monkeypatch.delenv("CSADP_TEST_HBM_LIMIT_MB")
+    got = csa_amd.align_batch([(big, None, None, None)])
+    cons, strs, st = oracle_progressive(big, None)
+    assert got[0]["status"] == 0 and got[0]["aligned"] == strs and got[0]["score"] == st.last_score
