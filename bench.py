@@ -65,13 +65,61 @@ ALG_BYTES_PER_CELL = 0.25             # the 2-bit direction of ever
 PREWARM_S = 1.0                       # untimed passes before the W warm-up steps of `value`: the device leaves its idle clocks (main())
 
 
+PROFILE_ROUNDS = ("r05", "r04")        # the committed rocprofv3 summaries of the newest round that has them
+
+
+def profile_file(name):
+    """profiles/<round>_<name> of the newest round that committed one, or None."""
+    for rnd in PROFILE_ROUNDS:
+        path = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, name))
+        if os.path.exists(path):
+            return path
+    return None
+
+
 def pmc_summary(kernel):
-    """Per-launch PMC figures of `kernel` from this round's committed rocprofv3 passes, or None."""
+    """Per-launch PMC figures of `kernel` from the committed rocprofv3 passes (tools/profile_round.sh, tools/summarize_profile.py), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r04_pmc_summary.json")) as f:
+        with open(profile_file("pmc_summary.json")) as f:
             return json.load(f)[kernel]
     except Exception:
         return None
+
+
+def kernel_stats_row(csv_name, kernel_prefix):
+    """(calls, average ns) of the first kernel whose name contains `kernel_prefix` in a committed `rocprofv3 --kernel-trace --stats` summary."""
+    import csv
+    path = profile_file(csv_name)
+    if not path:
+        return None
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel_prefix in row["Name"]:
+                    return {"file": os.path.relpath(path, ROOT), "kernel": row["Name"].split("(")[0], "calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3}
+    except Exception:
+        return None
+    return None
+
+
+def roofline_from_profiles(valu_per_cell, launch_cells, wpl):
+    """The roofline fraction twice more, each recomputable from ONE committed file under profiles/ (round-4 VERDICT, item 5):
+    frac_from_kernel_duration = VALU lane-ops of one launch / rocprofv3's average duration of that launch alone on the device / peak;
+    frac_from_counters = SQ_INSTS_VALU x 2 issue cycles / SQ_WAVE_CYCLES of the same launch shape (one wave per SIMD: the wave's own
+    share of its SIMD's issue slots).  Both describe a launch ALONE (one wave per SIMD); `frac` beside them is VALU work over the WALL time
+    of the pre-warmed timed region with two launches in flight."""
+    out = {}
+    row = kernel_stats_row("bench_kernel_solo.csv", "nw_fill_bits<%d" % wpl)
+    if row:
+        tops = valu_per_cell * launch_cells / (row["avg_us"] * 1e-6) / 1e12
+        out["kernel_avg_us"] = round(row["avg_us"], 1)
+        out["frac_from_kernel_duration"] = round(tops / VALU_PEAK_TOPS, 4)
+        out["kernel_duration_source"] = "%s: %s, %d calls" % (row["file"], row["kernel"], row["calls"])
+    pmc = pmc_summary("nw_fill_bits")
+    if pmc and pmc.get("valu_insts_per_wave") and pmc.get("wave_cycles_per_wave_x4"):
+        out["frac_from_counters"] = round(pmc["valu_insts_per_wave"] * 2.0 / pmc["wave_cycles_per_wave_x4"], 4)
+        out["counters_source"] = "%s: SQ_INSTS_VALU / SQ_WAVES x 2 / (SQ_WAVE_CYCLES x 4 / SQ_WAVES)" % os.path.relpath(profile_file("pmc_summary.json"), ROOT)
+    return out
 
 
 def host_description():
@@ -160,7 +208,7 @@ def one_shot_leg(csa_amd, tasks):
         cur = {"device_ms": round(tm["total_ms"], 3), "fill_ms": round(tm["fill_ms"], 3), "traceback_expand_ms": round(tm["traceback_ms"], 3),
                "create_ms": round((t1 - t0) * 1e3, 2), "run_and_wait_ms": round((t2 - t1) * 1e3, 2), "fetch_ms": round((t3 - t2) * 1e3, 2),
                "gcups_device": round(tm["cells"] / tm["total_ms"] / 1e6, 1), "gcups_create_to_fetch": round(tm["cells"] / (t3 - t0) / 1e9, 1),
-               "words_per_lane": tm["words_per_lane"], "ok": ok}
+               "words_per_lane": tm["words_per_lane"], "ok": ok, "recoveries": tm["recoveries"]}
         if best is None or cur["device_ms"] < best["device_ms"]:
             best = cur
     best["what"] = ("one pass of the same %d pairs with nothing else on the chip (best of 3): device_ms = HIP events around pack + fill + "
@@ -413,7 +461,7 @@ def real_sets_leg(csa_amd, steps=48, warmup=8):
         out[setname] = {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
                         "ms_per_step": round(dt * 1e3 / steps, 3), "steps": steps, "warmup": warmup,
                         "equal_to_reference_digests": same, "words_per_lane": tm["words_per_lane"],
-                        "passes_per_launch": tm["merge_group"], "launches_in_flight": tm["streams"]}
+                        "passes_per_launch": tm["merge_group"], "launches_in_flight": tm["streams"], "recoveries": tm["recoveries"]}
     out["what"] = ("config 3: the 66 Mammals and the 120 Primates whole-sequence pairs (16.3-17.7 k letters, gap-rich paths), letters in HBM -> "
                    "aligned rows in HBM, timed like `value`")
     return out
@@ -441,7 +489,7 @@ def config5_leg(csa_amd, steps=3, warmup=1):
                (g["sp"], g["consensus"], int(g["fnv1a"], 16)))
     return {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
             "ms_per_step": round(dt * 1e3 / steps, 2), "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"],
-            "properties_hold_for_all": bool(ok), "reference_digests": len(gold), "equal_to_reference_digests": same,
+            "properties_hold_for_all": bool(ok), "reference_digests": len(gold), "equal_to_reference_digests": same, "recoveries": tm["recoveries"],
             "what": "256 synthetic pairs of 1-200 kbp in one batch (jobs of up to 33 strips run as chains of workgroups)"}
 
 
@@ -464,7 +512,7 @@ def unrelated_leg(csa_amd, steps=20, warmup=5):
                (g["sp"], g["consensus"], int(g["fnv1a"], 16)))
     return {"pairs": len(tasks), "gcups": round(tm["cells"] * steps / dt / 1e9, 1), "ms_per_step": round(dt * 1e3 / steps, 3),
             "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"], "properties_hold_for_all": bool(ok),
-            "equal_to_reference_digests": same,
+            "equal_to_reference_digests": same, "recoveries": tm["recoveries"],
             "what": "64 unrelated random 16384-letter pairs, every record against the compiled reference's (tests/golden/unrelated_pairs.json)"}
 
 
@@ -480,7 +528,7 @@ def config4_all_leg(csa_amd, first_tasks, steps=4, warmup=1):
                (r["score"], r["consensus"], csa_amd.fnv1a(r["aligned"])) == (gold["sp"][p], gold["consensus"][p], int(gold["fnv1a"][p], 16)))
     return {"pairs": len(tasks), "cells_per_step": tm["cells"], "gcups": round(tm["cells"] * steps / dt / 1e9, 1),
             "ms_per_step": round(dt * 1e3 / steps, 3), "steps": steps, "warmup": warmup, "words_per_lane": tm["words_per_lane"],
-            "equal_to_reference_digests": same,
+            "equal_to_reference_digests": same, "recoveries": tm["recoveries"],
             "what": "all 1024 pairs of config 4 in one batch on one GPU; every (score, consensus, FNV-1a of the rows) equal to the compiled reference's"}
 
 
@@ -521,7 +569,8 @@ def profile_path_leg(csa_amd):
             walls.append(wall)
             if best is None or st["dp_ms"] < best["dp_ms"]:
                 best = {"dp_ms": round(st["dp_ms"], 2), "total_ms": round(wall * 1e3, 1), "fills": st["fills"],
-                        "gaps": st["dp_gaps"], "cells": st["cells"], "gcups": round(st["cells"] / st["dp_ms"] / 1e6, 1)}
+                        "gaps": st["dp_gaps"], "cells": st["cells"], "gcups": round(st["cells"] / st["dp_ms"] / 1e6, 1),
+                        "recoveries": st.get("recoveries", 0)}
         if best is not None:
             best["total_ms_best"] = round(min(walls) * 1e3, 1)
         out[name] = best
@@ -550,7 +599,7 @@ def single_matrix_leg(csa_amd):
         pb.close()
         out[str(length)] = {"fill_ms": round(best["fill_ms"], 3), "traceback_expand_ms": round(best["traceback_ms"], 3),
                             "gcups": round(len(a) * len(b) / best["total_ms"] / 1e6, 1),
-                            "path": "cell-per-lane" if best["words_per_lane"] == 0 else "bit-parallel"}
+                            "path": "cell-per-lane" if best["words_per_lane"] == 0 else "bit-parallel", "recoveries": best["recoveries"]}
     return out
 
 
@@ -774,7 +823,10 @@ def main():
                        "passes_per_launch": max(tm_pipe["launch_passes"], 1), "device_io": tm["device_io"],
                        "parallelism": "independent tasks over %d GPU(s); no collective in the timed region; result records "
                                       "all-gathered over %s afterwards" % (args.gpus, "RCCL" if args.backend == "nccl" else "gloo"),
-                       "lpt_imbalance": round(imbalance, 4)},
+                       "lpt_imbalance": round(imbalance, 4),
+                       # the clock story where the driver's parser keeps it: `value` follows PREWARM_S seconds of untimed passes;
+                       # the same W + K steps from idle clocks (what rounds 1-3 reported as `value`) are value_from_idle_gcups
+                       "prewarm_s": PREWARM_S, "value_from_idle_gcups": round(cells_step * args.steps / elapsed_idle / 1e9, 3)},
             "records": {"gathered": len(by_id), "checked_against_reference_digests": checked,
                         "rows_on_rank0": len(rows_by_id), "rows_match_their_records": bool(rows_ok),
                         "rows_bytes": sum(len(x) for v in rows_by_id.values() for x in v), "rows_gather_ms": round(gather_s * 1e3, 2)},
@@ -801,12 +853,13 @@ def main():
                                  "as well as the time: `value` is the figure to compare across rounds" % (
                                      round(valu_per_cell * 32 * wpl), 32 * wpl, wpl, tm_pipe["streams"], valu_per_cell),
                          "valu_per_cell": round(valu_per_cell, 4), "words_per_lane": wpl,
+                         **roofline_from_profiles(valu_per_cell, launch_cells, wpl),
                          "frac_at_round2_instructions_per_cell": round(sustained_tops / valu_per_cell * (31.0 / 32.0) / VALU_PEAK_TOPS, 4),
                          "one_launch_alone": {"cells": launch_cells, "avg_launch_us": round(tm["fill_ms"] * 1e3, 1),
                                               "achieved": round(alone_tops, 2), "frac": round(alone_tops / VALU_PEAK_TOPS, 4),
                                               "what": "HIP events around ONE launch with nothing else in flight (one workgroup "
                                                       "per compute unit; the timed region keeps two such launches in "
-                                                      "flight); rocprofv3: profiles/r04_bench_kernel_solo.csv"},
+                                                      "flight); rocprofv3: kernel_duration_source"},
                          "calibrated": {"peak_gcups": round(calibrated_peak_gcups, 1),
                                         "frac_alone": round(launch_cells / fill_s / 1e9 / calibrated_peak_gcups, 4),
                                         "frac_sustained": round(value / args.gpus / calibrated_peak_gcups, 4),

@@ -61,7 +61,7 @@ class MsaStats(ctypes.Structure):
     _fields_ = [("nseq", ctypes.c_int), ("border_nodes", ctypes.c_int), ("segments", ctypes.c_int),
                 ("dp_gaps", ctypes.c_int), ("fills", ctypes.c_int), ("alignment_length", ctypes.c_int),
                 ("cells", ctypes.c_longlong), ("rotations_ms", ctypes.c_double), ("anchors_ms", ctypes.c_double),
-                ("dp_ms", ctypes.c_double), ("rows_ms", ctypes.c_double)]
+                ("dp_ms", ctypes.c_double), ("rows_ms", ctypes.c_double), ("recoveries", ctypes.c_int)]
 
 
 class Timing(ctypes.Structure):

@@ -47,6 +47,8 @@ struct Config {
 
 const Config &config();
 void reload_config();
+/* passes the primary engine's batches have repeated chunk by chunk so far (csadp_engine.cpp); 0 before the library is initialised */
+long primary_engine_recoveries();
 
 }  // namespace csadp
 

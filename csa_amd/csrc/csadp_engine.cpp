@@ -150,6 +150,12 @@ int Engine::init(int dev, const csadp_config *cfg)
 	return CSADP_OK;
 }
 
+long primary_engine_recoveries()
+{
+	Engine *E = Engine::primary_if_ready();
+	return E ? E->recoveries.load() : 0;
+}
+
 int Engine::mark_busy(int stream_index, hipStream_t st)
 {
 	if (stream_index < 0 || stream_index >= nstreams_) return CSADP_ERR_ARG;
@@ -1259,6 +1265,7 @@ int FillBatch::check_abort()
 		if (*h_abort_ == 0) return CSADP_OK;
 		fprintf(stderr, "csadp: a wait of the cell-per-lane fill timed out; repeating the pass chunk by chunk\n");
 		++recoveries_;
+	++E_->recoveries;
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 0, 4, st));
 		const int rc = run_slot_cells(last_slot_, true);
 		if (rc != CSADP_OK) return rc;
@@ -1281,6 +1288,7 @@ int FillBatch::check_abort()
 	}
 	fprintf(stderr, "csadp: a cross-workgroup wait of the chunked fill timed out; repeating the pass chunk by chunk\n");
 	++recoveries_;
+	++E_->recoveries;
 	HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 0, 4, st));
 	const int rc = launch_bits_pass(last_first_, last_slot_ - last_first_ + 1, st, st, true, last_lone_);
 	if (rc != CSADP_OK) return rc;

@@ -73,6 +73,7 @@ public:
 
 	/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) per device alive
 	 * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per input set) */
+	std::atomic<long> recoveries{0};              /* passes of any batch of this engine repeated chunk by chunk (FillBatch::check_abort) */
 	std::mutex batch_mutex;
 	FillBatch *cached_batch = nullptr;
 	std::vector<FillBatch *> extra_batches;       /* ... and the arenas of the further round groups (guarded by batch_mutex too) */

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "csadp.h"
+#include "csadp_config.h"
 
 namespace {
 
@@ -106,7 +107,9 @@ int csadp_msa(int nseq, const char *const *texts, const int *sizes, const int *r
 		return init_rc;
 	}
 	if (ntasks > 0) {
+		const long rec0 = csadp::primary_engine_recoveries();
 		rc = csadp_align_batch(tasks.data(), ntasks, results.data());
+		st.recoveries = (int)(csadp::primary_engine_recoveries() - rec0);
 		if (rc == CSADP_OK)
 			for (int t = 0; t < ntasks && rc == CSADP_OK; ++t) rc = results[(size_t)t].status;
 		if (rc != CSADP_OK) {

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define CSADP_VERSION 400
+#define CSADP_VERSION 500
 
 /* only the C-ABI below is exported from libcsadp.so */
 #define CSADP_API __attribute__((visibility("default")))
@@ -287,6 +287,7 @@ typedef struct csadp_msa_stats {
 	int alignment_length;     /* length of row 0 ("Alignment size")                                        */
 	long long cells;
 	double rotations_ms, anchors_ms, dp_ms, rows_ms;
+	int recoveries;           /* (version 500) passes of the DP batch repeated chunk by chunk after a bounded cross-workgroup wait ran out; 0 in any healthy run */
 } csadp_msa_stats;
 
 /*

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         declared |= set(re.findall(r"\b(csadp_[a-z_0-9]+)\s*\(", text))
     declared -= {"csadp_debug_fill_fn"}
     assert declared == set(csa_amd.EXPORTS)
-    assert lib.csadp_version() == 400
+    assert lib.csadp_version() == 500
 
 
 def test_dropin_object_defines_progressivedp():
