@@ -192,6 +192,32 @@ def test_align_batch_multi_equals_single_device():
     assert st["max_cost"] == max(st["cost"]) and min(st["tasks"]) >= 1
 
 
+def test_align_batch_multi_with_eight_logical_devices(monkeypatch):
+    """The one-process form of the 8-GPU run (`csa_pairs --gpus 8`, csadp_align_batch_multi with 8 devices), which no round could
+    measure on an 8-GPU node: on a box with fewer GPUs CSADP_SHARE_DEVICE=1 maps the ordinals onto the visible ones, so eight host
+    threads each take their LPT share of a mixed batch (pairs of 300 .. 20 000 letters, families of 3 .. 6 sequences) through
+    csadp_align_batch_on.  Results in task order, equal to the single call; the split balanced within 5 %; every device has work."""
+    csa_amd.init(device=0)
+    if csa_amd.device_count() < 8:
+        monkeypatch.setenv("CSADP_SHARE_DEVICE", "1")
+    r = rng(808)
+    tasks = []
+    for i in range(96):
+        if i % 4 == 3:
+            fam = random_family(r, r.choice([3, 4, 6]), r.choice([200, 1200, 3000]), mut=0.1, indel=0.04)
+        else:
+            fam = random_family(r, 2, r.choice([300, 2000, 6000, 20000]), mut=0.1, indel=0.03)
+        fam = [f if f else b"G" for f in fam]
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    base = csa_amd.align_batch(tasks)
+    got, st = csa_amd.align_batch_multi(tasks, list(range(8)))
+    assert [g["status"] for g in got] == [0] * len(tasks)
+    assert [g["aligned"] for g in got] == [b["aligned"] for b in base]
+    assert [g["score"] for g in got] == [b["score"] for b in base]
+    assert st["ndevices"] == 8 and sum(st["tasks"]) == len(tasks) and min(st["tasks"]) >= 1
+    assert st["max_cost"] * 8 <= 1.05 * st["total_cost"]
+
+
 def test_csa_pairs_over_two_devices(monkeypatch):
     """The C harness with --gpus 2: csadp_align_batch_multi from plain C.  CSADP_SHARE_DEVICE=1 lets the second
     ordinal fall back onto the one GPU of this box (rehearsal switch); the 66 Mammals pairs must still equal the

@@ -7,6 +7,8 @@ import socket
 import subprocess
 import sys
 
+import pytest
+
 from csa_amd.dist import shard_range
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -80,17 +82,22 @@ from csa_amd import dist as cdist
 from csa_amd.synth import config5_lengths, synth_pair
 from helpers import oracle_filler
 g = cdist.Group(backend="gloo")
-# a miniature of config 5: 40 pairs whose lengths spread 1:50, costs = cells
-la, lb = config5_lengths(40, seed=11)
+# a miniature of config 5: 40 pairs whose lengths spread 1:50, costs = cells; or (CSADP_TEST_CONFIG5=1) config 5 itself:
+# its 256 pairs dealt by their REAL costs (1e6 .. 4e10 cells), the letters scaled down 1:400 so that the CPU can align them
+npairs = 256 if os.environ.get("CSADP_TEST_CONFIG5") == "1" else 40
+la, lb = config5_lengths(npairs, seed=5 if npairs == 256 else 11)
+real_costs = [a * b for a, b in zip(la, lb)]
 la = [max(8, x // 400) for x in la]
 pairs = [synth_pair(3000 + i, length=n) for i, n in enumerate(la)]
-costs = [len(a) * len(b) for a, b, _, _ in pairs]
+costs = real_costs if npairs == 256 else [len(a) * len(b) for a, b, _, _ in pairs]
+if os.environ.get("CSADP_TEST_SKEW") == "1":      # one task that outweighs all others: a rank with ONE task, the rest with everything else
+    costs = [10 ** 9] + [1] * (npairs - 1)
 fill = oracle_filler()          # the DEVICE step is stubbed by the test seam (csadp_debug.h): no GPU here
 # rank 0 owns the real inputs: every other rank gets them through the packed pool (letters + rotations), like a FASTA batch
 seqs = [x for a, b, _, _ in pairs for x in (a, b)] if g.rank == 0 else None
 rots = [x for _, _, ra, rb in pairs for x in (ra, rb)] if g.rank == 0 else None
 pool, prot = g.broadcast_pool(seqs, rots)
-assert len(pool) == 80 and all(pool[2 * i] == pairs[i][0] and pool[2 * i + 1] == pairs[i][1] for i in range(40))
+assert len(pool) == 2 * npairs and all(pool[2 * i] == pairs[i][0] and pool[2 * i + 1] == pairs[i][1] for i in range(npairs))
 assert prot == [x for _, _, ra, rb in pairs for x in (ra, rb)]
 def align_mine(ids):
     out = []
@@ -107,7 +114,7 @@ g.close()
 ''' % (ROOT, ROOT)
 
 
-def _run_flow(tmp_path, world):
+def _run_flow(tmp_path, world, extra_env=None):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -116,11 +123,12 @@ def _run_flow(tmp_path, world):
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", CSADP_HOST_THREADS="2")
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     outs = []
     for p in procs:
-        out, err = p.communicate(timeout=300)
+        out, err = p.communicate(timeout=600)
         assert p.returncode == 0, err.decode()
         outs.append(json.loads(out.decode().strip().splitlines()[-1]))
     return sorted(outs, key=lambda o: o["rank"])
@@ -144,14 +152,48 @@ def test_two_rank_lpt_split_and_gather_equals_single_rank(tmp_path):
     assert two[0]["mine"] and two[1]["mine"] and not set(two[0]["mine"]) & set(two[1]["mine"])
 
 
-def test_bench_spawns_its_own_ranks_and_refuses_nothing(tmp_path):
-    """`python bench.py --gpus 2` invoked PLAINLY (the driver's form) must start the ranks itself:
+def test_eight_rank_flow_on_config5s_cost_vector(tmp_path):
+    """World 8 (gloo) -- the shape of the driver's scaling run, which no round has been able to measure on hardware: config 5's
+    256 pairs dealt by LPT over their REAL costs (1e6 .. 4e10 cells; SURVEY 8e expects <= 5 %% imbalance), pool broadcast, every
+    rank aligns its share (letters scaled 1:400, fills from the test seam), records all-gathered on ALL ranks, rows gathered to
+    rank 0 with very unequal shards (a rank holding the 200 kbp pairs has a handful of tasks, another several dozen).  Must equal
+    the single-rank outcome."""
+    env = {"CSADP_TEST_CONFIG5": "1"}
+    one = _run_flow(tmp_path, 1, env)[0]
+    eight = _run_flow(tmp_path, 8, env)
+    assert len(one["records"]) == 256 and len(eight) == 8
+    for o in eight:
+        assert o["world"] == 8 and o["records"] == one["records"]
+        assert o["imbalance"] <= 1.05
+    assert eight[0]["rows"] == one["rows"] and all(o["rows"] == {} for o in eight[1:])
+    shares = [o["mine"] for o in eight]
+    assert sorted(t for m in shares for t in m) == list(range(256))
+    assert all(len(m) >= 1 for m in shares)
+
+
+def test_row_gather_with_very_unequal_shards(tmp_path):
+    """gather_rows pads every rank's byte buffer to the longest one (one max-reduce, one gather): a split in which one rank holds a
+    single task and the others hold everything else -- what LPT does when one task outweighs the rest -- must still deliver every
+    row to rank 0, on 2 and on 3 ranks."""
+    env = {"CSADP_TEST_SKEW": "1"}
+    one = _run_flow(tmp_path, 1)[0]
+    for world in (2, 3):
+        outs = _run_flow(tmp_path, world, env)
+        assert outs[0]["mine"] == [0] and sum(len(o["mine"]) for o in outs) == 40
+        assert outs[0]["rows"] == one["rows"]
+        for o in outs:
+            assert o["records"] == one["records"]
+
+
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_spawns_its_own_ranks_and_refuses_nothing(tmp_path, gpus):
+    """`python bench.py --gpus N` (N = 2, and 8 as the driver's scaling run asks) invoked PLAINLY (the driver's form) must start the ranks itself:
     without a GPU the children fail inside csadp_init with the library's 'no device' error --
     not with a launcher error -- and the parent reports a non-zero exit code."""
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0",
                         "--pairs", "2", "--len", "64", "--no-cpu-baseline", "--backend", "gloo"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     err = p.stderr.decode()
