@@ -196,7 +196,7 @@ def test_align_batch_multi_with_eight_logical_devices(monkeypatch):
     """The one-process form of the 8-GPU run (`csa_pairs --gpus 8`, csadp_align_batch_multi with 8 devices), which no round could
     measure on an 8-GPU node: on a box with fewer GPUs CSADP_SHARE_DEVICE=1 maps the ordinals onto the visible ones, so eight host
     threads each take their LPT share of a mixed batch (pairs of 300 .. 20 000 letters, families of 3 .. 6 sequences) through
-    csadp_align_batch_on.  Results in task order, equal to the single call; the split balanced within 5 %; every device has work."""
+    csadp_align_batch_on.  Results in task order, equal to the single call; the split within LPT's bound; every device has work."""
     csa_amd.init(device=0)
     if csa_amd.device_count() < 8:
         monkeypatch.setenv("CSADP_SHARE_DEVICE", "1")
@@ -215,7 +215,8 @@ def test_align_batch_multi_with_eight_logical_devices(monkeypatch):
     assert [g["aligned"] for g in got] == [b["aligned"] for b in base]
     assert [g["score"] for g in got] == [b["score"] for b in base]
     assert st["ndevices"] == 8 and sum(st["tasks"]) == len(tasks) and min(st["tasks"]) >= 1
-    assert st["max_cost"] * 8 <= 1.05 * st["total_cost"]
+    # a few 20 000-letter pairs carry most of the cost: LPT's own bound (mean + the largest task), not 5 %
+    assert st["max_cost"] <= st["total_cost"] / 8 + max(csa_amd.task_cost(t) for t in tasks)
 
 
 def test_csa_pairs_over_two_devices(monkeypatch):
