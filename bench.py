@@ -578,6 +578,46 @@ def profile_path_leg(csa_amd):
     return out
 
 
+def profile_batch_leg(csa_amd):
+    """Batches of N-SEQUENCE tasks through csadp_align_batch: profile fills (dynamicprogramming.c:990-1029 with i >= 2) at full occupancy --
+    nw_fill_cells in launches of thousands of workgroups -- which the reference's own sets never produce (their rounds are a handful of
+    matrices).  End to end, and where the time goes (csadp_last_batch_phases): the device part, and the host's part of ProgressiveDP between two
+    fills (trace application :1050-1155, DeleteGappedColumns :643-899, the next fill's tables).  Best of two calls after a warm one."""
+    from helpers import random_family, rng
+    out = {}
+    for name, nfam, nseq, length in (("256_families_of_8x4000", 256, 8, 4000), ("16_families_of_16x16000", 16, 16, 16000)):
+        r = rng(nfam * 1000 + nseq)
+        tasks = []
+        for _ in range(nfam):
+            fam = random_family(r, nseq, length, mut=0.08, indel=0.02)
+            tasks.append((fam, [r.randrange(len(x)) for x in fam], None, None))
+        best = None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            got = csa_amd.align_batch(tasks)
+            dt = time.perf_counter() - t0
+            ph = csa_amd.last_batch_phases()
+            cells = sum(g["cells"] for g in got)
+            ok = all(g["status"] == 0 and len(set(len(x) for x in g["aligned"])) == 1 for g in got)
+            cur = {"ms": round(dt * 1e3, 1), "gcups": round(cells / dt / 1e9, 1), "cells": cells, "fills": sum(g["fills"] for g in got),
+                   "rounds": ph["rounds"], "round_groups": ph["round_groups"], "ok": bool(ok),
+                   "phases_ms_summed_over_rounds_and_groups": {k: round(ph[k], 1) for k in (
+                       "device_ms", "tables_ms", "apply_ms", "refine_speculate_ms", "refine_commit_ms", "seed_ms", "results_ms")},
+                   "gcups_while_the_device_works": round(cells / max(ph["device_ms"], 1e-9) / 1e6, 1),
+                   "recoveries": csa_amd.recoveries()}
+            if rep > 0 and (best is None or cur["ms"] < best["ms"]):
+                best = cur
+        out[name] = best
+    kr = kernel_stats_row("profile_batch_kernel_stats.csv", "nw_fill_cells")
+    if kr:
+        out["nw_fill_cells_under_rocprofv3"] = kr
+    out["what"] = ("families of random related sequences (8 x 4 kbp: 9 workgroups of nw_fill_cells per matrix, 2 304 per round of 256 tasks; 16 x 16 kbp: "
+                   "32-40 per matrix) through csadp_align_batch: lock-step rounds over two round groups.  The rounds are HOST-bound: the device part "
+                   "is a fifth of the wall time, DeleteGappedColumns on the host's 16 usable cores most of the rest (DESIGN.md section 10); kernel-level "
+                   "figures of the same runs: profiles/r05_profile_batch_*")
+    return out
+
+
 def single_matrix_leg(csa_amd):
     """Latency of ONE matrix (BASELINE config 2: a 16 kbp pair; config 5's upper end: 100 and 200 kbp pairs): device fill and
     traceback of a one-job batch, best of 3.  A large pair alone takes the cell-per-lane kernels (every chunk of the matrix on a
@@ -893,6 +933,7 @@ def main():
                         rec["deferred_dp_vs_csadp_msa_dp"] = round(rec["deferred"]["dp_s"] * 1e3 / pp["dp_ms"], 2)
                 line["dropin"] = dropin
             line["single_matrix"] = single_matrix_leg(csa_amd)
+            line["profile_batch"] = profile_batch_leg(csa_amd)
             # SURVEY 8(d)'s unit of work counts H2D of the sequences and D2H of the results inside the wall time: that rate,
             # first class beside `value` (which starts and ends in HBM, as the bench contract asks)
             line["gcups_8d_h2d_d2h_inclusive"] = {"value": line["streaming"]["gcups"], "unit": "GCUPS", "vs_value": line["streaming"]["vs_value"],

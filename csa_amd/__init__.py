@@ -77,7 +77,7 @@ class Timing(ctypes.Structure):
 # symbols declared in include/csadp.h and include/csadp_debug.h
 EXPORTS = [
     "csadp_init", "csadp_warmup", "csadp_shutdown", "csadp_version", "csadp_strerror", "csadp_device_info",
-    "csadp_align_batch", "csadp_free_result", "csadp_free_results", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
+    "csadp_align_batch", "csadp_last_batch_phases", "csadp_recoveries", "csadp_free_result", "csadp_free_results", "csadp_device_count", "csadp_align_batch_on", "csadp_task_cost",
     "csadp_align_batch_multi", "csadp_pairs_create_on",
     "csadp_pairs_create", "csadp_pairs_run", "csadp_pairs_flush", "csadp_pairs_sync", "csadp_pairs_fetch",
     "csadp_pairs_destroy", "csadp_pairs_timing",
@@ -201,6 +201,26 @@ def align_batch(tasks):
     res = (Result * max(ta.n, 1))()
     _check(lib().csadp_align_batch(ta.arr, ta.n, res), "csadp_align_batch")
     return _unpack(res[:ta.n], ta.nseq)
+
+
+class BatchPhases(ctypes.Structure):
+    _fields_ = [("tasks", ctypes.c_int), ("rounds", ctypes.c_int), ("round_groups", ctypes.c_int)] + [
+        (k, ctypes.c_double) for k in ("wall_ms", "seed_ms", "layout_ms", "tables_ms", "device_ms", "apply_ms", "refine_speculate_ms",
+                                       "refine_commit_ms", "results_ms")]
+
+
+def recoveries():
+    """Passes the primary engine's batches have repeated chunk by chunk so far in this process (0 in any healthy run)."""
+    L = lib()
+    L.csadp_recoveries.restype = ctypes.c_long
+    return int(L.csadp_recoveries())
+
+
+def last_batch_phases():
+    """csadp_last_batch_phases: where the time of the last csadp_align_batch went (host clocks, summed over rounds and round groups)."""
+    ph = BatchPhases()
+    _check(lib().csadp_last_batch_phases(ctypes.byref(ph)), "csadp_last_batch_phases")
+    return {k: getattr(ph, k) for k, _ in BatchPhases._fields_}
 
 
 class MultiStats(ctypes.Structure):

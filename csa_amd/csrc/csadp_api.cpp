@@ -184,6 +184,10 @@ int device_fills(FillBatch &fb, std::vector<Progressive> &tasks, const std::vect
 	return CSADP_OK;
 }
 
+/* csadp_last_batch_phases: accumulated by the rounds of the last batch (any group's thread) */
+std::mutex g_phases_mutex;
+csadp_batch_phases g_phases;
+
 /* one lock-step round: every task with a pending fill contributes one job */
 int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, const RoundFills &fills, std::vector<int> &status)
 {
@@ -237,6 +241,16 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, c
 		parallel_for((int)large.size(), [&](int i) { tasks[large[(size_t)i]].refine_commit(); });
 	}
 	lap();
+	{
+		std::lock_guard<std::mutex> lock(g_phases_mutex);
+		++g_phases.rounds;
+		g_phases.layout_ms += ms[0];
+		g_phases.tables_ms += ms[1];
+		g_phases.device_ms += ms[2];
+		g_phases.apply_ms += ms[3];
+		g_phases.refine_speculate_ms += ms[4];
+		g_phases.refine_commit_ms += ms[5];
+	}
 	if (trace)
 		fprintf(stderr, "csadp round: %3d jobs  layout %.2f  tables %.2f  device %.2f  apply %.2f  refine: speculate %.2f  commit %.2f ms\n",
 		        (int)active.size(), ms[0], ms[1], ms[2], ms[3], ms[4], ms[5]);
@@ -281,6 +295,11 @@ int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *result
 	const bool trace = config().trace_host;
 	const auto t_begin = std::chrono::steady_clock::now();
 	auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+	{
+		std::lock_guard<std::mutex> lock(g_phases_mutex);
+		memset(&g_phases, 0, sizeof(g_phases));
+		g_phases.tasks = ntasks;
+	}
 	std::vector<Progressive> prog((size_t)ntasks);
 	std::vector<int> status((size_t)ntasks, CSADP_OK);
 	parallel_for(ntasks, [&](int t) {
@@ -344,6 +363,13 @@ int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *result
 		if (status[(size_t)t] == CSADP_OK) status[(size_t)t] = prog[(size_t)t].finish(&results[t]);
 		results[t].status = status[(size_t)t];
 	});
+	{
+		std::lock_guard<std::mutex> lock(g_phases_mutex);
+		g_phases.round_groups = groups;
+		g_phases.seed_ms = ms_init;
+		g_phases.results_ms = since() - ms_rounds;
+		g_phases.wall_ms = since();
+	}
 	if (trace)
 		fprintf(stderr, "csadp_align_batch: %d tasks in %d round group(s): seed %.2f  rounds %.2f  results %.2f ms\n", ntasks, groups, ms_init,
 		        ms_rounds - ms_init, since() - ms_rounds);
@@ -472,6 +498,16 @@ int csadp_warmup(void)
 	for (FillBatch *fb : E->extra_batches)
 		if (fb && rc == CSADP_OK) rc = fb->reserve((size_t)256 << 20, (size_t)8 << 20, (size_t)8 << 20);
 	return rc;
+}
+
+long csadp_recoveries(void) { return csadp::primary_engine_recoveries(); }
+
+int csadp_last_batch_phases(csadp_batch_phases *out)
+{
+	if (!out) return CSADP_ERR_ARG;
+	std::lock_guard<std::mutex> lock(g_phases_mutex);
+	*out = g_phases;
+	return CSADP_OK;
 }
 
 long long csadp_task_cost(const csadp_task *task)

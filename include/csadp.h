@@ -127,6 +127,18 @@ CSADP_API int csadp_free_results(csadp_result *results, int count, int nseq);
 
 /* The same on an explicitly named HIP device (brought up on first use).  Calls naming different
  * devices may run concurrently from different host threads. */
+/* Where the time of the calling process' LAST csadp_align_batch[_on] went (host clocks; summed over the lock-step rounds of all round
+ * groups, which run side by side: the phases can add up to more than wall_ms).  device_ms = upload + kernels + download as the host waits
+ * for them; tables / apply / refine_* = the host's part of ProgressiveDP between two fills (dynamicprogramming.c:957-987, :1050-1155,
+ * :643-899).  What bench.py's profile_batch leg reports. */
+typedef struct csadp_batch_phases {
+	int tasks, rounds, round_groups;
+	double wall_ms, seed_ms, layout_ms, tables_ms, device_ms, apply_ms, refine_speculate_ms, refine_commit_ms, results_ms;
+} csadp_batch_phases;
+CSADP_API int csadp_last_batch_phases(csadp_batch_phases *out);
+/* passes of the primary device's batches that were repeated chunk by chunk after a bounded cross-workgroup wait of a chunked fill ran out,
+ * since the library was initialised (csadp_timing.recoveries is the per-batch figure of the pair batches); 0 in any healthy run */
+CSADP_API long csadp_recoveries(void);
 CSADP_API int csadp_align_batch_on(int device, const csadp_task *tasks, int ntasks, csadp_result *results);
 
 /* Work estimate of a task in DP cells (sum over its fills of rows x columns, the consensus taken

@@ -415,3 +415,28 @@ def test_publisher_wave_that_falls_behind_its_strip(slow, monkeypatch):
     monkeypatch.setenv("CSADP_BITS", "0")                     # the pair's first fill on nw_fill_cells too
     g = csa_amd.align_batch([([a, b], [3, 1], None, None)])[0]
     assert g["status"] == 0 and g["aligned"] == wantp[1] and g["score"] == wantp[2].last_score
+
+
+@pytest.mark.parametrize("walk", ["serial", "banded"])
+def test_thousands_of_small_families_in_one_batch(walk, monkeypatch):
+    """The N-sequence twin of the test above: 2048 families of 3-6 sequences of 60-700 letters through csadp_align_batch -- lock-step
+    rounds of up to 2048 profile fills (nw_fill_cells: one- to six-strip matrices, thousands of workgroups per launch: the plain layout,
+    two workgroups per compute unit), serial walks, trace application and DeleteGappedColumns for every task between two rounds.  Every
+    result by its properties (equal lengths, rows re-spell the rotated regions); 64 of them string for string against the oracle."""
+    if walk == "banded":
+        monkeypatch.setenv("CSADP_TB_BAND_MIN", "1")         # every matrix takes the band-parallel walk (scout / resolve / emit / gather)
+    r = rng(2048)
+    tasks = []
+    for i in range(2048):
+        fam = random_family(r, 3 + i % 4, r.choice([60, 130, 300, 700]), mut=0.1, indel=0.05)
+        fam = [f if f else b"T" for f in fam]
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    got = csa_amd.align_batch(tasks)
+    for t, g in zip(tasks, got):
+        assert g["status"] == 0 and len(g["aligned"]) == len(t[0])
+        assert len(set(len(x) for x in g["aligned"])) == 1 and len(g["aligned"][0]) == g["consensus"]
+        for s, row in enumerate(g["aligned"]):
+            assert degap(row) == rotated(t[0][s], t[1][s])
+    for i in range(0, 2048, 32):
+        cons, strs, st = oracle_progressive(tasks[i][0], tasks[i][1])
+        assert got[i]["consensus"] == cons and got[i]["aligned"] == strs and got[i]["fills"] == st.fills
