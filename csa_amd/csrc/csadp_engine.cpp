@@ -717,18 +717,16 @@ int FillBatch::layout_bits()
 		bits_streams_ = std::max(1, std::min(bits_streams_, Engine::kMaxSlots / (2 * bits_group_)));
 		nslots_ = bits_streams_ * 2 * bits_group_;
 	}
-	/* How many strips share a workgroup.  A job is normally ONE workgroup (up to 16 strips).  A launch with few strips
-	 * in all -- a single 16 kbp pair, the first fills of a whole-genome profile alignment, a 200 kbp pair -- is
-	 * latency-bound: its strips are spread over compute units, 4 per workgroup = one wave per SIMD while the launch
-	 * fits the chip that way, else 8 (the chunks of a job hand over through granules in HBM). */
-	bits_chunk_ = kBitMaxStrips;
+	/* How many strips share a workgroup.  A job of at most FOUR strips is one workgroup, a wave per SIMD.  A wider one is a chain of
+	 * four-strip workgroups (`bits_chunk_`) handing over through granules in HBM, so that its strips spread over compute units: one
+	 * workgroup of up to 16 strips keeps a job's whole wavefront on the four SIMDs of ONE unit, and the longest jobs of a batch -- the
+	 * chain every pass waits for -- then run four waves to a SIMD while other units idle.  Until round 5 only launches of few strips
+	 * were spread this way (4 per workgroup up to one wave per SIMD in all, 8 up to two, else 16); measured over batch shapes
+	 * (tools/r05/chunk_probe.py, profiles/r05_chunk_probe.txt, TCUPS at 16 / 8 / 4 strips per workgroup): config 5's 256 pairs of
+	 * 1-200 kbp 30.7 / 33.3 / 41.8-44.6, 64 pairs of 33 kbp 27.4 / 36.7 / 36.5, 40 of 50 kbp 20.3 / 26.4 / 28.8, 8 of 200 kbp
+	 * 12.7 / 12.7 / 16.4; batches of a hundred and more equal jobs the same within the run-to-run spread (+-5 %). */
+	bits_chunk_ = 4;
 	{
-		long long launch_strips = 0;
-		for (const BitJob &B : bjobs_) launch_strips += B.nstrips;
-		launch_strips *= bits_group_;
-		const long long simds = 4LL * std::max(E.compute_units(), 1);
-		if (launch_strips <= simds) bits_chunk_ = 4;
-		else if (launch_strips <= 2 * simds) bits_chunk_ = 8;
 		const int forced = cfg.bits_chunk;
 		if (forced == 4 || forced == 8 || forced == 16) bits_chunk_ = forced;
 	}
