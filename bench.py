@@ -608,7 +608,7 @@ def profile_batch_leg(csa_amd):
             if rep > 0 and (best is None or cur["ms"] < best["ms"]):
                 best = cur
         out[name] = best
-    kr = kernel_stats_row("profile_batch_kernel_stats.csv", "nw_fill_cells")
+    kr = kernel_stats_row("pbatch_kernel_stats.csv", "nw_fill_cells")
     if kr:
         out["nw_fill_cells_under_rocprofv3"] = kr
     out["what"] = ("families of random related sequences (8 x 4 kbp: 9 workgroups of nw_fill_cells per matrix, 2 304 per round of 256 tasks; 16 x 16 kbp: "

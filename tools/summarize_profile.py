@@ -2,7 +2,7 @@
 """Condense rocprofv3 outputs (gpurun_out/<dir>, written by tools/profile_round.sh) into the small files
 committed under profiles/.
 
-usage: python tools/summarize_profile.py gpurun_out/r03 profiles/r03
+usage: python tools/summarize_profile.py gpurun_out/r03 profiles/r03        (workloads: bench, msa; round 5: pbatch, pbatchfetch)
 Writes <prefix>_<workload>_kernel_stats.csv (copies of the --stats summaries) and <prefix>_pmc_summary.json:
 per workload and kernel the sums of every collected counter, per-launch HBM traffic with the gfx950 corrections of
 MI355X_MICROARCH.md (FETCH_SIZE x2 for wide coalesced reads, both counters in KiB), VALU instructions per wave, and
@@ -36,7 +36,7 @@ def main():
     src, prefix = sys.argv[1], sys.argv[2]
     os.makedirs(os.path.dirname(prefix), exist_ok=True)
     out = {}
-    for wl in ("bench", "msa"):
+    for wl in ("bench", "msa", "pbatch", "pbatchfetch"):
         for variant in ("stats", "solo"):
             st = find(src, "%s_%s" % (wl, variant), "kernel_stats.csv")
             if st:
