@@ -221,7 +221,11 @@ int run_round(std::vector<Progressive> &tasks, const std::vector<int> &active, c
 		/* items: (task, chunk >= 0) = speculate that chunk of a LARGE task; (task, -1) = the whole refinement of a small
 		 * one, plain.  The passes of the large tasks follow -- there are a handful at most, so that loop usually runs on
 		 * this thread without waking the pool a third time. */
-		constexpr int kLargeColumns = 1024;
+		/* ... unless the round holds several tasks per host thread: the tasks themselves then fill the pool, and the plain pass of a task
+		 * does less work than speculation + commit (a fifth of the candidates are scored twice) and needs no second region
+		 * (N-sequence throughput batches, profiles/r05_profile_batch_sweep.txt) */
+		const bool many_tasks = (int)active.size() >= 2 * std::min(csadp::HostPool::get().size(), 16);
+		const int kLargeColumns = many_tasks ? 2000000000 : 1024;
 		std::vector<std::pair<int, int>> items;
 		std::vector<int> large;
 		for (size_t j = 0; j < active.size(); ++j) {
