@@ -641,19 +641,23 @@ int FillBatch::layout_bits()
 			for (int w = 1; w <= 3; ++w) {
 				const long long sw = (words + 64 * w - 1) / (64 * w);
 				strips[w] += sw;
-				/* a workgroup's waves go round the four SIMDs: a fifth strip -- 17 000 columns at two words per lane -- doubles
-				 * up on the first strip's SIMD and the whole chain of strips runs at that pair's pace; so beyond four, strips
-				 * count in fours, times the step's instructions */
-				cost[w] += (sw <= 4 ? sw : (sw + 3) / 4 * 4) * kStepValu[w];
+				/* strips times the step's instructions.  (Until round 5 a job of up to 16 strips was ONE workgroup: a fifth strip
+				 * doubled up on the first strip's SIMD, and strips beyond four counted in fours.  Jobs wider than four strips are
+				 * chains of four-strip workgroups now -- below -- and a fifth strip is a workgroup of its own.) */
+				cost[w] += sw * kStepValu[w];
 			}
 		}
 		const long long simds = 4LL * std::max(E.compute_units(), 1);
 		const int group2 = pipelined_ ? std::max(1, std::min(std::max(E.compute_units(), 1) / std::max(nj, 1), 4)) : 1;
 		const int passes = pipelined_ ? 2 * group2 : 1;
-		/* two words per lane when that still keeps 1.5 waves per SIMD in flight; three -- real mitochondrial genomes: 16.4-17.0 k
-		 * letters are three strips of 6144 columns instead of five of 4096 -- when one wave per SIMD; one word per lane only
-		 * when it is clearly cheaper (at equal cost two words measure 14 % faster: 64 jobs of 33 000 columns) */
-		const bool ok2 = 2 * strips[2] * passes >= 3 * simds, ok3 = strips[3] * passes >= simds;
+		/* two or three words per lane when that still keeps a wave per SIMD in flight (three: real mitochondrial genomes: 16.4-17.0 k
+		 * letters are three strips of 6144 columns instead of five of 4096); one word per lane only when it is clearly cheaper (at
+		 * equal cost two words measure 14 % faster: 64 jobs of 33 000 columns) or the batch is a handful of matrices whose chains of
+		 * strips are all there is to wait for.  tools/r05/words_probe.py, profiles/r05_words_probe.txt: 15 shapes from 2 pairs of
+		 * 200 kbp to 1000 of 5 kbp at 1 / 2 / 3 words; round 4's rule (1.5 waves per SIMD for two words, strips in fours) chose one
+		 * word for 16 pairs of 33 kbp and 32 of 17 kbp (18.7 against 22.7 TCUPS) and two for 40 of 50 kbp and 64 of 100 kbp
+		 * (33.3 / 41.0 against 36.0 / 44.0 at three). */
+		const bool ok2 = strips[2] * passes >= simds, ok3 = strips[3] * passes >= simds;
 		int w = 1;
 		long long best = cost[1] * 100 / 93;
 		if (ok2 && cost[2] <= best) { w = 2; best = cost[2]; }
