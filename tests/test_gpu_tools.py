@@ -276,3 +276,23 @@ def test_bench_shards_a_real_fasta_batch_over_rccl():
     assert line["verified"] is True
     assert line["records"]["gathered"] == 66 and line["records"]["checked_against_reference_digests"] == 66
     assert line["records"]["rows_on_rank0"] == 66 and line["records"]["rows_match_their_records"] is True
+
+
+def test_warmup_pays_the_first_batch_costs_and_changes_no_result():
+    """csadp_warmup (include/csadp.h): the code objects, the copy paths, the host pool and the arenas of csadp_align_batch are paid for up
+    front by a small synthetic batch through every kernel family.  It may be called any number of times, before or between batches, and
+    the batches around it return the oracle's strings; csadp_last_batch_phases / csadp_recoveries report on the last real batch."""
+    csa_amd.init(device=0)
+    r = rng(55)
+    fam = random_family(r, 5, 800, mut=0.1, indel=0.04)
+    tasks = [(fam, [r.randrange(len(f)) for f in fam], None, None), (random_family(r, 2, 3000), None, None, None)]
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    for _ in range(2):
+        csa_amd.warmup()
+        got = csa_amd.align_batch(tasks[:1]) + csa_amd.align_batch(tasks[1:])
+        for g, (cons, strs, st) in zip(got, want):
+            assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score
+    got = csa_amd.align_batch([tasks[0], tasks[0]])
+    ph = csa_amd.last_batch_phases()
+    assert ph["tasks"] == 2 and ph["rounds"] == 8 and ph["round_groups"] == 2 and ph["device_ms"] > 0 and ph["wall_ms"] >= ph["seed_ms"]
+    assert csa_amd.recoveries() == 0

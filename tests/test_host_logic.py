@@ -247,3 +247,22 @@ def test_progress_tokens_equal_the_reference_log(refine_mode):
     for a, b in checked:
         assert a == b
     assert sum(a.count("!") for a, _ in checked) >= 1
+
+
+def test_bench_reads_its_roofline_sources_from_profiles():
+    """bench.py's `frac_from_kernel_duration` and `frac_from_counters` must be recomputable from ONE committed file each (round-4 VERDICT,
+    item 5): the helper finds the newest round's summaries under profiles/ and the arithmetic is the one DESIGN.md section 5 states."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    row = bench.kernel_stats_row("bench_kernel_solo.csv", "nw_fill_bits<2")
+    assert row and row["calls"] >= 10 and 1500 < row["avg_us"] < 3500 and row["file"].startswith("profiles/r0")
+    cells = 2 * 128 * 16384 * 16384                       # two passes of the 128-pair batch per launch (roughly: b is a little longer or shorter)
+    out = bench.roofline_from_profiles(bench.bits_valu_per_cell(2), cells, 2)
+    assert abs(out["frac_from_kernel_duration"] - bench.bits_valu_per_cell(2) * cells / (row["avg_us"] * 1e-6) / 1e12 / bench.VALU_PEAK_TOPS) < 1e-3
+    with open(os.path.join(ROOT, out["counters_source"].split(":")[0])) as f:
+        pmc = json.load(f)["nw_fill_bits"]
+    assert abs(out["frac_from_counters"] - 2.0 * pmc["valu_insts_per_wave"] / pmc["wave_cycles_per_wave_x4"]) < 1e-3
+    assert 0.2 < out["frac_from_kernel_duration"] < 0.6 and 0.2 < out["frac_from_counters"] < 0.6
