@@ -1040,6 +1040,13 @@ int FillBatch::alloc_buffers()
 
 int FillBatch::reserve(size_t arena_bytes, size_t in_bytes, size_t res_bytes)
 {
+	/* best effort: on a device that is short of memory (another process holds most of it) the reservation is skipped -- a real batch
+	 * then allocates what it needs, or reports what it lacks */
+	{
+		size_t free_b = 0, total_b = 0;
+		if (E_->bind() != CSADP_OK || hipMemGetInfo(&free_b, &total_b) != hipSuccess) return CSADP_OK;
+		if (arena_bytes > arena_cap_ && free_b < 4 * arena_bytes) return CSADP_OK;
+	}
 	const size_t t = total_bytes_, i = in_bytes_, r = res_bytes_;
 	total_bytes_ = std::max(t, arena_bytes);
 	in_bytes_ = std::max(i, in_bytes);
