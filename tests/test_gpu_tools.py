@@ -7,7 +7,7 @@ import subprocess
 import pytest
 
 import csa_amd
-from helpers import GOLDEN, ROOT, load_golden, random_family, rng, sp_score
+from helpers import GOLDEN, ROOT, load_golden, random_family, rng, sp_score, oracle_progressive
 
 pytestmark = pytest.mark.gpu
 
