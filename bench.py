@@ -580,17 +580,20 @@ def profile_path_leg(csa_amd):
 
 def profile_batch_leg(csa_amd):
     """Batches of N-SEQUENCE tasks through csadp_align_batch: profile fills (dynamicprogramming.c:990-1029 with i >= 2) at full occupancy --
-    nw_fill_cells in launches of thousands of workgroups -- which the reference's own sets never produce (their rounds are a handful of
+    nw_fill_cells in launches of a thousand and more workgroups -- which the reference's own sets never produce (their rounds are a handful of
     matrices).  End to end, and where the time goes (csadp_last_batch_phases): the device part, and the host's part of ProgressiveDP between two
-    fills (trace application :1050-1155, DeleteGappedColumns :643-899, the next fill's tables).  Best of two calls after a warm one."""
+    fills (trace application :1050-1155, DeleteGappedColumns :643-899, the next fill's tables).  Families are co-linear (what lies between two
+    anchors of the reference's pipeline); the `misrotated` entry gives every sequence a random rotation instead -- alignments that are mostly end
+    gaps, the worst case of DeleteGappedColumns, where the rounds become host-bound.  Best of two calls after a warm one."""
     from helpers import random_family, rng
     out = {}
-    for name, nfam, nseq, length in (("256_families_of_8x4000", 256, 8, 4000), ("16_families_of_16x16000", 16, 16, 16000)):
+    for name, nfam, nseq, length, rotate in (("256_families_of_8x4000", 256, 8, 4000, False), ("16_families_of_16x16000", 16, 16, 16000, False),
+                                             ("64_families_of_8x4000_misrotated", 64, 8, 4000, True)):
         r = rng(nfam * 1000 + nseq)
         tasks = []
         for _ in range(nfam):
             fam = random_family(r, nseq, length, mut=0.08, indel=0.02)
-            tasks.append((fam, [r.randrange(len(x)) for x in fam], None, None))
+            tasks.append((fam, [r.randrange(len(x)) for x in fam] if rotate else None, None, None))
         best = None
         for rep in range(3):
             t0 = time.perf_counter()
@@ -603,18 +606,17 @@ def profile_batch_leg(csa_amd):
                    "rounds": ph["rounds"], "round_groups": ph["round_groups"], "ok": bool(ok),
                    "phases_ms_summed_over_rounds_and_groups": {k: round(ph[k], 1) for k in (
                        "device_ms", "tables_ms", "apply_ms", "refine_speculate_ms", "refine_commit_ms", "seed_ms", "results_ms")},
-                   "gcups_while_the_device_works": round(cells / max(ph["device_ms"], 1e-9) / 1e6, 1),
                    "recoveries": csa_amd.recoveries()}
             if rep > 0 and (best is None or cur["ms"] < best["ms"]):
                 best = cur
         out[name] = best
     kr = kernel_stats_row("pbatch_kernel_stats.csv", "nw_fill_cells")
     if kr:
-        out["nw_fill_cells_under_rocprofv3"] = kr
-    out["what"] = ("families of random related sequences (8 x 4 kbp: 9 workgroups of nw_fill_cells per matrix, 2 304 per round of 256 tasks; 16 x 16 kbp: "
-                   "32-40 per matrix) through csadp_align_batch: lock-step rounds over two round groups.  The rounds are HOST-bound: the device part "
-                   "is a fifth of the wall time, DeleteGappedColumns on the host's 16 usable cores most of the rest (DESIGN.md section 10); kernel-level "
-                   "figures of the same runs: profiles/r05_profile_batch_*")
+        out["nw_fill_cells_under_rocprofv3"] = dict(kr, what="launches of ~580 workgroups (64 matrices of 4 000 x 4 050, one round group's round of the 256-family batch), "
+                                                            "up to four such launches on the chip at once: the duration is a launch's own, not a solo rate")
+    out["what"] = ("families of random related sequences through csadp_align_batch: lock-step rounds over two round groups, four from 128 tasks on; 8 x 4 kbp: 9 workgroups of "
+                   "nw_fill_cells per matrix; 16 x 16 kbp: 32-40 per matrix.  Co-linear families run device-bound (the two groups' "
+                   "device parts overlap); misrotated ones are bound by DeleteGappedColumns on the host (DESIGN.md section 10)")
     return out
 
 

@@ -331,7 +331,11 @@ int align_batch_rounds(const csadp_task *tasks, int ntasks, csadp_result *result
 		if (status[(size_t)t] == CSADP_OK) live.push_back(t);
 	int groups = 1;
 	{
-		const int want = config().round_groups;
+		/* two groups for the reference's own sets (a large gap alone beside the many small ones: DESIGN.md section 4); FOUR for batches of
+		 * many tasks, whose rounds are device-bound -- the fill of one group then runs under the walks, the trace application and the
+		 * refinement of three others (profiles/r05_profile_batch_sweep_colinear.txt: 512 families of 8 x 4 kbp 62-69 -> 48-52 ms, 16 of
+		 * 16 x 16 kbp 50 -> 47; the example sets the same within their spread) */
+		const int want = (!config().round_groups_forced && live.size() >= 128) ? 4 : config().round_groups;      /* 64 tasks: 11.2 ms with two groups, 12.0 with four */
 		groups = std::max(1, std::min(std::min(want, max_groups), (int)live.size()));
 	}
 	{

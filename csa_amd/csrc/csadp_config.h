@@ -32,6 +32,7 @@ struct Config {
 	bool pull_uploads = true;       /* CSADP_PULL_UPLOADS: a round's tables are pulled from pinned memory by a kernel */
 	/* host */
 	int round_groups = 2;           /* CSADP_ROUND_GROUPS: task groups whose lock-step rounds run side by side */
+	bool round_groups_forced = false; /* ... was set explicitly; else batches of 128 tasks and more take 4 (csadp_api.cpp) */
 	int refine_speculate = 0;       /* CSADP_REFINE_SPECULATE: one-task entry points speculate DeleteGappedColumns too (1: same thread, 2: threads) */
 	int host_threads = 0;           /* CSADP_HOST_THREADS: size of the host pool (0: by the machine); read when the pool starts */
 	bool trace_host = false;        /* CSADP_TRACE_HOST: per-stage host timings on stderr */

@@ -201,6 +201,7 @@ Config read_config()
 	c.tb_corridor_forced = getenv("CSADP_TB_CORRIDOR") != nullptr;
 	c.pull_uploads = env_int("CSADP_PULL_UPLOADS", 1) != 0;
 	c.round_groups = env_int("CSADP_ROUND_GROUPS", 2);
+	c.round_groups_forced = getenv("CSADP_ROUND_GROUPS") != nullptr;
 	c.refine_speculate = env_int("CSADP_REFINE_SPECULATE", 0);
 	c.host_threads = env_int("CSADP_HOST_THREADS", 0);
 	c.trace_host = getenv("CSADP_TRACE_HOST") != nullptr;

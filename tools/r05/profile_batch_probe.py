@@ -12,14 +12,15 @@ import csa_amd  # noqa: E402
 from helpers import random_family, rng  # noqa: E402
 
 csa_amd.init(device=0)
-shapes = [(int(a), int(b), int(c)) for a, b, c in (x.split("x") for x in sys.argv[1:])] or [(512, 8, 4000), (64, 16, 16000)]
+rotate = "--misrotated" in sys.argv
+shapes = [(int(a), int(b), int(c)) for a, b, c in (x.split("x") for x in sys.argv[1:] if not x.startswith("--"))] or [(512, 8, 4000), (64, 16, 16000)]
 for nfam, nseq, length in shapes:
     r = rng(nfam * 1000 + nseq)
     t0 = time.perf_counter()
     tasks = []
     for f in range(nfam):
         fam = random_family(r, nseq, length, mut=0.08, indel=0.02)
-        tasks.append((fam, [r.randrange(len(s)) for s in fam], None, None))
+        tasks.append((fam, [r.randrange(len(x)) for x in fam] if rotate else None, None, None))      # co-linear (what lies between two anchors) unless --misrotated
     gen = time.perf_counter() - t0
     best = None
     for rep in range(3):
@@ -34,4 +35,4 @@ for nfam, nseq, length in shapes:
               "while the device works), tables %.1f apply %.1f speculate %.1f commit %.1f seed %.1f results %.1f"
               % (nfam, nseq, length, rep, dt * 1e3, cells / 1e9, fills, cells / dt / 1e9, ph["rounds"], ph["round_groups"], ph["device_ms"],
                  cells / max(ph["device_ms"], 1e-9) / 1e6, ph["tables_ms"], ph["apply_ms"], ph["refine_speculate_ms"], ph["refine_commit_ms"],
-                 ph["seed_ms"], ph["results_ms"]), flush=True)
+                 ph["seed_ms"], ph["results_ms"]), "recoveries so far:", csa_amd.recoveries(), flush=True)
