@@ -292,7 +292,8 @@ def test_warmup_pays_the_first_batch_costs_and_changes_no_result():
         got = csa_amd.align_batch(tasks[:1]) + csa_amd.align_batch(tasks[1:])
         for g, (cons, strs, st) in zip(got, want):
             assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score
+    before = csa_amd.recoveries()                          # process-wide since init: other tests force recoveries on purpose
     got = csa_amd.align_batch([tasks[0], tasks[0]])
     ph = csa_amd.last_batch_phases()
     assert ph["tasks"] == 2 and ph["rounds"] == 8 and ph["round_groups"] == 2 and ph["device_ms"] > 0 and ph["wall_ms"] >= ph["seed_ms"]
-    assert csa_amd.recoveries() == 0
+    assert csa_amd.recoveries() == before
