@@ -440,3 +440,24 @@ def test_thousands_of_small_families_in_one_batch(walk, monkeypatch):
     for i in range(0, 2048, 32):
         cons, strs, st = oracle_progressive(tasks[i][0], tasks[i][1])
         assert got[i]["consensus"] == cons and got[i]["aligned"] == strs and got[i]["fills"] == st.fills
+
+
+def test_many_task_batches_run_four_round_groups_without_recoveries():
+    """From 128 tasks on csadp_align_batch drives FOUR round groups side by side (csadp_api.cpp): up to four chunked fills of nw_fill_cells share
+    the chip, each waiting across workgroups for its own producers.  The bounded waits must not run out in such batches (a run-out is repaired --
+    the pass is repeated chunk by chunk -- but costs half a second): families whose matrices span 3 to 24 workgroups, twice; recoveries unchanged;
+    a sample against the oracle."""
+    r = rng(4128)
+    tasks = []
+    for i in range(160):
+        fam = random_family(r, r.choice([3, 5, 8]), r.choice([1500, 3000, 6000]) if i % 8 else 12000, mut=0.08, indel=0.02)
+        tasks.append((fam, None, None, None))
+    before = csa_amd.recoveries()
+    for _ in range(2):
+        got = csa_amd.align_batch(tasks)
+        ph = csa_amd.last_batch_phases()
+        assert ph["round_groups"] == 4 and all(g["status"] == 0 for g in got)
+    assert csa_amd.recoveries() == before
+    for i in (0, 8, 77, 159):
+        cons, strs, st = oracle_progressive(tasks[i][0], None)
+        assert got[i]["consensus"] == cons and got[i]["aligned"] == strs and got[i]["score"] == st.last_score
