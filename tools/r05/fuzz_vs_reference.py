@@ -96,7 +96,7 @@ while time.time() < t_end:
             os.environ.pop(k, None)
         csa_amd.reload_config()
     else:
-        tasks = [make_task() for _ in range(120)]
+        tasks = [make_task() for _ in range(r.choice([40, 120, 160, 300]))]      # 128 and more: four round groups
         got = csa_amd.align_batch(tasks)
     for t, g in zip(tasks, got):
         cons, strs, _ = ref_progressive(*t)
