@@ -712,13 +712,23 @@ int FillBatch::layout_bits()
 		 * as long); workgroups of more strips than SIMDs are uneven anyway and do better queued deep (120 jobs of 9 strips: 4
 		 * passes 27.5 TCUPS, 2 passes 22.6) */
 		const int want = std::max(E.compute_units(), 1);
-		if (bits_maxstrips_ <= 4) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
+		/* ... and workgroups of one or two strips fill a compute unit a quarter or half as much: their launches hold as many passes as put two
+		 * waves on every SIMD, up to seven (tools/r05/group_probe.py, profiles/r05_group_probe.txt: 128 pairs of 12 kbp 31.0 -> 38.4 TCUPS,
+		 * 256 of them 32.0 -> 37.6, 512 of 5 kbp 23.1 -> 26.3, 128 of 6 kbp at one word per lane 27.0 -> 30.1; three-strip workgroups -- the
+		 * real mitochondrial sets -- keep the shape round 4 measured for them) */
+		if (bits_maxstrips_ <= 2) {
+			const int two_per_simd = 8 * want / std::max(nj * bits_maxstrips_, 1);        /* passes that put two waves on every SIMD */
+			/* fewer jobs than even eight passes fill: four launches of four passes keep more in flight than two of seven (64 pairs of 12 kbp:
+			 * 32.1 against 28.4 TCUPS) */
+			bits_group_ = two_per_simd > 8 ? 4 : std::max(1, std::min(two_per_simd, 7));
+		}
+		else if (bits_maxstrips_ <= 4) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
 		else bits_group_ = std::max(1, std::min((2 * want + nj - 1) / nj, 4));
 		bits_group_ = std::max(1, std::min(cfg.bits_group >= 0 ? cfg.bits_group : bits_group_, 8));
 		bits_streams_ = std::max(1, std::min(cfg.bits_streams >= 0 ? cfg.bits_streams : dflt_streams, E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
 		 * stream while the next fill of the stream already works on the other range */
-		bits_streams_ = std::max(1, std::min(bits_streams_, Engine::kMaxSlots / (2 * bits_group_)));
+		bits_streams_ = std::max(1, std::min(bits_streams_, (Engine::kMaxSlots - 1) / (2 * bits_group_)));
 		nslots_ = bits_streams_ * 2 * bits_group_;
 	}
 	/* How many strips share a workgroup.  A job of at most FOUR strips is one workgroup, a wave per SIMD.  A wider one is a chain of

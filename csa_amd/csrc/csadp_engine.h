@@ -41,7 +41,7 @@ public:
 	static uint32_t next_epoch();
 	static uint32_t set_epoch_counter(uint32_t v);   /* test seam (csadp_debug_set_epoch) */
 	bool ready() const { return ready_; }
-	static constexpr int kMaxSlots = 32;
+	static constexpr int kMaxSlots = 33;             /* 32 pipelined passes (streams x two slot ranges x passes per launch) + the slot of a lone pass's shape */
 	hipStream_t stream(int slot = 0) const { return streams_[slot]; }
 	int slots() const { return slots_; }
 	/* streams [0, main_streams()) carry fills; stream main_streams() + q is the side stream of main stream q:
