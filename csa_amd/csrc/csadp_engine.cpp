@@ -205,9 +205,13 @@ constexpr size_t kPoolEntries = 6;
 
 uint8_t *pool_take(std::vector<std::pair<uint8_t *, size_t>> &pool, size_t need, size_t *got)
 {
+	/* best fit, but never a buffer far larger than asked for: the grow-only arenas of csadp_align_batch once took the 41 GB arenas a
+	 * streaming caller's pair batches had just released for rounds that need a few MB, and kept them for the life of the process
+	 * (round 5: bench.py's config 5 leg then found 143 of 288 GB free) */
+	const size_t most = 4 * need + ((size_t)256 << 20);
 	int best = -1;
 	for (size_t i = 0; i < pool.size(); ++i)
-		if (pool[i].second >= need && (best < 0 || pool[i].second < pool[(size_t)best].second)) best = (int)i;
+		if (pool[i].second >= need && pool[i].second <= most && (best < 0 || pool[i].second < pool[(size_t)best].second)) best = (int)i;
 	if (best < 0) return nullptr;
 	uint8_t *p = pool[(size_t)best].first;
 	*got = pool[(size_t)best].second;
@@ -722,8 +726,35 @@ int FillBatch::layout_bits()
 			 * 32.1 against 28.4 TCUPS) */
 			bits_group_ = two_per_simd > 8 ? 4 : std::max(1, std::min(two_per_simd, 7));
 		}
-		else if (bits_maxstrips_ <= 4) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
-		else bits_group_ = std::max(1, std::min((2 * want + nj - 1) / nj, 4));
+		else if (bits_maxstrips_ == 3) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
+		else if (bits_maxstrips_ == 4) {
+			/* Four-strip workgroups (16 kbp pairs at two words per lane): a launch should be whole "waves" of workgroups -- a multiple of the
+			 * compute units.  Round 3 found one workgroup per compute unit per launch (128 jobs x 2 passes, 64 x 4: 360 workgroups ran 29 TCUPS
+			 * where 240 ran 39) and took floor(CUs / jobs) passes; job counts that do not divide the compute units were left with launches of
+			 * 192 or 128 or 64 workgroups: 96 jobs ran 35 TCUPS, 192 jobs 36.5, 32 jobs 24 (tools/r05/streams_probe.py).  Now: the FEWEST
+			 * passes (up to eight) whose workgroups are a multiple of the compute units, else the count with the smallest idle share of its
+			 * last wave: 96 jobs x 8 = 768 = 3 x 256: 47.0 TCUPS; 192 x 4: 48; 32 x 8: 45.6; 128 x 2 and 64 x 4 as before.  Not simply "eight":
+			 * gap-rich pairs (the unrelated 16 kbp variant) lose a quarter in launches of eight passes -- their tracebacks are as long as
+			 * their fills and a launch's traceback holds its slot range (profiles/r05_streams_probe.txt: 128 unrelated pairs 39.9 at two passes,
+			 * 28.9 at eight).  Held back by memory: a slot is a pass' checkpoints (5.3 MB per 16 kbp pair). */
+			int best_rel = 1 << 30;
+			bits_group_ = 8;
+			for (int g = 1; g <= 8; ++g) {
+				const long total = (long)nj * g;
+				if (total < want && g < 8) continue;                      /* not even one workgroup per compute unit */
+				const long waves = (total + want - 1) / want;
+				const int rel = (int)((waves * want - total) * 1000 / (waves * want));
+				if (rel < best_rel) { best_rel = rel; bits_group_ = g; }
+			}
+			while (bits_group_ > 1 && 4.0 * bits_group_ * (double)border_bytes_ > 48e9) --bits_group_;
+		}
+		else {
+			/* jobs wider than four strips: two workgroups per compute unit per launch, as before -- up to eight passes, not four, for the
+			 * same reason as above (16 pairs of 16 kbp at one word per lane: 16.7 -> 30.6 TCUPS), within the same memory */
+			bits_group_ = std::max(1, std::min((2 * want + nj - 1) / nj, 8));
+			const int floor_g = std::min(bits_group_, 4);                  /* what round 4 took whatever the memory (config 5: two passes, 168 GB) */
+			while (bits_group_ > floor_g && 4.0 * bits_group_ * (double)border_bytes_ > 48e9) --bits_group_;
+		}
 		bits_group_ = std::max(1, std::min(cfg.bits_group >= 0 ? cfg.bits_group : bits_group_, 8));
 		bits_streams_ = std::max(1, std::min(cfg.bits_streams >= 0 ? cfg.bits_streams : dflt_streams, E.main_streams()));
 		/* every stream alternates between TWO slot ranges: the traceback of a launch runs on the stream's side
