@@ -400,6 +400,7 @@ int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result 
 	/* one FillBatch (arena, streams) per round group: the engine's cached one and its spares */
 	std::lock_guard<std::mutex> lock(E->batch_mutex);
 	auto prepare = [&](int groups) -> int {
+		E->cells_sharers.store(groups, std::memory_order_relaxed);
 		if (!E->cached_batch) E->cached_batch = new (std::nothrow) FillBatch(E);
 		if (!E->cached_batch) return CSADP_ERR_NOMEM;
 		if ((int)E->extra_batches.size() < groups - 1) E->extra_batches.resize((size_t)groups - 1, nullptr);
@@ -416,7 +417,9 @@ int align_batch_on(Engine *E, const csadp_task *tasks, int ntasks, csadp_result 
 			return device_fills(*fb, tasks_, active, out, ms);
 		};
 	};
-	return align_batch_rounds(tasks, ntasks, results, E->main_streams(), prepare, fills_of, [E]() { return E->bind(); });
+	const int rc = align_batch_rounds(tasks, ntasks, results, E->main_streams(), prepare, fills_of, [E]() { return E->bind(); });
+	E->cells_sharers.store(1, std::memory_order_relaxed);
+	return rc;
 }
 
 }  // namespace

@@ -394,10 +394,15 @@ int FillBatch::add(int nrows, int ncols, int nprev, int left_i)
 /* The helper-wave layout of nw_fill_cells wants one workgroup per compute unit (every chain alone on its units): the limit follows the
  * device's compute units -- a partitioned or smaller part has fewer than the 256 of a whole MI355X (round-4 ADVICE) -- unless
  * CSADP_CELLS_FETCH was set explicitly. */
-int cells_fetch_limit(const Engine &E)
+/* A workgroup of that layout has a compute unit to itself (six waves, the LDS rings), and its consumer waves spin on their producers: when
+ * several launches share the device (`sharers`: round groups, passes of one batch in flight) and together hold more workgroups than there
+ * are compute units, a producer can wait for a unit behind consumers that wait for it, until their bounded waits run out (seen with the
+ * layout forced onto four round groups of a thousand workgroups each: seconds per launch).  The limit is therefore per sharer. */
+int cells_fetch_limit(const Engine &E, int sharers)
 {
 	const Config &cfg = config();
-	return cfg.cells_fetch_forced ? cfg.cells_fetch_wgs : std::min(cfg.cells_fetch_wgs, E.compute_units());
+	if (cfg.cells_fetch_forced) return cfg.cells_fetch_wgs;
+	return std::min(cfg.cells_fetch_wgs, E.compute_units()) / std::max(1, sharers);
 }
 
 bool FillBatch::lone_pairs_take_cells() const
@@ -409,7 +414,7 @@ bool FillBatch::lone_pairs_take_cells() const
 		if (J.nprev != 1 || J.leftmul != 0 || J.nrows < 4096 || J.ncols > 2L * J.nrows || J.ncols <= 0) return false;
 		chunks += (J.ncols + kCellStripCols * kCellWaves - 1) / (kCellStripCols * kCellWaves);
 	}
-	return chunks <= cells_fetch_limit(*E_);   /* (run_slot_cells: when a launch takes the fetcher layout) */
+	return chunks <= cells_fetch_limit(*E_, 1);   /* (run_slot_cells: when a launch takes the fetcher layout) */
 }
 
 int FillBatch::layout()
@@ -1370,7 +1375,7 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	 * the layout with a fetcher and a publisher wave (csadp_cells.hip, fetch_granules, publish_halves).  More: a compute unit holds two
 	 * workgroups of four waves, but only one of six.  (ONE matrix of 391 chunks in that layout, its later chunks starting as the first ones end: a 200 kbp pair fills in
 	 * 19.15 ms, as in the plain layout, and the bit-parallel path stays ahead host to host: 20.5 against 22.3 ms.) */
-	const bool fetch = (int)tiles_.size() <= cells_fetch_limit(*E_);
+	const bool fetch = (int)tiles_.size() <= cells_fetch_limit(*E_, std::max(nslots_, E_->cells_sharers.load(std::memory_order_relaxed)));
 	if (!serial) {
 		HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st,
 		                          config().test_slow_publisher));

@@ -73,6 +73,9 @@ public:
 
 	/* csadp_align_batch keeps one FillBatch (HBM arena + pinned staging, grow-only) per device alive
 	 * between calls: the drop-in adapter calls it once per un-anchored gap (~50 times per input set) */
+	/* launches of nw_fill_cells that may share the device: the round groups of the batch in flight (csadp_align_batch) -- the helper-wave
+	 * layout is taken only while ALL of them together fit one workgroup per compute unit (cells_fetch_limit) */
+	std::atomic<int> cells_sharers{1};
 	std::atomic<long> recoveries{0};              /* passes of any batch of this engine repeated chunk by chunk (FillBatch::check_abort) */
 	std::mutex batch_mutex;
 	FillBatch *cached_batch = nullptr;
