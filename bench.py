@@ -588,6 +588,7 @@ def profile_batch_leg(csa_amd):
     from helpers import random_family, rng
     out = {}
     for name, nfam, nseq, length, rotate in (("256_families_of_8x4000", 256, 8, 4000, False), ("16_families_of_16x16000", 16, 16, 16000, False),
+                                             ("64_families_of_4x30000", 64, 4, 30000, False),
                                              ("64_families_of_8x4000_misrotated", 64, 8, 4000, True)):
         r = rng(nfam * 1000 + nseq)
         tasks = []

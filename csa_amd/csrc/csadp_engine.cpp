@@ -542,6 +542,16 @@ int FillBatch::layout_cells()
 		for (size_t i = 0; i < serial_tiles_.size(); ++i)
 			if (i == 0 || serial_tiles_[i].a != serial_tiles_[i - 1].a) chunk_first_.push_back(i);
 		chunk_first_.push_back(serial_tiles_.size());
+		/* Job by job, a launch that does not fit the device keeps the later chunks of every resident job spinning until their wavefront
+		 * arrives -- chunk c of a job starts 3.6 us x 4 strips x c behind its first: 0.66 ncols of nrows + 0.66 ncols steps on average, a
+		 * quarter to 40 % of the slots a batch of families holds -- while the jobs behind them wait for those slots.  Level by level
+		 * (every job's first chunk, then every second one, ...; a job's chunks still in ascending order, so a producer is still dispatched
+		 * before its consumer) a chunk gets its slot when its producer is nearly or wholly through: resident workgroups work.  The price is
+		 * a job's own latency (its levels queue behind everyone's), so only launches beyond what the device holds at two workgroups per
+		 * compute unit -- shared with the other round groups -- take it (tools/r05/profile_batch_probe.py, profiles/r05_cells_order.txt). */
+		const int sharers = std::max(1, E.cells_sharers.load(std::memory_order_relaxed));
+		const bool by_level = cfg.cells_order >= 0 ? cfg.cells_order == 1 : (long)tiles_.size() * sharers > 2 * cus;
+		if (by_level) tiles_ = serial_tiles_;
 	}
 
 	nslots_ = pipelined_ ? E.slots() : 1;

@@ -417,6 +417,30 @@ def test_publisher_wave_that_falls_behind_its_strip(slow, monkeypatch):
     assert g["status"] == 0 and g["aligned"] == wantp[1] and g["score"] == wantp[2].last_score
 
 
+@pytest.mark.parametrize("order", ["0", "1", None])
+def test_work_list_order_of_a_profile_launch(order, monkeypatch):
+    """nw_fill_cells takes its workgroups from a list: job by job (CSADP_CELLS_ORDER=0: launches the device holds at once) or chunk level
+    by chunk level (=1: larger launches, so that a resident workgroup's producer is through, not still on its way; csadp_engine.cpp,
+    layout_cells).  Either way a job's chunks are in ascending order and the results are the oracle's: 160 families of 3 sequences of
+    1 500-2 600 letters (12-21 strips: 3-6 chunks per matrix; four round groups of ~160 workgroups, together more than the device holds),
+    forced to one order, to the other, and left to the rule."""
+    if order is not None:
+        monkeypatch.setenv("CSADP_CELLS_ORDER", order)
+    r = rng(4242)
+    tasks = []
+    for i in range(160):
+        fam = random_family(r, 3, 1500 + 275 * (i % 5), mut=0.08, indel=0.03)
+        tasks.append((fam, [r.randrange(len(f)) for f in fam], None, None))
+    before = csa_amd.recoveries()
+    got = csa_amd.align_batch(tasks)
+    assert csa_amd.recoveries() == before
+    for t, g in zip(tasks, got):
+        assert g["status"] == 0 and len(set(len(x) for x in g["aligned"])) == 1
+    for i in range(0, 160, 7):
+        cons, strs, st = oracle_progressive(tasks[i][0], tasks[i][1])
+        assert got[i]["consensus"] == cons and got[i]["aligned"] == strs and got[i]["score"] == st.last_score
+
+
 @pytest.mark.parametrize("walk", ["serial", "banded"])
 def test_thousands_of_small_families_in_one_batch(walk, monkeypatch):
     """The N-sequence twin of the test above: 2048 families of 3-6 sequences of 60-700 letters through csadp_align_batch -- lock-step
