@@ -133,7 +133,7 @@ struct RingHalf {
 };
 
 /* The statement's operands.  The lane state (outvA .. sh) goes in and comes out in the same registers; the block's letters are eight FIXED
- * vector registers with the same content in every lane (v[246:253], register variables of run_strip: the statement asks for the next
+ * vector registers with the same content in every lane (CELLS_LT0..7, register variables of run_strip: the statement asks for the next
  * block's itself). */
 #define CELLS_BLOCK_OPERANDS                                                                                                   \
 	: [outvA] "+v"(outvA), [outvB] "+v"(outvB), [dgA] "+v"(dgA), [dgB] "+v"(dgB), [sh] "+v"(sh), [w0A] "=&v"(w0A),             \
@@ -345,14 +345,14 @@ __device__ __forceinline__ bool run_strip(const CellJob &J, const uint8_t *rsh, 
 	typedef const __attribute__((address_space(4))) uint32_t *ConstWords;
 	ConstWords rw = (ConstWords)(uintptr_t)rsh;
 	/* the block's 32 letter offsets: eight registers the statement names itself (it loads the next block's into them) */
-	register uint32_t lt0 asm("v246") = rw[0];
-	register uint32_t lt1 asm("v247") = rw[1];
-	register uint32_t lt2 asm("v248") = rw[2];
-	register uint32_t lt3 asm("v249") = rw[3];
-	register uint32_t lt4 asm("v250") = rw[4];
-	register uint32_t lt5 asm("v251") = rw[5];
-	register uint32_t lt6 asm("v252") = rw[6];
-	register uint32_t lt7 asm("v253") = rw[7];
+	register uint32_t lt0 asm(CELLS_LT0) = rw[0];
+	register uint32_t lt1 asm(CELLS_LT1) = rw[1];
+	register uint32_t lt2 asm(CELLS_LT2) = rw[2];
+	register uint32_t lt3 asm(CELLS_LT3) = rw[3];
+	register uint32_t lt4 asm(CELLS_LT4) = rw[4];
+	register uint32_t lt5 asm(CELLS_LT5) = rw[5];
+	register uint32_t lt6 asm(CELLS_LT6) = rw[6];
+	register uint32_t lt7 asm(CELLS_LT7) = rw[7];
 	const unsigned long long lbase = (unsigned long long)(uintptr_t)rsh;
 	/* ROLE_CHUNK: 8-byte granules {X, epoch << 8}, each written by ONE write-through store and valid exactly
 	 * when it carries this launch's epoch -- no counter, no fence, one memory round trip, and that one is

@@ -1385,7 +1385,11 @@ int FillBatch::run_slot_cells(int sl, bool serial)
 	 * the layout with a fetcher and a publisher wave (csadp_cells.hip, fetch_granules, publish_halves).  More: a compute unit holds two
 	 * workgroups of four waves, but only one of six.  (ONE matrix of 391 chunks in that layout, its later chunks starting as the first ones end: a 200 kbp pair fills in
 	 * 19.15 ms, as in the plain layout, and the bit-parallel path stays ahead host to host: 20.5 against 22.3 ms.) */
-	const bool fetch = (int)tiles_.size() <= cells_fetch_limit(*E_, std::max(nslots_, E_->cells_sharers.load(std::memory_order_relaxed)));
+	/* (sharers: the other round groups of the batch in flight, and the fills of this batch's other slots that have not finished) */
+	int own_in_flight = 1;
+	for (int o = 0; o < nslots_; ++o)
+		if (o != sl && slot_used_[o] && hipEventQuery(ev_[o][1]) != hipSuccess) ++own_in_flight;
+	const bool fetch = (int)tiles_.size() <= cells_fetch_limit(*E_, std::max(own_in_flight, E_->cells_sharers.load(std::memory_order_relaxed)));
 	if (!serial) {
 		HIP_TRY(launch_fill_cells(wide_, fetch, arena_, cj, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size(), epoch, abort_word, st,
 		                          config().test_slow_publisher));

@@ -11,25 +11,34 @@ bit-parallel block gains 15 % from keeping them at 0 mod 8 (tools/gen_bits_block
 instruction per step in its VOP3 form behind a .p2align 3 -- a strip alone 90 against 91 cycles per step, a 16 384^2 fill 1.156 against
 1.153 ms) and stays as it is.
 
-Register map (clobbered by the statement):
-  v[128:163]  XW   the 9 x ds_read_b128 window of hand-off values; word 3 + t = XP(t), the lane-0 preset of
-                   step t (hand-off value + leftcA), which v_add_u32_dpp turns into lfA(t) for all other lanes
-  v[168:199]  OXB  X of the lane's B cell after step t (what lane 63 hands to the next strip): 8 x ds_write_b128
-  v[200:231]  Y    letter offset of step t (lane 0 preset from the row sequence, v_mov_b32_dpp for the others)
-  v[236:243]  H, G, ACCA, ACCB, DGA, DGB, OXA, LFB
-  v244        LM   ramp variants (a strip's first two blocks): -4 in the lanes whose first row has arrived, 0 in the others; moves one
+Register map (clobbered by the statement; BASE = 56: the compiler's own values of the kernel -- 52 registers -- fit below it, so the kernel
+takes 150 registers and a SIMD holds THREE of its waves.  Rounds 2-4 had the map at v128 and 32 registers for OXB: 254 registers, two waves):
+  v[BASE:BASE+35]      XW   the 9 x ds_read_b128 window of hand-off values; word 3 + t = XP(t), the lane-0 preset of
+                            step t (hand-off value + leftcA), which v_add_u32_dpp turns into lfA(t) for all other lanes
+  v[BASE+36:BASE+43]   OXB  X of the lane's B cell after step t, in register t % 8 (what lane 63 hands to the next strip: a 16-byte LDS store
+                            of four of them every four steps, from the half of the eight that the next four steps do not write)
+  v[BASE+44:BASE+75]   Y    letter offset of step t (lane 0 preset from the row sequence, v_mov_b32_dpp for the others)
+  v[BASE+76:BASE+83]   H, G, ACCA, ACCB, DGA, DGB, OXA, LFB
+  v(BASE+84)           LM   ramp variants (a strip's first two blocks): -4 in the lanes whose first row has arrived, 0 in the others; moves one
                    lane to the right per step like the letters.  A lane that is not live yet runs the same instructions on its border
                    values and keeps them: X is taken through v_bfi_b32 (LM ? h & -4 : old X) where the later blocks have v_and_b32;
                    everything else such a lane computes is either unused or already what its first row needs (lf = the left lane's border
                    value + leftc = its own D; the next step's dg from that and the letter that arrives with the row)
+  v[BASE+86:BASE+93]   LT   the block's 32 letter offsets (below)
 """
+import os
 import sys
 
-XW, OXB, Y = 128, 168, 200
-H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM = 236, 237, 238, 239, 240, 241, 242, 243, 244
-LT = 246        # v[246:253] (tuples start at even registers): the block's 32 letter offsets, the same in every lane (operands of the statement, pinned by register variables)
+BASE = int(os.environ.get("CELLS_BLOCK_BASE", "56"))      # (128: the occupancy of rounds 2-4, two waves per SIMD, for A/B runs)
+XW, OXB0, Y = BASE, BASE + 36, BASE + 44
+H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM = (BASE + 76 + i for i in range(9))
+LT = BASE + 86  # eight registers (tuples start at even registers): the block's 32 letter offsets, the same in every lane (operands of the statement, pinned by register variables)
 PX = XW + 3
 DPP = "wave_shr:1 row_mask:0xf bank_mask:0xf"
+
+
+def OXB(t):
+    return OXB0 + t % 8
 
 
 def gain(wide, ysrc, col):
@@ -118,7 +127,7 @@ def block(wide, role, ramp=False):
         for t in range(32):
             a.append("v_add_u32 v%d, v%d, %%[leftcA]" % (PX + t, PX + t))
     for t in range(32):
-        prevB = "%[outvB]" if t == 0 else "v%d" % (OXB + t - 1)
+        prevB = "%[outvB]" if t == 0 else "v%d" % OXB(t - 1)
         if t == 12 and role == "RING":
             # the second half is asked for five steps before it is needed (the counter in front of it)
             a.append("ds_read_b32 %[vtmp], %[paddr]")
@@ -156,14 +165,14 @@ def block(wide, role, ramp=False):
             a += gain(wide, Y + t + 1, "B")
             a.append("v_add_u32 v%d, v%d, v%d" % (DGB, LFB, G))
         if ramp:
-            a.append("v_bfi_b32 v%d, v%d, v%d, %s" % (OXB + t, LM, H, prevB))
+            a.append("v_bfi_b32 v%d, v%d, v%d, %s" % (OXB(t), LM, H, prevB))
             if t < 31:
                 a.append("v_mov_b32_dpp v%d, v%d %s" % (LM, LM, DPP))
         else:
-            a.append("v_and_b32 v%d, -4, v%d" % (OXB + t, H))
+            a.append("v_and_b32 v%d, -4, v%d" % (OXB(t), H))
         a.append("v_alignbit_b32 v%d, v%d, v%d, 2" % (ACCB, H, ACCB))
         if t % 4 == 3:
-            a.append("ds_write_b128 %%[waddr], v[%d:%d] offset:%d" % (OXB + t - 3, OXB + t, 16 * (t // 4)))
+            a.append("ds_write_b128 %%[waddr], v[%d:%d] offset:%d" % (OXB(t - 3), OXB(t), 16 * (t // 4)))
         if t == 15:
             # half of the block's hand-off values are in the ring: the half-block counter (lane 63's address is the counter,
             # every other lane's its scrap slot; the LDS runs a wave's stores in order)
@@ -183,7 +192,7 @@ def block(wide, role, ramp=False):
     a.append("v_mov_b32 %%[dgB], v%d" % LFB)               # ... of column B: lfB
     a.append("v_mov_b32 %%[sh], v%d" % (Y + 31))
     a.append("v_mov_b32 %%[outvA], v%d" % OXA)
-    a.append("v_mov_b32 %%[outvB], v%d" % (OXB + 31))
+    a.append("v_mov_b32 %%[outvB], v%d" % OXB(31))
     return a
 
 
@@ -205,6 +214,8 @@ def statement(wide, role):
 for wide in (0, 1):
     for role in ("LDS", "FIRST", "RING"):
         out.append("#define CELLS_BLOCK_ASM_%s_%s \\\n%s" % ("WIDE" if wide else "BYTE", role, cstring(statement(wide, role))))
-regs = list(range(XW, XW + 36)) + list(range(OXB, OXB + 32)) + list(range(Y, Y + 32)) + [H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM]
+regs = list(range(XW, XW + 36)) + list(range(OXB0, OXB0 + 8)) + list(range(Y, Y + 32)) + [H, G, ACCA, ACCB, DGA, DGB, OXA, LFB, LM]
 out.append("#define CELLS_BLOCK_CLOBBERS " + ", ".join('"v%d"' % r for r in regs) + ', "memory"')
+for i in range(8):
+    out.append('#define CELLS_LT%d "v%d"' % (i, LT + i))
 open(sys.argv[1], "w").write("\n".join(out) + "\n")
