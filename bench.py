@@ -617,7 +617,8 @@ def profile_batch_leg(csa_amd):
                                                             "up to four such launches on the chip at once: the duration is a launch's own, not a solo rate")
     out["what"] = ("families of random related sequences through csadp_align_batch: lock-step rounds over two round groups, four from 128 tasks on; 8 x 4 kbp: 9 workgroups of "
                    "nw_fill_cells per matrix; 16 x 16 kbp: 32-40 per matrix.  Co-linear families run device-bound (the two groups' "
-                   "device parts overlap); misrotated ones are bound by DeleteGappedColumns on the host (DESIGN.md section 10)")
+                   "device parts overlap); misrotated ones are bound by DeleteGappedColumns on the host (DESIGN.md section 10).  nw_fill_cells is issue-bound at 86 cycles per "
+                   "step of 128 cells per SIMD whatever its occupancy: 3.66 TCUPS for the chip (DESIGN.md section 3 K1c); the first fill of every family runs on nw_fill_bits")
     return out
 
 
