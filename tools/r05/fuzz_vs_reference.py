@@ -97,7 +97,13 @@ while time.time() < t_end:
         csa_amd.reload_config()
     else:
         tasks = [make_task() for _ in range(r.choice([40, 120, 160, 300]))]      # 128 and more: four round groups
+        order = r.choice(["0", "1", None])                                       # work list of nw_fill_cells: job by job, level by level, by the rule
+        if order is not None:
+            os.environ["CSADP_CELLS_ORDER"] = order
+        csa_amd.reload_config()
         got = csa_amd.align_batch(tasks)
+        os.environ.pop("CSADP_CELLS_ORDER", None)
+        csa_amd.reload_config()
     for t, g in zip(tasks, got):
         cons, strs, _ = ref_progressive(*t)
         same = g["status"] == 0 and ((g["aligned"] is None and all(s is None for s in strs)) or g["aligned"] == strs)
