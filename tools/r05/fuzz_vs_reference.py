@@ -7,7 +7,7 @@ regions, sub-regions with rotations, homopolymers and short periods (ties everyw
 A third argument "pairs" fuzzes the device-I/O pair path instead (nw_pack_planes, nw_fill_bits at 1-4 words per lane and 4 / 8 / 16 strips per
 workgroup, nw_traceback_windows, nw_expand_rows): batches of 2-sequence tasks only, 1..9000 letters, sub-regions and rotations, run twice per batch.
 
-usage: python tools/r05/fuzz_vs_reference.py [seconds] [seed] [pairs]"""
+usage: python tools/r05/fuzz_vs_reference.py [seconds] [seed] [pairs|long]"""
 import os
 import sys
 import time
@@ -27,6 +27,8 @@ r = rng(seed)
 
 def make_task():
     kind = r.choice(["family", "family", "family", "pair", "equal", "periodic", "skewed", "subregions", "tiny"])
+    if LONG and r.random() < 0.04:
+        kind = "long"
     if kind == "pair":
         fam = random_family(r, 2, r.choice([1, 5, 60, 300, 1500, 4000]), mut=r.choice([0.0, 0.05, 0.3, 0.75]), indel=r.choice([0.0, 0.05, 0.3]))
     elif kind == "equal":
@@ -42,6 +44,8 @@ def make_task():
         n = r.choice([3, 5, 8])
         fam = random_family(r, n, 40, mut=0.2, indel=0.1)
         fam[r.randrange(n)] = bytes(r.choice(b"ACGT") for _ in range(r.choice([800, 2500])))
+    elif kind == "long":                                 # matrices of 40-100 strips: chains of 10-25 workgroups of nw_fill_cells
+        fam = random_family(r, r.choice([3, 4, 5]), r.choice([5000, 8000, 12000]), mut=r.choice([0.03, 0.15]), indel=r.choice([0.01, 0.05]))
     elif kind == "tiny":
         n = r.choice([2, 3, 4, 12, 24])
         fam = [bytes(r.choice(b"ACGT") for _ in range(r.randrange(1, 6))) for _ in range(n)]
@@ -76,6 +80,7 @@ def make_pair():
 
 
 pairs_mode = len(sys.argv) > 3 and sys.argv[3] == "pairs"
+LONG = len(sys.argv) > 3 and sys.argv[3] == "long"      # families mode with a few long families per batch
 t_end = time.time() + budget
 done = bad = 0
 cells = 0
