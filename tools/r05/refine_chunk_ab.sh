@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs a build in which that size is read from CSADP_REFINE_CHUNK -- a four-line patch of csadp_progressive.cpp / csadp_config.h; the shipped code has 256 as a constant)
 # columns per speculation item of DeleteGappedColumns (CSADP_REFINE_CHUNK): the refine phases of the example sets' rounds, summed
 cd ${GRAFT_REPO_ROOT:-.}
 for rep in 1 2; do
