@@ -21,6 +21,7 @@ struct Config {
 	bool lone_shape = true;         /* CSADP_LONE_SHAPE: a pass flushed alone takes the spread shape (csadp_engine.h) */
 	int stream_rotate = -1;         /* CSADP_STREAM_ROTATE: batches of one engine start on different streams (default: by batch size) */
 	bool cells_fetch_forced = false; /* CSADP_CELLS_FETCH was set: taken as it is; else min(256, the device's compute units) */
+	int bits_pack = 1;              /* CSADP_BITS_PACK: jobs of one or two strips share four-wave workgroups of nw_fill_bits (1, the default; 0: a workgroup per job) */
 	int cells_order = -1;           /* CSADP_CELLS_ORDER: work list of a cell-per-lane launch: 0 job by job, 1 chunk level by chunk level, -1 by size (layout_cells) */
 	int cells_fetch_wgs = 256;      /* CSADP_CELLS_FETCH: cell-per-lane launches of at most this many workgroups carry a fetcher wave (0: none) */
 	bool lone_cells = true;         /* CSADP_LONE_CELLS: at most 8 large square-ish pairs alone take the cell-per-lane path (FillBatch::layout) */

@@ -653,13 +653,14 @@ int FillBatch::layout_bits()
 		/* two words per lane when that still puts two waves on every SIMD: strips of 64 lanes x 2 words, times the passes a
 		 * pipelined batch keeps in flight (2 launches of up to 4 passes, chosen below by the same rule).  Batches smaller than
 		 * that -- down to one matrix -- are bound by the latency of a step: one word per lane, twice the strips. */
-		long long strips[4] = {0, 0, 0, 0}, cost[4] = {0, 0, 0, 0};
+		long long strips[4] = {0, 0, 0, 0}, cost[4] = {0, 0, 0, 0}, widest[4] = {0, 0, 0, 0};
 		static const int kStepValu[4] = {0, 31, 52, 73};              /* VALU instructions per step (tools/count_valu.py) */
 		for (const FillJob &J : jobs_) {
 			const long long words = (J.ncols + 31) / 32;
 			for (int w = 1; w <= 3; ++w) {
 				const long long sw = (words + 64 * w - 1) / (64 * w);
 				strips[w] += sw;
+				widest[w] = std::max(widest[w], sw);
 				/* strips times the step's instructions.  (Until round 5 a job of up to 16 strips was ONE workgroup: a fifth strip
 				 * doubled up on the first strip's SIMD, and strips beyond four counted in fours.  Jobs wider than four strips are
 				 * chains of four-strip workgroups now -- below -- and a fifth strip is a workgroup of its own.) */
@@ -676,7 +677,11 @@ int FillBatch::layout_bits()
 		 * 200 kbp to 1000 of 5 kbp at 1 / 2 / 3 words; round 4's rule (1.5 waves per SIMD for two words, strips in fours) chose one
 		 * word for 16 pairs of 33 kbp and 32 of 17 kbp (18.7 against 22.7 TCUPS) and two for 40 of 50 kbp and 64 of 100 kbp
 		 * (33.3 / 41.0 against 36.0 / 44.0 at three). */
-		const bool ok2 = strips[2] * passes >= simds, ok3 = strips[3] * passes >= simds;
+		/* ... and where every job is at most two strips the jobs share four-wave workgroups (bits_pack_ below) and a launch holds up to eight
+		 * passes of them: sixteen passes in flight (tools/r05/pack_words.py, profiles/r05_pack_words.txt: 200 pairs of 7 kbp 31.6 at one word,
+		 * 35.6 at two; 128 of 4 kbp 25.0 / 30.8; 96 of 8 kbp 33.2 / 36.9) */
+		auto in_flight = [&](int w) { return (pipelined_ && cfg.bits_pack != 0 && widest[w] <= 2) ? 16 : passes; };
+		const bool ok2 = strips[2] * in_flight(2) >= simds, ok3 = strips[3] * in_flight(3) >= simds;
 		int w = 1;
 		long long best = cost[1] * 100 / 93;
 		if (ok2 && cost[2] <= best) { w = 2; best = cost[2]; }
@@ -715,13 +720,17 @@ int FillBatch::layout_bits()
 	 * four per SIMD. */
 	bits_group_ = 1;
 	nslots_ = 1;
+	/* jobs of one or two strips share workgroups of four waves (nw_fill_bits<.., PACK>): the launch then has the shape of four-strip jobs */
+	bits_pack_ = 1;
+	if (cfg.bits_pack != 0 && bits_maxstrips_ <= 2) bits_pack_ = bits_maxstrips_ == 1 ? 4 : 2;
 	if (pipelined_) {
 		/* workgroups of at most three strips (real mitochondrial genomes at three words per lane: 16.3-17.7 k columns) leave a
 		 * SIMD of their compute unit idle and a pass is few waves (66 pairs: 198): four launches in flight, and no LDS
 		 * reservation below, so that a compute unit takes three or four of them (profiles/r04_sweep_real.txt, 48 steps, with
 		 * round 3's traceback: 66 Mammals pairs 24.6 -> 29.6 TCUPS, 120 Primates pairs 31.2 -> 33.7; with the windowed traceback
 		 * 32-33 and 36-38 in every shape of four launches; synthetic pairs of the same shape: profiles/r04_shape_probe.txt) */
-		const bool small_wgs = bits_maxstrips_ <= 3;
+		const int wg_strips = bits_pack_ > 1 ? 4 : bits_maxstrips_;      /* waves of a workgroup */
+		const bool small_wgs = wg_strips <= 3;
 		const int dflt_streams = small_wgs ? 4 : 2;
 		/* passes per launch: one workgroup per compute unit (tools/history/sweep_words.sh, profiles/r03_sweep_words.txt: with two words
 		 * per lane 2 streams x 2 passes = two waves per SIMD runs 44 TCUPS, 4 x 2 39-43, 2 x 4 37-40: more workgroups than compute
@@ -735,14 +744,14 @@ int FillBatch::layout_bits()
 		 * waves on every SIMD, up to seven (tools/r05/group_probe.py, profiles/r05_group_probe.txt: 128 pairs of 12 kbp 31.0 -> 38.4 TCUPS,
 		 * 256 of them 32.0 -> 37.6, 512 of 5 kbp 23.1 -> 26.3, 128 of 6 kbp at one word per lane 27.0 -> 30.1; three-strip workgroups -- the
 		 * real mitochondrial sets -- keep the shape round 4 measured for them) */
-		if (bits_maxstrips_ <= 2) {
+		if (wg_strips <= 2) {
 			const int two_per_simd = 8 * want / std::max(nj * bits_maxstrips_, 1);        /* passes that put two waves on every SIMD */
 			/* fewer jobs than even eight passes fill: four launches of four passes keep more in flight than two of seven (64 pairs of 12 kbp:
 			 * 32.1 against 28.4 TCUPS) */
 			bits_group_ = two_per_simd > 8 ? 4 : std::max(1, std::min(two_per_simd, 7));
 		}
-		else if (bits_maxstrips_ == 3) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
-		else if (bits_maxstrips_ == 4) {
+		else if (wg_strips == 3) bits_group_ = std::max(1, std::min(want / std::max(nj, 1), 4));
+		else if (wg_strips == 4) {
 			/* Four-strip workgroups (16 kbp pairs at two words per lane): a launch should be whole "waves" of workgroups -- a multiple of the
 			 * compute units.  Round 3 found one workgroup per compute unit per launch (128 jobs x 2 passes, 64 x 4: 360 workgroups ran 29 TCUPS
 			 * where 240 ran 39) and took floor(CUs / jobs) passes; job counts that do not divide the compute units were left with launches of
@@ -755,7 +764,7 @@ int FillBatch::layout_bits()
 			int best_rel = 1 << 30;
 			bits_group_ = 8;
 			for (int g = 1; g <= 8; ++g) {
-				const long total = (long)nj * g;
+				const long total = ((long)nj * g + bits_pack_ - 1) / bits_pack_;    /* workgroups of a launch of g passes */
 				if (total < want && g < 8) continue;                      /* not even one workgroup per compute unit */
 				const long waves = (total + want - 1) / want;
 				const int rel = (int)((waves * want - total) * 1000 / (waves * want));
@@ -799,7 +808,7 @@ int FillBatch::layout_bits()
 	 * reserves dynamic LDS so that exactly two of them fit next to one traceback workgroup (tools/history/sweep_pad.sh,
 	 * profiles/r03_sweep_pad.txt: +2-4 %, and a collapse of 25 % as soon as two fills and a traceback no longer fit). */
 	bits_lds_pad_ = 0;
-	if (pipelined_ && !bits_wide_ && bits_maxstrips_ > 3) {
+	if (pipelined_ && !bits_wide_ && (bits_maxstrips_ > 3 || bits_pack_ > 1)) {
 		const int waves = bits_maxstrips_ <= 4 ? 4 : bits_maxstrips_ <= 8 ? 8 : 16;
 		const int room = (160 * 1024 - traceback_bits_lds_bytes(bits_words_)) / 2 - fill_bits_lds_bytes(waves) - 2048;
 		bits_lds_pad_ = std::max(0, std::min(room, 60 * 1024)) & ~255;
@@ -1301,7 +1310,7 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 				                              (int)(chunk_first[c + 1] - chunk_first[c]), epoch, abort_word, st));
 		}
 	} else {
-		HIP_TRY(launch_fill_bits(words, arena_, bj, g * nj, lone ? 4 : bits_maxstrips_, lone ? 0 : bits_lds_pad_, abort_word, st));
+		HIP_TRY(launch_fill_bits(words, arena_, bj, g * nj, lone ? 4 : bits_maxstrips_, lone ? 0 : bits_lds_pad_, abort_word, st, lone ? 1 : bits_pack_));
 	}
 	if (!serial && wide && test_abort_)                   /* testing: see run_slot_cells */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));

@@ -191,6 +191,7 @@ Config read_config()
 	c.bits_lds_pad = env_int("CSADP_BITS_LDS_PAD", -1);
 	c.lone_shape = env_int("CSADP_LONE_SHAPE", 1) != 0;
 	c.stream_rotate = env_int("CSADP_STREAM_ROTATE", -1);
+	c.bits_pack = env_int("CSADP_BITS_PACK", 1);
 	c.cells_order = env_int("CSADP_CELLS_ORDER", -1);
 	c.cells_fetch_wgs = env_int("CSADP_CELLS_FETCH", 256);
 	c.cells_fetch_forced = getenv("CSADP_CELLS_FETCH") != nullptr;

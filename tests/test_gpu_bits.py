@@ -145,6 +145,40 @@ def test_pair_batch_pipelined_passes_agree(bits_mode):
         assert g["aligned"] == strs and g["score"] == st.last_score
 
 
+@pytest.mark.parametrize("words", ["1", "2", "3", "4"])
+def test_jobs_of_one_and_two_strips_share_workgroups(words, monkeypatch):
+    """Jobs of at most two strips share four-wave workgroups of nw_fill_bits (two per workgroup, four when every job is one strip;
+    csadp_bits.hip, PACK): an odd number of jobs (the last workgroup has an empty place), one- and two-strip jobs side by side, jobs
+    whose rows end long before their neighbour's, a batch of one-strip jobs only -- pipelined (several passes per launch) and alone,
+    packed and one workgroup per job (CSADP_BITS_PACK=0): the same rows, the oracle's."""
+    monkeypatch.setenv("CSADP_BITS_WORDS", words)
+    r = rng(2200 + int(words))
+    w = int(words)
+    one, two = 2048 * w, 4096 * w                        # columns of one / two strips at this many words per lane
+    lens = [one - 7, two - 5, 3, one + 1, two, one, 60, one // 2, two - 1, one + 300, 900]     # 11 jobs: five and a half workgroups of two
+    tasks = []
+    for n in lens:
+        a, b = related(r, n, n)                          # neither sequence longer than n: whichever becomes the columns fits the strips meant
+        tasks.append(([a, b], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    only_one = [t for t, n in zip(tasks, lens) if n <= one][:7]                               # 7 one-strip jobs: workgroups of four, the last with three
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    for batch, exp in ((tasks, want), (only_one, [want[tasks.index(t)] for t in only_one])):
+        rows = None
+        for pack in ("1", "0"):
+            monkeypatch.setenv("CSADP_BITS_PACK", pack)
+            pb = csa_amd.PairBatch(batch)
+            for passes in (1, 9):
+                for _ in range(passes):
+                    pb.run()
+                pb.sync()
+                got = pb.fetch()
+                for g, (cons, strs, st) in zip(got, exp):
+                    assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score and g["consensus"] == cons, (pack, passes)
+                assert rows is None or rows == [g["aligned"] for g in got]
+                rows = [g["aligned"] for g in got]
+            pb.close()
+
+
 def test_pair_batch_run_once_then_many_times(bits_mode):
     """A pipelined batch of one workgroup per job whose single pass does not fill the chip keeps a second shape for a pass
     flushed alone onto an idle device (one word per lane, four strips per workgroup over all compute units:
