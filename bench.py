@@ -516,6 +516,36 @@ def unrelated_leg(csa_amd, steps=20, warmup=5):
             "what": "64 unrelated random 16384-letter pairs, every record against the compiled reference's (tests/golden/unrelated_pairs.json)"}
 
 
+def small_pairs_leg(csa_amd, steps=48, warmup=8):
+    """Batches of pairs narrower than a four-strip workgroup (what the anchors of the reference's pipeline leave between them when a set is
+    aligned pair by pair): 256 pairs of 8 192 letters (two strips at two words per lane) and 128 of 12 000 (two at three), with the jobs
+    sharing four-wave workgroups of nw_fill_bits (the default) and one workgroup per job (CSADP_BITS_PACK=0); properties checked on every result."""
+    from csa_amd.synth import synth_pair
+    from helpers import degap, rotated, sp_score
+    out = {}
+    for name, npairs, length in (("256_pairs_of_8192", 256, 8192), ("128_pairs_of_12000", 128, 12000)):
+        tasks = []
+        for p in range(npairs):
+            a, b, ra, rb = synth_pair(90000 + p, length=length)
+            tasks.append(([a, b], [ra, rb], None, None))
+        entry = {}
+        for tag, pack in (("shared_workgroups", None), ("one_workgroup_per_job", "0")):
+            if pack is not None:
+                os.environ["CSADP_BITS_PACK"] = pack
+            csa_amd.reload_config()
+            dt, tm, res = timed_pair_batch(csa_amd, tasks, steps, warmup)
+            os.environ.pop("CSADP_BITS_PACK", None)
+            csa_amd.reload_config()
+            ok = all(r["status"] == 0 and degap(r["aligned"][0]) == rotated(t[0][0], t[1][0]) and degap(r["aligned"][1]) == rotated(t[0][1], t[1][1]) and
+                     sp_score(r["aligned"]) == r["score"] for t, r in zip(tasks, res))
+            entry[tag] = {"gcups": round(tm["cells"] * steps / dt / 1e9, 1), "ms_per_step": round(dt * 1e3 / steps, 3), "words_per_lane": tm["words_per_lane"],
+                          "passes_per_launch": tm["merge_group"], "launches_in_flight": tm["streams"], "properties_hold_for_all": bool(ok),
+                          "recoveries": tm["recoveries"]}
+        out[name] = entry
+    out["what"] = "pair jobs of at most two strips: two (or four) jobs per four-wave workgroup against one workgroup per job, 48 + 8 steps each"
+    return out
+
+
 def config4_all_leg(csa_amd, first_tasks, steps=4, warmup=1):
     """BASELINE config 4 whole: all 1024 synthetic pairs on this one GPU as ONE device-resident batch (what the 8 ranks of the
     scaling run share out 128 apiece), every record against the compiled reference's (tests/golden/config4_all.json)."""
@@ -948,6 +978,7 @@ def main():
                 line["real_sets"] = real_sets_leg(csa_amd)
                 line["config5"] = config5_leg(csa_amd)
                 line["unrelated_16k"] = unrelated_leg(csa_amd)
+                line["small_pairs"] = small_pairs_leg(csa_amd)
                 if args.pairs <= 1024 and args.length == 16384:
                     line["config4_all"] = config4_all_leg(csa_amd, tasks)
                 line["records"]["checked_against_reference_digests_in_all_legs"] = (
