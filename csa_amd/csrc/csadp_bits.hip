@@ -392,9 +392,10 @@ __device__ __forceinline__ unsigned long long granule(uint32_t v, uint32_t epoch
  * only: every wait is bounded in time, a time-out raises the abort word and the host repeats the pass chunk by chunk.
  * LONE (WORK with 4 waves: one wave per SIMD, launches of few strips): inputs are read further ahead and polls do not sleep.
  */
-/* PACK (one workgroup per job only): jobs of at most WAVES / PACK strips share a workgroup, PACK of them -- four waves, one per SIMD of the
- * compute unit, where a workgroup of one or two waves leaves SIMDs to chance (round 5).  The jobs of a workgroup have nothing to do with each
- * other: a wave's ring neighbour is the wave before it only inside its own job. */
+/* PACK (the launches of whole jobs only): jobs narrower than the workgroup SHARE it -- four waves, one per SIMD of the compute unit, where a
+ * workgroup of one to three waves leaves SIMDs to chance (round 5).  `work` then is a table of one entry per wave, {job, strip} (job < 0: the
+ * place is empty), a job's strips on consecutive waves.  The jobs of a workgroup have nothing to do with each other: a wave's ring neighbour
+ * is the wave before it only inside its own job. */
 template <int W, int WAVES, bool WORK, int PACK = 1>
 __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restrict__ arena, const BitJob *__restrict__ jobs, int njobs,
                                                               const TileRef *__restrict__ work, uint32_t epoch, int *__restrict__ abort_word)
@@ -417,10 +418,9 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 	/* 4 words further than a multiple of the 64 banks from the inject rows: the first lane's 16 bytes and everybody else's never share a bank */
 	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];
 	__shared__ int made[WAVES], taken[WAVES];
-	static_assert(PACK == 1 || (!WORK && WAVES % PACK == 0), "jobs share a workgroup only in the one-workgroup-per-job form");
-	constexpr int SPJ = WAVES / PACK;                            /* strips (waves) a job of this workgroup may have */
+	static_assert(PACK == 1 || !WORK, "jobs share a workgroup only where a workgroup holds whole jobs");
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-	const int sw = PACK > 1 ? wv % SPJ : wv;                     /* this wave's place among the waves of its job */
+	int sw = wv;                                                 /* this wave's place among the waves of its job */
 	int chunk = 0;
 	bool present = true;
 	const BitJob *jp;
@@ -429,9 +429,10 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 		jp = &jobs[(size_t)blockIdx.y * njobs + item.job];
 		chunk = item.a;
 	} else if (PACK > 1) {
-		const int jidx = (int)blockIdx.x * PACK + wv / SPJ;      /* njobs: all jobs of the launch */
-		present = jidx < njobs;
-		jp = &jobs[present ? jidx : njobs - 1];
+		const TileRef item = work[(size_t)blockIdx.x * WAVES + wv];   /* x: the workgroups of one pass, y: the pass */
+		present = item.job >= 0;
+		jp = &jobs[(size_t)blockIdx.y * njobs + (present ? item.job : 0)];
+		sw = item.a;
 	} else {
 		jp = &jobs[blockIdx.x];
 	}
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 		}
 	}
 	const uint32_t b00 = __builtin_amdgcn_readfirstlane(B0[0]), b10 = __builtin_amdgcn_readfirstlane(B1[0]);
-	const bool feeds = sw + 1 < SPJ && s + 1 < J.nstrips;                /* a wave of this workgroup reads my ring */
+	const bool feeds = (PACK > 1 || wv + 1 < WAVES) && s + 1 < J.nstrips;   /* a wave of this workgroup reads my ring (shared workgroups: a job's strips are all here) */
 	const bool publishes = WORK && wv + 1 == WAVES && s + 1 < J.nstrips;  /* the next chunk reads my granules */
 	const bool from_left_chunk = WORK && wv == 0 && chunk > 0;
 	uint4 *ck = reinterpret_cast<uint4 *>(arena + J.ckpt);
@@ -1032,14 +1033,10 @@ hipError_t launch_fill_w(bool chunked, uint8_t *arena, const BitJob *jobs, int n
                          uint32_t epoch, int *abort_word, hipStream_t st)
 {
 	/* chunked: `passes` doubles as nothing else; one workgroup per job: `passes` carries the dynamic LDS to reserve */
-	/* (one workgroup per job, nwork = 2 or 4: that many jobs per workgroup of four waves, launch_fill_bits) */
+	/* (whole jobs, work != nullptr: shared workgroups of four waves -- nwork of them per pass, `threads` passes; launch_fill_bits_shared) */
 	if constexpr (WAVES == 4) {
-		if (!chunked && nwork == 2) {
-			hipLaunchKernelGGL((nw_fill_bits<W, 4, false, 2>), dim3((njobs + 1) / 2), dim3(4 * kLanes), passes, st, arena, jobs, njobs, work, epoch, abort_word);
-			return hipGetLastError();
-		}
-		if (!chunked && nwork == 4) {
-			hipLaunchKernelGGL((nw_fill_bits<W, 4, false, 4>), dim3((njobs + 3) / 4), dim3(4 * kLanes), passes, st, arena, jobs, njobs, work, epoch, abort_word);
+		if (!chunked && work != nullptr) {
+			hipLaunchKernelGGL((nw_fill_bits<W, 4, false, 4>), dim3(nwork, threads), dim3(4 * kLanes), passes, st, arena, jobs, njobs, work, epoch, abort_word);
 			return hipGetLastError();
 		}
 	}
@@ -1070,13 +1067,22 @@ hipError_t launch_fill_any(int words, int waves, bool chunked, uint8_t *arena, c
 
 }  // namespace
 
-hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st, int pack)
+hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st)
 {
 	if (njobs <= 0) return hipSuccess;
 	if (maxstrips < 1 || maxstrips > kBitMaxStrips || lds_pad < 0 || lds_pad > 60 * 1024) return hipErrorInvalidValue;
-	if (pack != 1 && !((pack == 2 && maxstrips <= 2) || (pack == 4 && maxstrips == 1))) return hipErrorInvalidValue;
 	const int waves = maxstrips <= 4 ? 4 : maxstrips <= 8 ? 8 : 16;
-	return launch_fill_any(words, waves, false, arena, jobs, njobs, lds_pad, maxstrips * kLanes, nullptr, pack == 1 ? 0 : pack, 0u, abort_word, st);
+	return launch_fill_any(words, waves, false, arena, jobs, njobs, lds_pad, maxstrips * kLanes, nullptr, 0, 0u, abort_word, st);
+}
+
+/* jobs of at most four strips sharing four-wave workgroups: `table` = nwgs x 4 entries {job of the pass, strip} (job < 0: empty), the same for
+ * each of the `passes` passes whose job tables follow each other (njobs per pass) */
+hipError_t launch_fill_bits_shared(int words, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *table, int nwgs, int lds_pad,
+                                   int *abort_word, hipStream_t st)
+{
+	if (njobs <= 0 || nwgs <= 0 || passes <= 0) return hipSuccess;
+	if (table == nullptr || lds_pad < 0 || lds_pad > 60 * 1024) return hipErrorInvalidValue;
+	return launch_fill_any(words, 4, false, arena, jobs, njobs, lds_pad, passes, table, nwgs, 0u, abort_word, st);
 }
 
 hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,

@@ -720,9 +720,47 @@ int FillBatch::layout_bits()
 	 * four per SIMD. */
 	bits_group_ = 1;
 	nslots_ = 1;
-	/* jobs of one or two strips share workgroups of four waves (nw_fill_bits<.., PACK>): the launch then has the shape of four-strip jobs */
+	/* Jobs narrower than four strips share workgroups of four waves (nw_fill_bits<.., PACK>): first fit, widest and longest first, a job's
+	 * strips on consecutive waves; `shared_table_` is the launch's table, one {job, strip} per wave.  The launch then has the shape of
+	 * four-strip jobs.  Not when nothing is gained (every job takes a workgroup anyway: three- and four-strip jobs only). */
 	bits_pack_ = 1;
-	if (cfg.bits_pack != 0 && bits_maxstrips_ <= 2) bits_pack_ = bits_maxstrips_ == 1 ? 4 : 2;
+	shared_table_.clear();
+	if (cfg.bits_pack != 0 && bits_maxstrips_ <= 4) {
+		std::vector<int> order((size_t)nj);
+		for (int j = 0; j < nj; ++j) order[(size_t)j] = j;
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+			const BitJob &A = bjobs_[(size_t)a], &B = bjobs_[(size_t)b];
+			return A.nstrips != B.nstrips ? A.nstrips > B.nstrips : A.steps_pad > B.steps_pad;
+		});
+		std::vector<int> fill;                                 /* waves taken per workgroup */
+		std::vector<int> open_with[4];                         /* workgroups with 1, 2, 3 free waves (index = free waves) */
+		std::vector<TileRef> table;
+		for (int j : order) {
+			const int need = bjobs_[(size_t)j].nstrips;
+			int wg = -1;
+			for (int room = need; room <= 3 && wg < 0; ++room)
+				if (!open_with[room].empty()) { wg = open_with[room].back(); open_with[room].pop_back(); }
+			if (wg < 0) {
+				wg = (int)fill.size();
+				fill.push_back(0);
+				TileRef none;
+				none.job = -1; none.a = 0; none.s = 0; none.first = 0;
+				table.insert(table.end(), 4, none);
+			}
+			for (int c = 0; c < need; ++c) {
+				TileRef &t = table[(size_t)wg * 4 + fill[(size_t)wg] + c];
+				t.job = j;
+				t.a = c;
+			}
+			fill[(size_t)wg] += need;
+			if (fill[(size_t)wg] < 4) open_with[4 - fill[(size_t)wg]].push_back(wg);
+		}
+		if ((int)fill.size() < nj) {
+			shared_table_.swap(table);
+			bits_pack_ = 2;                                    /* (any value > 1: workgroups are shared) */
+		}
+	}
+	const int nwgs = bits_pack_ > 1 ? (int)shared_table_.size() / 4 : nj;       /* workgroups of a pass */
 	if (pipelined_) {
 		/* workgroups of at most three strips (real mitochondrial genomes at three words per lane: 16.3-17.7 k columns) leave a
 		 * SIMD of their compute unit idle and a pass is few waves (66 pairs: 198): four launches in flight, and no LDS
@@ -764,7 +802,7 @@ int FillBatch::layout_bits()
 			int best_rel = 1 << 30;
 			bits_group_ = 8;
 			for (int g = 1; g <= 8; ++g) {
-				const long total = ((long)nj * g + bits_pack_ - 1) / bits_pack_;    /* workgroups of a launch of g passes */
+				const long total = (long)nwgs * g;                /* workgroups of a launch of g passes */
 				if (total < want && g < 8) continue;                      /* not even one workgroup per compute unit */
 				const long waves = (total + want - 1) / want;
 				const int rel = (int)((waves * want - total) * 1000 / (waves * want));
@@ -880,6 +918,12 @@ int FillBatch::layout_bits()
 	}
 	tiles_off_ = off;
 	chunk_first_.clear();
+	if (!bits_wide_ && bits_pack_ > 1) {                 /* the table of the shared workgroups travels where a chunked launch has its work list */
+		tiles_ = shared_table_;
+		serial_tiles_.clear();
+		off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
+		serial_off_ = off;
+	}
 	if (bits_wide_) {
 		/* work list of the chunked kernel: (job, chunk of bits_chunk_ strips), the longest jobs first -- they
 		 * are the critical path of a mixed batch -- and a job's chunks in ascending order, so that the
@@ -1310,7 +1354,10 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 				                              (int)(chunk_first[c + 1] - chunk_first[c]), epoch, abort_word, st));
 		}
 	} else {
-		HIP_TRY(launch_fill_bits(words, arena_, bj, g * nj, lone ? 4 : bits_maxstrips_, lone ? 0 : bits_lds_pad_, abort_word, st, lone ? 1 : bits_pack_));
+		if (!lone && bits_pack_ > 1)
+			HIP_TRY(launch_fill_bits_shared(words, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off_), (int)tiles_.size() / 4, bits_lds_pad_,
+			                                abort_word, st));
+		else HIP_TRY(launch_fill_bits(words, arena_, bj, g * nj, lone ? 4 : bits_maxstrips_, lone ? 0 : bits_lds_pad_, abort_word, st));
 	}
 	if (!serial && wide && test_abort_)                   /* testing: see run_slot_cells */
 		HIP_TRY(hipMemsetAsync(arena_ + abort_off_, 1, 4, st));

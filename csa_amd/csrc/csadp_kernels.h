@@ -10,7 +10,9 @@ namespace csadp {
 
 /* csadp_bits.hip: bit-parallel first fills and their traceback; words = 32-column words per lane (1 .. 4: BitJob::wpl
  * of every job of the table).  One workgroup per job (at most 16 strips each) ... */
-hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st, int pack = 1);
+hipError_t launch_fill_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, int maxstrips, int lds_pad, int *abort_word, hipStream_t st);
+hipError_t launch_fill_bits_shared(int words, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *table, int nwgs, int lds_pad,
+                                   int *abort_word, hipStream_t st);
 /* ... or chunked: one workgroup per work item = (job, chunk of `waves` strips; 4, 8 or 16); `work` lists the items of
  * ONE pass, `passes` consecutive passes (job tables of njobs entries each) share a launch; epoch = a non-zero value
  * no earlier launch on this memory has used: it tags the hand-off granules between chunks */

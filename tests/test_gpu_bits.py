@@ -147,15 +147,17 @@ def test_pair_batch_pipelined_passes_agree(bits_mode):
 
 @pytest.mark.parametrize("words", ["1", "2", "3", "4"])
 def test_jobs_of_one_and_two_strips_share_workgroups(words, monkeypatch):
-    """Jobs of at most two strips share four-wave workgroups of nw_fill_bits (two per workgroup, four when every job is one strip;
-    csadp_bits.hip, PACK): an odd number of jobs (the last workgroup has an empty place), one- and two-strip jobs side by side, jobs
+    """Jobs narrower than four strips share four-wave workgroups of nw_fill_bits (first fit over a table of {job, strip} per wave;
+    csadp_bits.hip, PACK; csadp_engine.cpp, layout_bits): workgroups with empty places, one- to four-strip jobs side by side, jobs
     whose rows end long before their neighbour's, a batch of one-strip jobs only -- pipelined (several passes per launch) and alone,
-    packed and one workgroup per job (CSADP_BITS_PACK=0): the same rows, the oracle's."""
+    shared and one workgroup per job (CSADP_BITS_PACK=0): the same rows, the oracle's."""
     monkeypatch.setenv("CSADP_BITS_WORDS", words)
     r = rng(2200 + int(words))
     w = int(words)
     one, two = 2048 * w, 4096 * w                        # columns of one / two strips at this many words per lane
-    lens = [one - 7, two - 5, 3, one + 1, two, one, 60, one // 2, two - 1, one + 300, 900]     # 11 jobs: five and a half workgroups of two
+    lens = [one - 7, two - 5, 3, one + 1, two, one, 60, one // 2, two - 1, one + 300, 900]     # 11 jobs of one and two strips
+    if w <= 2:                                           # ... and of three and four (first fit: 4 | 3 + 1 | 2 + 2 | 2 + 1 + 1 | ...)
+        lens += [2 * two - 3, two + one - 11, two + 1, 2 * two, two + one]
     tasks = []
     for n in lens:
         a, b = related(r, n, n)                          # neither sequence longer than n: whichever becomes the columns fits the strips meant
