@@ -518,15 +518,18 @@ def unrelated_leg(csa_amd, steps=20, warmup=5):
 
 def small_pairs_leg(csa_amd, steps=48, warmup=8):
     """Batches of pairs narrower than a four-strip workgroup (what the anchors of the reference's pipeline leave between them when a set is
-    aligned pair by pair): 256 pairs of 8 192 letters (two strips at two words per lane) and 128 of 12 000 (two at three), with the jobs
-    sharing four-wave workgroups of nw_fill_bits (the default) and one workgroup per job (CSADP_BITS_PACK=0); properties checked on every result."""
+    aligned pair by pair): 256 pairs of 8 192 letters (two strips at two words per lane), 128 of 12 000 (two at three) and 256 of mixed
+    lengths (500-16 000: one to four strips), with the jobs sharing four-wave workgroups of nw_fill_bits by first fit (the default) and one
+    workgroup per job (CSADP_BITS_PACK=0); properties checked on every result."""
     from csa_amd.synth import synth_pair
     from helpers import degap, rotated, sp_score
     out = {}
-    for name, npairs, length in (("256_pairs_of_8192", 256, 8192), ("128_pairs_of_12000", 128, 12000)):
+    import random
+    mixed = random.Random(5)
+    for name, npairs, length in (("256_pairs_of_8192", 256, 8192), ("128_pairs_of_12000", 128, 12000), ("256_pairs_of_500_to_16000", 256, 0)):
         tasks = []
         for p in range(npairs):
-            a, b, ra, rb = synth_pair(90000 + p, length=length)
+            a, b, ra, rb = synth_pair(90000 + p, length=length or mixed.randrange(500, 16000))
             tasks.append(([a, b], [ra, rb], None, None))
         entry = {}
         for tag, pack in (("shared_workgroups", None), ("one_workgroup_per_job", "0")):
@@ -542,7 +545,7 @@ def small_pairs_leg(csa_amd, steps=48, warmup=8):
                           "passes_per_launch": tm["merge_group"], "launches_in_flight": tm["streams"], "properties_hold_for_all": bool(ok),
                           "recoveries": tm["recoveries"]}
         out[name] = entry
-    out["what"] = "pair jobs of at most two strips: two (or four) jobs per four-wave workgroup against one workgroup per job, 48 + 8 steps each"
+    out["what"] = "pair jobs narrower than four strips: jobs sharing four-wave workgroups (first fit) against one workgroup per job, 48 + 8 steps each"
     return out
 
 
