@@ -418,13 +418,20 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 	/* 4 words further than a multiple of the 64 banks from the inject rows: the first lane's 16 bytes and everybody else's never share a bank */
 	__shared__ __attribute__((aligned(16))) uint32_t konst[kBitBlock * kInjWords + 4];
 	__shared__ int made[WAVES], taken[WAVES];
-	static_assert(PACK == 1 || !WORK, "jobs share a workgroup only where a workgroup holds whole jobs");
 	const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-	int sw = wv;                                                 /* this wave's place among the waves of its job */
+	int sw = wv;                                                 /* this wave's place among the waves of its job's chunk */
 	int chunk = 0;
 	bool present = true;
 	const BitJob *jp;
-	if (WORK) {
+	if (WORK && PACK > 1) {
+		/* chunked launch with shared workgroups: whole chunks of wide jobs as before, their last, partial chunks and the narrow jobs of the
+		 * batch side by side in workgroups of their own; the table's strip index says which chunk a wave belongs to and where in it */
+		const TileRef item = work[(size_t)blockIdx.x * WAVES + wv];
+		present = item.job >= 0;
+		jp = &jobs[(size_t)blockIdx.y * njobs + (present ? item.job : 0)];
+		chunk = item.a / WAVES;
+		sw = item.a % WAVES;
+	} else if (WORK) {
 		const TileRef item = work[blockIdx.x];                   /* x: the work list of one pass, y: the pass */
 		jp = &jobs[(size_t)blockIdx.y * njobs + item.job];
 		chunk = item.a;
@@ -469,9 +476,9 @@ __global__ __launch_bounds__(WAVES *kLanes) void nw_fill_bits(uint8_t *__restric
 		}
 	}
 	const uint32_t b00 = __builtin_amdgcn_readfirstlane(B0[0]), b10 = __builtin_amdgcn_readfirstlane(B1[0]);
-	const bool feeds = (PACK > 1 || wv + 1 < WAVES) && s + 1 < J.nstrips;   /* a wave of this workgroup reads my ring (shared workgroups: a job's strips are all here) */
-	const bool publishes = WORK && wv + 1 == WAVES && s + 1 < J.nstrips;  /* the next chunk reads my granules */
-	const bool from_left_chunk = WORK && wv == 0 && chunk > 0;
+	const bool feeds = sw + 1 < WAVES && s + 1 < J.nstrips;              /* the next wave of this workgroup reads my ring */
+	const bool publishes = WORK && sw + 1 == WAVES && s + 1 < J.nstrips;  /* the next chunk reads my granules */
+	const bool from_left_chunk = WORK && sw == 0 && chunk > 0;
 	uint4 *ck = reinterpret_cast<uint4 *>(arena + J.ckpt);
 	uint2 *hand = reinterpret_cast<uint2 *>(arena + J.hand);
 	/* granules [chunk boundary][block][3] */
@@ -1040,6 +1047,12 @@ hipError_t launch_fill_w(bool chunked, uint8_t *arena, const BitJob *jobs, int n
 			return hipGetLastError();
 		}
 	}
+	if constexpr (WAVES == 4) {
+		if (chunked && threads < 0) {                     /* (launch_fill_bits_wide, shared: nwork workgroups of four table entries each) */
+			hipLaunchKernelGGL((nw_fill_bits<W, 4, true, 4>), dim3(nwork, passes), dim3(4 * kLanes), 0, st, arena, jobs, njobs, work, epoch, abort_word);
+			return hipGetLastError();
+		}
+	}
 	if (chunked) hipLaunchKernelGGL((nw_fill_bits<W, WAVES, true>), dim3(nwork, passes), dim3(WAVES * kLanes), 0, st, arena, jobs, njobs, work, epoch, abort_word);
 	else hipLaunchKernelGGL((nw_fill_bits<W, WAVES, false>), dim3(njobs), dim3(threads), passes, st, arena, jobs, njobs, work, epoch, abort_word);
 	return hipGetLastError();
@@ -1086,11 +1099,12 @@ hipError_t launch_fill_bits_shared(int words, uint8_t *arena, const BitJob *jobs
 }
 
 hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
-                                 uint32_t epoch, int *abort_word, hipStream_t st)
+                                 uint32_t epoch, int *abort_word, hipStream_t st, bool shared)
 {
 	if (njobs <= 0 || nwork <= 0 || passes <= 0) return hipSuccess;
 	if (epoch == 0) return hipErrorInvalidValue;           /* zeroed granules must never look valid */
-	return launch_fill_any(words, waves, true, arena, jobs, njobs, passes, waves * kLanes, work, nwork, epoch, abort_word, st);
+	if (shared && waves != 4) return hipErrorInvalidValue; /* `work`: four {job, strip} entries per workgroup, nwork workgroups */
+	return launch_fill_any(words, waves, true, arena, jobs, njobs, passes, shared ? -1 : waves * kLanes, work, nwork, epoch, abort_word, st);
 }
 
 hipError_t launch_traceback_bits(int words, uint8_t *arena, const BitJob *jobs, int njobs, hipStream_t st)

@@ -918,6 +918,7 @@ int FillBatch::layout_bits()
 	}
 	tiles_off_ = off;
 	chunk_first_.clear();
+	wide_shared_ = false;
 	if (!bits_wide_ && bits_pack_ > 1) {                 /* the table of the shared workgroups travels where a chunked launch has its work list */
 		tiles_ = shared_table_;
 		serial_tiles_.clear();
@@ -933,6 +934,82 @@ int FillBatch::layout_bits()
 		std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
 			return (long long)bjobs_[(size_t)a].steps_pad * bjobs_[(size_t)a].nstrips > (long long)bjobs_[(size_t)b].steps_pad * bjobs_[(size_t)b].nstrips;
 		});
+		/* ... in batches whose widest job is at most three chunks: with longer chains in the batch -- config 5: up to 33 strips -- the shared
+		 * form measures 3 % LOWER over eight alternating runs (41.4 against 42.6 TCUPS, profiles/r05_config5_pack_ab.txt) where batches of
+		 * jobs of up to ten strips gain 10-24 % (profiles/r05_pack_wide.txt); CSADP_BITS_PACK=2 shares whatever the widths */
+		wide_shared_ = cfg.bits_pack != 0 && bits_chunk_ == 4 && (bits_maxstrips_ <= 12 || cfg.bits_pack >= 2);
+		if (wide_shared_) {
+			/* Shared workgroups in a chunked launch (round 5): whole chunks as before; the LAST, partial chunk of a job and the jobs narrower
+			 * than a chunk go side by side into workgroups of their own, first fit in the order of the list, and such a workgroup follows the
+			 * chunks of the job that completed it (its members' producers are then all in front of it).  `tiles_` = four {job, strip}
+			 * entries per workgroup (job < 0: empty); `level` = the highest chunk index in a workgroup, for the repeat path. */
+			/* The tails of LONG chains stay alone: config 5 (jobs of up to 33 strips; its step is its longest chains) measured 43.3 TCUPS with
+			 * one workgroup per chunk and 37-42 with every tail shared (tools/r05/config5_pack_ab.py); batches of jobs of up to ten strips gain
+			 * 10-24 % (tools/r05/pack_wide.py). */
+			constexpr int kSharedTailChunks = 2;
+			std::vector<int> level;
+			TileRef none;
+			none.job = -1; none.a = 0; none.s = 0; none.first = 0;
+			struct Open { int at; int used; };
+			std::vector<Open> open;                               /* shared workgroups with room, by position in pending */
+			std::vector<std::vector<TileRef>> pending;            /* shared workgroups not yet emitted */
+			std::vector<int> pending_level;
+			auto emit = [&](const TileRef *four, int lv) {
+				tiles_.insert(tiles_.end(), four, four + 4);
+				level.push_back(lv);
+			};
+			for (int j : order) {
+				const int ns = bjobs_[(size_t)j].nstrips, full = ns / 4, rest = ns % 4;
+				for (int c = 0; c < full; ++c) {
+					TileRef four[4];
+					for (int w = 0; w < 4; ++w) { four[w] = none; four[w].job = j; four[w].a = 4 * c + w; }
+					emit(four, c);
+				}
+				if (rest == 0) continue;
+				if (full > kSharedTailChunks) {                   /* a long chain keeps its tail to itself (below) */
+					TileRef four[4] = {none, none, none, none};
+					for (int w = 0; w < rest; ++w) { four[w].job = j; four[w].a = 4 * full + w; }
+					emit(four, full);
+					continue;
+				}
+				int slot = -1;
+				for (size_t o = 0; o < open.size(); ++o)
+					if (4 - open[o].used >= rest) { slot = (int)o; break; }
+				if (slot < 0) {
+					pending.push_back(std::vector<TileRef>(4, none));
+					pending_level.push_back(0);
+					open.push_back(Open{(int)pending.size() - 1, 0});
+					slot = (int)open.size() - 1;
+				}
+				Open &O = open[(size_t)slot];
+				for (int w = 0; w < rest; ++w) {
+					TileRef &t = pending[(size_t)O.at][(size_t)(O.used + w)];
+					t.job = j;
+					t.a = 4 * full + w;
+				}
+				O.used += rest;
+				pending_level[(size_t)O.at] = std::max(pending_level[(size_t)O.at], full);
+				if (O.used == 4) {                                /* complete: it goes out behind this job's chunks */
+					emit(pending[(size_t)O.at].data(), pending_level[(size_t)O.at]);
+					pending[(size_t)O.at].clear();
+					open.erase(open.begin() + slot);
+				}
+			}
+			for (const Open &O : open) emit(pending[(size_t)O.at].data(), pending_level[(size_t)O.at]);
+			off = align_up(off + tiles_.size() * sizeof(TileRef), 256);
+			serial_off_ = off;
+			std::vector<int> by_level(level.size());
+			for (size_t i = 0; i < by_level.size(); ++i) by_level[i] = (int)i;
+			std::stable_sort(by_level.begin(), by_level.end(), [&](int a, int b) { return level[(size_t)a] < level[(size_t)b]; });
+			std::vector<TileRef> serial;
+			for (size_t i = 0; i < by_level.size(); ++i) {
+				if (i == 0 || level[(size_t)by_level[i]] != level[(size_t)by_level[i - 1]]) chunk_first_.push_back(4 * i);
+				serial.insert(serial.end(), tiles_.begin() + 4 * by_level[i], tiles_.begin() + 4 * by_level[i] + 4);
+			}
+			chunk_first_.push_back(serial.size());
+			serial_tiles_.swap(serial);
+			off = align_up(off + serial_tiles_.size() * sizeof(TileRef), 256);
+		} else {
 		for (int j : order)
 			for (int c = 0; c * bits_chunk_ < bjobs_[(size_t)j].nstrips; ++c) {
 				TileRef t;
@@ -953,6 +1030,7 @@ int FillBatch::layout_bits()
 		chunk_first_.push_back(serial.size());
 		serial_tiles_.swap(serial);
 		off = align_up(off + serial_tiles_.size() * sizeof(TileRef), 256);
+		}
 	}
 	if (io_) {
 		/* inputs = the raw texts (each once) + one status word per job; the planes are per-slot scratch
@@ -1345,13 +1423,16 @@ int FillBatch::launch_bits_pass(int first, int g, hipStream_t st, hipStream_t si
 	if (wide) {
 		/* hand-off words between the chunks of a job carry this pass' epoch (see nw_fill_bits_wide) */
 		const uint32_t epoch = Engine::next_epoch();
+		/* (shared workgroups: four table entries per workgroup, the lists count entries) */
+		const bool shared = wide_shared_ && !lone;
+		const int per = shared ? 4 : 1;
 		if (!serial) {
-			HIP_TRY(launch_fill_bits_wide(words, chunk, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off), (int)ntiles, epoch,
-			                              abort_word, st));
+			HIP_TRY(launch_fill_bits_wide(words, chunk, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + tiles_off), (int)ntiles / per, epoch,
+			                              abort_word, st, shared));
 		} else {
 			for (size_t c = 0; c + 1 < chunk_first.size(); ++c)
 				HIP_TRY(launch_fill_bits_wide(words, chunk, arena_, bj, nj, g, reinterpret_cast<const TileRef *>(arena_ + serial_off) + chunk_first[c],
-				                              (int)(chunk_first[c + 1] - chunk_first[c]), epoch, abort_word, st));
+				                              (int)(chunk_first[c + 1] - chunk_first[c]) / per, epoch, abort_word, st, shared));
 		}
 	} else {
 		if (!lone && bits_pack_ > 1)

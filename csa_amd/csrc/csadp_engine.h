@@ -202,6 +202,7 @@ private:
 	int launch_bits_pass(int first, int g, hipStream_t st, hipStream_t side, bool serial, bool lone = false);
 	int check_abort();
 	int bits_group_ = 1, last_group_ = 1, bits_streams_ = 2, next_stream_ = 0, recoveries_ = 0, bits_pack_ = 1;
+	bool wide_shared_ = false;                    /* chunked launch: tiles_ holds four {job, strip} entries per workgroup */
 	std::vector<TileRef> shared_table_;           /* bits_pack_ > 1: one {job, strip} per wave of the shared workgroups of a pass */
 	int bits_words_ = 1;                          /* words of 32 columns per lane of this batch's bit-parallel kernels */
 	int bits_lds_pad_ = 0;                        /* dynamic LDS a one-workgroup-per-job fill launch reserves on top (bounds the workgroups per compute unit) */

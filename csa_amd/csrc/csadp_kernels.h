@@ -17,7 +17,7 @@ hipError_t launch_fill_bits_shared(int words, uint8_t *arena, const BitJob *jobs
  * ONE pass, `passes` consecutive passes (job tables of njobs entries each) share a launch; epoch = a non-zero value
  * no earlier launch on this memory has used: it tags the hand-off granules between chunks */
 hipError_t launch_fill_bits_wide(int words, int waves, uint8_t *arena, const BitJob *jobs, int njobs, int passes, const TileRef *work, int nwork,
-                                 uint32_t epoch, int *abort_word, hipStream_t st);
+                                 uint32_t epoch, int *abort_word, hipStream_t st, bool shared = false);
 int fill_bits_lds_bytes(int waves);          /* static LDS of a fill workgroup */
 int traceback_bits_lds_bytes(int words);    /* ... of a traceback workgroup */
 /* scores: the replay traceback also sums the move scores of its path into summary[3] */
