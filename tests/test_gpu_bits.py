@@ -429,6 +429,42 @@ def test_abort_word_triggers_the_chunk_by_chunk_repeat(monkeypatch, capfd):
         assert g["status"] == 0 and g["consensus"] == cons and g["aligned"] == strs and g["score"] == st.last_score
 
 
+@pytest.mark.parametrize("forced", [False, True])
+def test_chunked_launch_with_shared_workgroups(forced, monkeypatch, capfd):
+    """A batch with jobs wider than four strips is a chunked launch; the last, partial chunk of a job and the jobs narrower than a chunk share
+    workgroups there too (a table of {job, strip} per wave; csadp_engine.cpp, layout_bits): at one word per lane 13 pairs of one to ten strips
+    -- tails of one, two and three strips, whole narrow jobs, a job of exactly two chunks -- pipelined and alone, shared and one workgroup per
+    chunk (CSADP_BITS_PACK=0), and once more with the abort word raised behind every launch (the repeat path takes the table level by level):
+    the same rows, the oracle's."""
+    monkeypatch.setenv("CSADP_BITS_WORDS", "1")
+    r = rng(3300)
+    strip = 2048
+    lens = [5 * strip - 9, 900, 6 * strip + 1, 2 * strip, 9 * strip + 700, 3 * strip - 1, 8 * strip, 40, 7 * strip - 300, strip + 5, 4 * strip + 1, 10 * strip - 3, 3000]
+    tasks = []
+    for n in lens:
+        a, b = related(r, n, n)
+        tasks.append(([a, b], [r.randrange(len(a)), r.randrange(len(b))], None, None))
+    want = [oracle_progressive(t[0], t[1]) for t in tasks]
+    if forced:
+        monkeypatch.setenv("CSADP_TEST_FORCE_ABORT", "1")
+    rows = None
+    for pack in ("1", "0"):
+        monkeypatch.setenv("CSADP_BITS_PACK", pack)
+        pb = csa_amd.PairBatch(tasks)
+        for passes in (1, 5):
+            for _ in range(passes):
+                pb.run()
+            pb.sync()
+            got = pb.fetch()
+            for g, (cons, strs, st) in zip(got, want):
+                assert g["status"] == 0 and g["aligned"] == strs and g["score"] == st.last_score and g["consensus"] == cons, (pack, passes)
+            assert rows is None or rows == [g["aligned"] for g in got]
+            rows = [g["aligned"] for g in got]
+        pb.close()
+    if forced:
+        assert "repeating the pass chunk by chunk" in capfd.readouterr().err
+
+
 @pytest.mark.parametrize("slow", [1, 4])
 def test_publisher_wave_that_falls_behind_its_strip(slow, monkeypatch):
     """Helper-wave layout of nw_fill_cells (launches of at most 256 workgroups): a chunk's last strip hands its values to the
